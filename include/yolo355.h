@@ -1,0 +1,153 @@
+/*
+ * yolo355.h — C ABI of libyolo355.so: the MI355X (gfx950) YOLOv3 hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (wizyoung/YOLOv3_TensorFlow) has no FFI of its own: its boundary is the Python
+ * API of model.py and the utils package, whose arithmetic executes inside TensorFlow.  Each
+ * entry point below names the reference interface (file:line under /root/reference)
+ * whose TensorFlow-side execution it replaces.  The Python mirror of that API lives
+ * in yolov3_tensorflow_amd/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain C, no torch/TF types: device pointers + sizes only;
+ *   - every call returns 0 on success, a negative Y3_E* code otherwise; the message
+ *     is available from y3_last_error() (thread-local);
+ *   - the caller owns every device buffer; the library allocates no device memory
+ *     and keeps no pointer beyond the call, except the per-layer parameter pointers
+ *     registered in a y3_net (which the caller must keep alive);
+ *   - activations are NHWC fp32 contiguous; conv kernels in TF layout are HWIO
+ *     (utils/misc_utils.py:117-120) and are re-packed once by y3_pack_conv_weights;
+ *   - every launch goes to the hipStream_t bound to the context; no call synchronises
+ *     the host except y3_nms_counts_to_host-style helpers that say so.
+ */
+#ifndef YOLO355_H
+#define YOLO355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y3_OK 0
+#define Y3_EINVAL (-1)   /* bad argument / unsupported shape (maps to ValueError / InvalidArgumentError) */
+#define Y3_EHIP (-2)     /* a HIP runtime call failed */
+#define Y3_ESTATE (-3)   /* object used before it was fully configured */
+
+#define Y3_ABI_VERSION 1
+
+typedef struct y3_ctx y3_ctx; /* one per (device, stream) */
+typedef struct y3_net y3_net; /* the 75-conv YOLOv3 graph bound to caller-owned parameters */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* y3_last_error(void);
+int y3_abi_version(void);
+
+/* stream: a hipStream_t (0 = the null stream).  The library never creates streams. */
+int y3_ctx_create(int device, void* stream, y3_ctx** out);
+int y3_ctx_destroy(y3_ctx* ctx);
+
+/* ---- parameter preparation (one-off, utils/misc_utils.py:114-124 produces HWIO) ---------------
+ * w_hwio [k][k][cin][cout]  ->  w_packed [k*k][cout][cin]   (cin contiguous: 16-B loads along K).
+ * For the Cin==3 stem conv the kernel consumes HWIO directly and no packing is needed. */
+int y3_pack_conv_weights(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, float* w_packed);
+
+/* Inference batch-norm folding (model.py:35-41, eps=1e-5):
+ *   scale = gamma * rsqrt(var + eps) ; shift = beta - mean * scale                              */
+int y3_bn_fold(y3_ctx* ctx, const float* gamma, const float* beta, const float* mean,
+               const float* var, float eps, int c, float* scale, float* shift);
+
+/* ---- a1-a4: conv2d + BN + LeakyReLU (+ residual) (+ fused upsample/concat input) ---------------
+ * Replaces utils/layer_utils.py:9-22 `conv2d` (slim.conv2d + batch_norm + leaky_relu, model.py:43-49),
+ * the residual add of `res_block` (utils/layer_utils.py:25-32), `upsample_layer` (:82-87) and the
+ * channel concat of model.py:62,72.
+ *
+ *   y = act(conv(x, w) * scale + shift) + residual
+ *
+ * k in {1,3}; stride 1 -> SAME; stride 2 -> explicit zero pad 1 each side then VALID
+ * (utils/layer_utils.py:10-21), i.e. input row = oy*stride + ky - (k/2) in both cases.
+ * If x_up != NULL (k must be 1): the logical input is concat([nearest_up2x(x_up), x], axis=3),
+ * x_up is [N, H/2, W/2, c_up], x is [N, H, W, cin - c_up]; never materialised.
+ * act: 0 = linear (detection convs, model.py:55-57), 1 = LeakyReLU(0.1).
+ * scale/shift are per-output-channel (folded BN, or scale=1/shift=bias); residual may be NULL. */
+typedef struct y3_conv_desc {
+    int n, h, w;   /* logical input spatial size (after upsample for the fused-concat case) */
+    int cin;       /* logical input channels (c_up + channels of x) */
+    int c_up;      /* channels coming from x_up (0 if none) */
+    int cout;
+    int k;         /* 1 or 3 */
+    int stride;    /* 1 or 2 */
+    int act;       /* 0 linear, 1 leaky(0.1) */
+} y3_conv_desc;
+
+int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
+                  const float* w, const float* scale, const float* shift, const float* residual,
+                  float* y);
+
+/* ---- unfused graph ops, for callers composing the network op by op (utils/layer_utils.py) ---------
+ * y3_net_forward never launches these (it fuses them into the neighbouring convs).
+ * y3_upsample_nearest : tf.image.resize_nearest_neighbor, align_corners=False (utils/layer_utils.py:82-87)
+ * y3_concat_channels  : tf.concat([a, b], axis=3) on NHWC with `rows` = N*H*W (model.py:62,72)
+ * y3_add              : net + shortcut (utils/layer_utils.py:30)
+ * y3_reorg_boxes      : box part of reorg_layer for one scale (model.py:96-131):
+ *                       boxes [N,gh,gw,3,4] = (cx,cy,w,h) in input pixels; anchors3 = the 3 (w,h) pairs. */
+int y3_upsample_nearest(y3_ctx* ctx, const float* x, int n, int h, int w, int c, int out_h, int out_w,
+                        float* y);
+int y3_concat_channels(y3_ctx* ctx, const float* a, int ca, const float* b, int cb, long long rows, float* y);
+int y3_add(y3_ctx* ctx, const float* a, const float* b, long long count, float* y);
+int y3_reorg_boxes(y3_ctx* ctx, const float* fm, int n, int gh, int gw, int class_num, int img_h, int img_w,
+                   const float* anchors3_host, float* boxes);
+
+/* ---- a6-a8: reorg_layer + predict (+ conf*prob) ------------------------------------------------
+ * Replaces model.py:82-137 / :140-190 and the score product of test_single_image.py:55.
+ * fm_s: [N, H/stride_s, W/stride_s, 3*(5+C)] for strides 32,16,8 (in that order).
+ * anchors: 9 (w,h) pairs in data/yolo_anchors.txt order; scale s uses anchors[6-3s .. 8-3s].
+ * boxes [N,B,4] = (x_min,y_min,x_max,y_max); confs [N,B,1]; probs [N,B,C]; scores [N,B,C] or NULL.
+ * B = 3*(g1^2+g2^2+g3^2), box order = scale (13,26,52), then y, x, anchor (model.py:155-180). */
+int y3_decode(y3_ctx* ctx, const float* fm1, const float* fm2, const float* fm3, int n, int h, int w,
+              int class_num, const float* anchors_host18, float* boxes, float* confs, float* probs,
+              float* scores);
+
+/* ---- a9/a10: per-class NMS ---------------------------------------------------------------------
+ * mode Y3_NMS_TF : utils/nms_utils.py:8-48 `gpu_nms` = per class {score >= thresh,
+ *                  tf.image.non_max_suppression (IoU without +1, suppress if IoU > thresh)}.
+ * mode Y3_NMS_PY : utils/nms_utils.py:51-123 `cpu_nms`/`py_nms` (+1 on intersection w/h only,
+ *                  keep while ovr <= thresh).
+ * Tie-break in both modes: (score descending, box index ascending).
+ * Batched over n images (the reference handles one image per call; n=1 reproduces it).
+ * Outputs per image i, concatenated by class ascending, selection order within a class:
+ *   out_boxes [n][cap][4], out_scores [n][cap], out_labels [n][cap] (int32),
+ *   out_index [n][cap] (int32 box index into the B inputs; NULL to skip), out_counts [n] (int32),
+ *   with cap = class_num * max_boxes.  All device pointers; counts are read by the caller. */
+#define Y3_NMS_TF 0
+#define Y3_NMS_PY 1
+size_t y3_nms_workspace_bytes(int n, int num_boxes, int class_num, int max_boxes);
+int y3_nms(y3_ctx* ctx, int mode, const float* boxes, const float* scores, int n, int num_boxes,
+           int class_num, int max_boxes, float score_thresh, float iou_thresh, void* workspace,
+           size_t workspace_bytes, float* out_boxes, float* out_scores, int32_t* out_labels,
+           int32_t* out_index, int32_t* out_counts);
+
+/* ---- a5: yolov3.forward (model.py:30-80) as one call -------------------------------------------
+ * The graph is fixed by class_num: 52 backbone convs (utils/layer_utils.py:24-68) + 23 head convs
+ * (model.py:53-78), indexed 0..74 in variable-creation order (= darknet file order).
+ * Per layer the caller registers device pointers: packed weights (HWIO for layer 0), scale, shift. */
+int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out);
+int y3_net_destroy(y3_net* net);
+int y3_net_num_layers(const y3_net* net);
+/* geometry of layer i for input-independent fields: k, stride, cin, cout, has_bn */
+int y3_net_layer_info(const y3_net* net, int i, int* k, int* stride, int* cin, int* cout, int* has_bn);
+int y3_net_set_layer(y3_net* net, int i, const float* w_packed, const float* scale, const float* shift);
+size_t y3_net_workspace_bytes(const y3_net* net, int n, int h, int w);
+/* x [n,h,w,3] -> fm1 [n,h/32,w/32,3*(5+C)], fm2 (/16), fm3 (/8).  h,w multiples of 32. */
+int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* workspace,
+                   size_t workspace_bytes, float* fm1, float* fm2, float* fm3);
+/* Optional per-layer timing with hipEvents on the context stream: after a forward with
+ * profiling enabled, ms[i] holds layer i's elapsed time (synchronises the stream). */
+int y3_net_set_profiling(y3_net* net, int enabled);
+int y3_net_get_layer_ms(y3_net* net, float* ms, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO355_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libyolo355.so (include/yolo355.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every op raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libyolo355.so")
+
+Y3_OK, Y3_EINVAL, Y3_EHIP, Y3_ESTATE = 0, -1, -2, -3
+Y3_NMS_TF, Y3_NMS_PY = 0, 1
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("n", "h", "w", "cin", "c_up", "cout", "k", "stride", "act")]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
+PROTOTYPES = {
+    "y3_last_error": (c_char_p, []),
+    "y3_abi_version": (c_int, []),
+    "y3_ctx_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "y3_ctx_destroy": (c_int, [c_void_p]),
+    "y3_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "y3_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "y3_conv2d_fwd": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "y3_upsample_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "y3_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong, c_void_p]),
+    "y3_add": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "y3_reorg_boxes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                               POINTER(c_float), c_void_p]),
+    "y3_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                          POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_nms_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "y3_nms": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                       c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_net_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "y3_net_destroy": (c_int, [c_void_p]),
+    "y3_net_num_layers": (c_int, [c_void_p]),
+    "y3_net_layer_info": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                  POINTER(c_int), POINTER(c_int)]),
+    "y3_net_set_layer": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "y3_net_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "y3_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                               c_void_p, c_void_p]),
+    "y3_net_set_profiling": (c_int, [c_void_p, c_int]),
+    "y3_net_get_layer_ms": (c_int, [c_void_p, POINTER(c_float), c_int]),
+}
+
+_lib = None
+
+
+class Y3Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Y3Error(
+                "libyolo355.so is not built (%s). Run `python -m yolov3_tensorflow_amd.build` "
+                "(needs hipcc). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.y3_abi_version() != 1:
+            raise Y3Error("libyolo355.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a C status to the exception types the reference's callers see."""
+    if rc == Y3_OK:
+        return
+    msg = lib().y3_last_error().decode(errors="replace")
+    if rc == Y3_EINVAL:
+        raise ValueError(msg)
+    raise Y3Error("%s (status %d)" % (msg, rc))

@@ -1,0 +1,335 @@
+// Host side of the C ABI: error channel, contexts, the conv entry point and the y3_net graph
+// (yolov3.forward, model.py:30-80 of the reference, as a fixed launch plan over caller-owned buffers).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "y3_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void y3_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* y3_last_error(void) { return g_err; }
+extern "C" int y3_abi_version(void) { return Y3_ABI_VERSION; }
+
+extern "C" int y3_ctx_create(int device, void* stream, y3_ctx** out) {
+    Y3_CHECK_ARG(out, "y3_ctx_create: null out pointer");
+    int count = 0;
+    Y3_CHECK_HIP(hipGetDeviceCount(&count));
+    Y3_CHECK_ARG(device >= 0 && device < count, "y3_ctx_create: device %d out of range (have %d)", device,
+                 count);
+    Y3_CHECK_HIP(hipSetDevice(device));
+    y3_ctx* c = new y3_ctx;
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(stream);
+    *out = c;
+    return Y3_OK;
+}
+
+extern "C" int y3_ctx_destroy(y3_ctx* ctx) {
+    delete ctx;
+    return Y3_OK;
+}
+
+extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
+                             const float* w, const float* scale, const float* shift,
+                             const float* residual, float* y) {
+    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd: null context");
+    return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y3_net: the 75-conv graph.  Tensor ids: 0 = network input; 1.. = conv outputs in creation order.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Tensor {
+    int c;        // channels
+    int sdiv;     // spatial divisor relative to the input (1,2,4,8,16,32)
+    int last_use; // index of the last layer reading it (-1: never read)
+    int ext;      // >=0: external output slot (fm1..fm3), storage provided by the caller
+};
+
+struct Layer {
+    int k, stride, cin, cout, bn, act;
+    int src, up, resid, dst;  // tensor ids (-1 = none)
+    int c_up;
+    const float *w, *scale, *shift;
+};
+
+}  // namespace
+
+struct y3_net {
+    y3_ctx* ctx;
+    int class_num;
+    std::vector<Tensor> tensors;
+    std::vector<Layer> layers;
+    // cached plan
+    int pn = 0, ph = 0, pw = 0;
+    std::vector<size_t> offsets;  // byte offset of each tensor in the workspace (SIZE_MAX if external)
+    size_t plan_bytes = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    bool events_valid = false;
+
+    int add_conv(int src, int cout, int k, int stride = 1, bool bn = true, bool act = true, int resid = -1,
+                 int up = -1) {
+        Layer l;
+        l.k = k; l.stride = stride; l.cout = cout; l.bn = bn; l.act = act;
+        l.src = src; l.up = up; l.resid = resid;
+        l.c_up = up >= 0 ? tensors[up].c : 0;
+        l.cin = tensors[src].c + l.c_up;
+        l.w = l.scale = l.shift = nullptr;
+        Tensor t;
+        t.c = cout; t.sdiv = tensors[src].sdiv * stride; t.last_use = -1; t.ext = -1;
+        tensors.push_back(t);
+        l.dst = (int)tensors.size() - 1;
+        const int li = (int)layers.size();
+        tensors[src].last_use = li;
+        if (up >= 0) tensors[up].last_use = li;
+        if (resid >= 0) tensors[resid].last_use = li;
+        layers.push_back(l);
+        return l.dst;
+    }
+    // utils/layer_utils.py:25-32
+    int res_block(int x, int f) {
+        const int a = add_conv(x, f, 1);
+        return add_conv(a, 2 * f, 3, 1, true, true, /*resid=*/x);
+    }
+    // utils/layer_utils.py:71-79 ; `up` >= 0 means the input is concat([upsample(up), x])
+    void yolo_block(int x, int f, int up, int* route, int* net) {
+        int t = add_conv(x, f, 1, 1, true, true, -1, up);
+        t = add_conv(t, 2 * f, 3);
+        t = add_conv(t, f, 1);
+        t = add_conv(t, 2 * f, 3);
+        t = add_conv(t, f, 1);
+        *route = t;
+        *net = add_conv(t, 2 * f, 3);
+    }
+    void build() {
+        tensors.clear(); layers.clear();
+        tensors.push_back(Tensor{3, 1, -1, -1});
+        // utils/layer_utils.py:34-68 darknet53_body
+        int t = add_conv(0, 32, 3);
+        t = add_conv(t, 64, 3, 2);
+        t = res_block(t, 32);
+        t = add_conv(t, 128, 3, 2);
+        for (int i = 0; i < 2; ++i) t = res_block(t, 64);
+        t = add_conv(t, 256, 3, 2);
+        for (int i = 0; i < 8; ++i) t = res_block(t, 128);
+        const int route1 = t;
+        t = add_conv(t, 512, 3, 2);
+        for (int i = 0; i < 8; ++i) t = res_block(t, 256);
+        const int route2 = t;
+        t = add_conv(t, 1024, 3, 2);
+        for (int i = 0; i < 4; ++i) t = res_block(t, 512);
+        const int route3 = t;
+        // model.py:53-78 yolov3_head
+        const int det = 3 * (5 + class_num);
+        int inter1, net1, inter2, net2, inter3, net3;
+        yolo_block(route3, 512, -1, &inter1, &net1);
+        const int fm1 = add_conv(net1, det, 1, 1, false, false);
+        tensors[fm1].ext = 0;
+        const int i1 = add_conv(inter1, 256, 1);
+        yolo_block(route2, 256, i1, &inter2, &net2);
+        const int fm2 = add_conv(net2, det, 1, 1, false, false);
+        tensors[fm2].ext = 1;
+        const int i2 = add_conv(inter2, 128, 1);
+        yolo_block(route1, 128, i2, &inter3, &net3);
+        const int fm3 = add_conv(net3, det, 1, 1, false, false);
+        tensors[fm3].ext = 2;
+    }
+
+    size_t tensor_bytes(int id, int n, int h, int w) const {
+        const Tensor& t = tensors[id];
+        return (size_t)n * (h / t.sdiv) * (w / t.sdiv) * t.c * sizeof(float);
+    }
+
+    // Liveness-based arena: a tensor's bytes are recycled after its last reader has been launched
+    // (same stream => ordered), keeping the working set small enough to sit in the 256 MB Infinity Cache
+    // for the deeper layers.
+    void plan(int n, int h, int w) {
+        if (n == pn && h == ph && w == pw) return;
+        struct Free { size_t off, size; };
+        std::vector<Free> freelist;
+        std::vector<char> live(tensors.size(), 0);
+        size_t top = 0, peak = 0;
+        offsets.assign(tensors.size(), SIZE_MAX);
+        auto rounded = [&](int id) { return (tensor_bytes(id, n, h, w) + 255) & ~(size_t)255; };
+        auto release = [&](size_t off, size_t size) {
+            freelist.push_back({off, size});
+            std::sort(freelist.begin(), freelist.end(),
+                      [](const Free& a, const Free& b) { return a.off < b.off; });
+            std::vector<Free> merged;
+            for (const Free& f : freelist) {
+                if (!merged.empty() && merged.back().off + merged.back().size == f.off)
+                    merged.back().size += f.size;
+                else
+                    merged.push_back(f);
+            }
+            if (!merged.empty() && merged.back().off + merged.back().size == top) {
+                top = merged.back().off;  // give the tail back to the bump pointer
+                merged.pop_back();
+            }
+            freelist.swap(merged);
+        };
+        for (size_t li = 0; li < layers.size(); ++li) {
+            const Layer& l = layers[li];
+            for (size_t t = 1; t < tensors.size(); ++t)
+                if (live[t] && tensors[t].last_use < (int)li) {
+                    release(offsets[t], rounded((int)t));
+                    live[t] = 0;
+                }
+            if (tensors[l.dst].ext >= 0) continue;
+            const size_t need = rounded(l.dst);
+            size_t best = SIZE_MAX, best_size = SIZE_MAX;
+            for (size_t f = 0; f < freelist.size(); ++f)
+                if (freelist[f].size >= need && freelist[f].size < best_size) {
+                    best = f;
+                    best_size = freelist[f].size;
+                }
+            if (best != SIZE_MAX) {
+                offsets[l.dst] = freelist[best].off;
+                freelist[best].off += need;
+                freelist[best].size -= need;
+                if (freelist[best].size == 0) freelist.erase(freelist.begin() + best);
+            } else {
+                offsets[l.dst] = top;
+                top += need;
+            }
+            live[l.dst] = 1;
+            peak = std::max(peak, top);
+        }
+        plan_bytes = peak;
+        pn = n; ph = h; pw = w;
+    }
+};
+
+extern "C" int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out) {
+    Y3_CHECK_ARG(ctx && out, "y3_net_create: null argument");
+    Y3_CHECK_ARG(class_num > 0, "y3_net_create: class_num must be positive");
+    y3_net* net = new y3_net;
+    net->ctx = ctx;
+    net->class_num = class_num;
+    net->build();
+    *out = net;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_destroy(y3_net* net) {
+    if (net) {
+        for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+        delete net;
+    }
+    return Y3_OK;
+}
+
+extern "C" int y3_net_num_layers(const y3_net* net) { return net ? (int)net->layers.size() : 0; }
+
+extern "C" int y3_net_layer_info(const y3_net* net, int i, int* k, int* stride, int* cin, int* cout,
+                                 int* has_bn) {
+    Y3_CHECK_ARG(net && i >= 0 && i < (int)net->layers.size(), "y3_net_layer_info: bad layer index %d", i);
+    const Layer& l = net->layers[i];
+    if (k) *k = l.k;
+    if (stride) *stride = l.stride;
+    if (cin) *cin = l.cin;
+    if (cout) *cout = l.cout;
+    if (has_bn) *has_bn = l.bn;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_set_layer(y3_net* net, int i, const float* w_packed, const float* scale,
+                                const float* shift) {
+    Y3_CHECK_ARG(net && i >= 0 && i < (int)net->layers.size(), "y3_net_set_layer: bad layer index %d", i);
+    Y3_CHECK_ARG(w_packed && scale && shift, "y3_net_set_layer: null parameter pointer");
+    Layer& l = net->layers[i];
+    l.w = w_packed; l.scale = scale; l.shift = shift;
+    return Y3_OK;
+}
+
+static int check_size(const char* who, int n, int h, int w) {
+    Y3_CHECK_ARG(n > 0, "%s: batch must be positive", who);
+    Y3_CHECK_ARG(h > 0 && w > 0 && h % 32 == 0 && w % 32 == 0,
+                 "%s: input size must be a positive multiple of 32 (got %dx%d)", who, h, w);
+    return Y3_OK;
+}
+
+extern "C" size_t y3_net_workspace_bytes(const y3_net* net, int n, int h, int w) {
+    if (!net || check_size("y3_net_workspace_bytes", n, h, w) != Y3_OK) return 0;
+    const_cast<y3_net*>(net)->plan(n, h, w);
+    return net->plan_bytes;
+}
+
+extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* workspace,
+                              size_t workspace_bytes, float* fm1, float* fm2, float* fm3) {
+    Y3_CHECK_ARG(net && x && workspace && fm1 && fm2 && fm3, "y3_net_forward: null argument");
+    if (int rc = check_size("y3_net_forward", n, h, w)) return rc;
+    net->plan(n, h, w);
+    Y3_CHECK_ARG(workspace_bytes >= net->plan_bytes, "y3_net_forward: workspace too small (%zu < %zu)",
+                 workspace_bytes, net->plan_bytes);
+    Y3_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "y3_net_forward: workspace must be 256-byte aligned");
+    for (size_t i = 0; i < net->layers.size(); ++i)
+        if (!net->layers[i].w) {
+            y3_set_error("y3_net_forward: layer %zu has no parameters (call y3_net_set_layer)", i);
+            return Y3_ESTATE;
+        }
+    float* ext[3] = {fm1, fm2, fm3};
+    char* base = static_cast<char*>(workspace);
+    auto ptr = [&](int id) -> float* {
+        if (id < 0) return nullptr;
+        if (id == 0) return const_cast<float*>(x);
+        const Tensor& t = net->tensors[id];
+        if (t.ext >= 0) return ext[t.ext];
+        return reinterpret_cast<float*>(base + net->offsets[id]);
+    };
+    hipStream_t st = net->ctx->stream;
+    const size_t nl = net->layers.size();
+    if (net->profiling && net->events.size() != nl + 1) {
+        for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+        net->events.assign(nl + 1, nullptr);
+        for (size_t i = 0; i <= nl; ++i) Y3_CHECK_HIP(hipEventCreate(&net->events[i]));
+    }
+    net->events_valid = false;
+    if (net->profiling) Y3_CHECK_HIP(hipEventRecord(net->events[0], st));
+    for (size_t i = 0; i < nl; ++i) {
+        const Layer& l = net->layers[i];
+        const Tensor& in = net->tensors[l.src];
+        y3_conv_desc d;
+        d.n = n; d.h = h / in.sdiv; d.w = w / in.sdiv;
+        d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
+        const int rc = y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
+                                      ptr(l.dst));
+        if (rc != Y3_OK) return rc;
+        if (net->profiling) Y3_CHECK_HIP(hipEventRecord(net->events[i + 1], st));
+    }
+    net->events_valid = net->profiling;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_set_profiling(y3_net* net, int enabled) {
+    Y3_CHECK_ARG(net, "y3_net_set_profiling: null net");
+    net->profiling = enabled != 0;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, int count) {
+    Y3_CHECK_ARG(net && ms, "y3_net_get_layer_ms: null argument");
+    Y3_CHECK_ARG(count == (int)net->layers.size(), "y3_net_get_layer_ms: count must be %zu",
+                 net->layers.size());
+    if (!net->events_valid) {
+        y3_set_error("y3_net_get_layer_ms: no profiled forward has run");
+        return Y3_ESTATE;
+    }
+    Y3_CHECK_HIP(hipEventSynchronize(net->events[count]));
+    for (int i = 0; i < count; ++i)
+        Y3_CHECK_HIP(hipEventElapsedTime(&ms[i], net->events[i], net->events[i + 1]));
+    return Y3_OK;
+}

@@ -1,0 +1,346 @@
+// conv2d + folded-BN + LeakyReLU (+ residual) (+ fused nearest-upsample/concat input) for gfx950.
+//
+// Replaces the TensorFlow execution of utils/layer_utils.py:9-22 (conv2d), :25-32 (res_block add),
+// :82-87 (upsample_layer) and model.py:62,72 (concat) of the reference.
+//
+// Design (MI355X-first, not a port of anything):
+//   * implicit GEMM, M = N*Ho*Wo output pixels, N = Cout, K = k*k*Cin, never materialising im2col,
+//     the padded tensor, the upsampled tensor or the concat;
+//   * fp32-in/fp32-accumulate MFMA v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s chip peak): the fp32
+//     forward is matrix-pipe bound, so the tile is sized to keep the matrix pipe busy:
+//     128 x {128,64,32} block tile, BK = 32, 4 waves, each wave a grid of 32x32 MFMA tiles;
+//   * NHWC activations give 16-byte-per-lane loads along Cin; weights are pre-packed
+//     [tap][Cout][Cin] so the B tile is loaded exactly like the A tile;
+//   * LDS tiles are [rows][BK+4] floats: one ds_read_b128 per lane feeds FOUR k-steps of the MFMA
+//     (lane l holds k = 4*(l>>5)+j for step j on both operands) and the +4 pad makes the 16-lane
+//     groups of ds_read_b128 bank-conflict free;
+//   * double-buffered LDS with register prefetch of tile t+1 during the MFMAs of tile t: one
+//     barrier per K-step;
+//   * epilogue fused in registers: scale/shift (folded BN or bias), LeakyReLU(0.1), residual add.
+#include "y3_internal.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x;      // [N,H,W,Cx]  (Cx = Cin - Cu)
+    const float* xu;     // [N,H/2,W/2,Cu] or nullptr
+    const float* w;      // packed [taps][Cout][Cin]   (stem: HWIO [27][32])
+    const float* scale;  // [Cout]
+    const float* shift;  // [Cout]
+    const float* resid;  // [M,Cout] or nullptr
+    float* y;            // [M,Cout]
+    int N, H, W, Cin, Cu, Cx;
+    int Ho, Wo, Cout;
+    int stride, pad, act;
+    int M;
+};
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
+__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
+    constexpr int MI = WTM / 32, NI = WTN / 32;    // 32x32 MFMA tiles per wave
+    constexpr int AROWS = BM / 32, BROWS = BN / 32;  // float4 rows each thread stages
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;  // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int nbn = (p.Cout + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- per-thread staging coordinates: float4 column c4 of rows r0 + 32*j ---------------------
+    const int c4 = (tid & 7) * 4;
+    const int r0 = tid >> 3;
+
+    int a_base[AROWS];   // element offset of (n, iy0, ix0, 0) in x (may be negative at the border)
+    int a_iy0[AROWS], a_ix0[AROWS];
+    int a_base_u[UPCAT ? AROWS : 1];
+    {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            const int m = m0 + r0 + 32 * j;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad;
+                const int ix0 = ox * p.stride - p.pad;
+                a_iy0[j] = iy0;
+                a_ix0[j] = ix0;
+                a_base[j] = ((n * p.H + iy0) * p.W + ix0) * p.Cx;
+                if (UPCAT) a_base_u[j] = ((n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.Cu;
+            } else {
+                a_iy0[j] = -(1 << 24);
+                a_ix0[j] = -(1 << 24);
+                a_base[j] = 0;
+                if (UPCAT) a_base_u[j] = 0;
+            }
+        }
+    }
+
+    const int kchunks = p.Cin / BK;
+    const int T = KS * KS * kchunks;
+
+    f32x4 ra[AROWS], rb[BROWS];
+    int ld_tap = 0, ld_cc = 0;  // coordinates of the NEXT tile to fetch
+
+    auto load_tile = [&]() {
+        const int c0 = ld_cc * BK;
+        const int ky = (KS == 1) ? 0 : ld_tap / KS;
+        const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
+        if (UPCAT) {
+            const bool from_up = c0 < p.Cu;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                const bool ok = a_iy0[j] >= 0;
+                const float* src = from_up ? (p.xu + a_base_u[j] + c0 + c4)
+                                           : (p.x + a_base[j] + (c0 - p.Cu) + c4);
+                ra[j] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                ra[j] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[j] + tap_off)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float* wt = p.w + (size_t)ld_tap * p.Cout * p.Cin + c0 + c4;
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int co = n0 + r0 + 32 * j;
+            rb[j] = (co < p.Cout) ? *reinterpret_cast<const f32x4*>(wt + (size_t)co * p.Cin)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (++ld_cc == kchunks) { ld_cc = 0; ++ld_tap; }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BM * LDK;
+        float* bs = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j)
+            *reinterpret_cast<f32x4*>(as + (r0 + 32 * j) * LDK + c4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            *reinterpret_cast<f32x4*>(bs + (r0 + 32 * j) * LDK + c4) = rb[j];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = 4 * (lane >> 5);
+
+    auto compute_tile = [&](int buf) {
+        const float* as = As + buf * BM * LDK + (wm * WTM + frag_row) * LDK + frag_k;
+        const float* bs = Bs + buf * BN * LDK + (wn * WTN + frag_row) * LDK + frag_k;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j],
+                                                                           acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: one barrier per K-step ------------------------------------------------------
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const bool more = (t + 1) < T;
+        if (more) load_tile();
+        compute_tile(t & 1);
+        if (more) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const int col_l = lane & 31;
+    const int row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + wn * WTN + ni * 32 + col_l;
+        const bool cok = col < p.Cout;
+        const float sc = cok ? p.scale[col] : 0.f;
+        const float sh = cok ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int rbase = m0 + wm * WTM + mi * 32 + row_l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (cok && row < p.M) {
+                    float v = acc[mi][ni][r] * sc + sh;
+                    if (p.act) v = v > 0.f ? v : 0.1f * v;
+                    const size_t o = (size_t)row * p.Cout + col;
+                    if (p.resid) v += p.resid[o];
+                    p.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- stem conv: 3x3, Cin = 3 -> COUT (=32), stride 1 ------------------------------------------------
+// K = 27 is too short for the implicit-GEMM tile and the layer is HBM-write bound (709 MB out per
+// bs=32 batch vs 9.6 GFLOP): one thread per output pixel, weights HWIO [27][COUT] broadcast from LDS.
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
+    __shared__ float ssc[COUT], ssh[COUT];
+    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = p.w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) {
+        ssc[i] = p.scale[i];
+        ssh[i] = p.shift[i];
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    const int HoWo = p.Ho * p.Wo;
+    const int n = m / HoWo;
+    const int rem = m - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * p.stride - p.pad + ky;
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * p.stride - p.pad + kx;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float* src = p.x + ((size_t)(n * p.H + iy) * p.W + ix) * 3;
+            float xv[3];
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) xv[ci] = ok ? src[ci] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float* wr = ws + ((ky * 3 + kx) * 3 + ci) * COUT;
+#pragma unroll
+                for (int c = 0; c < COUT; c += 4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+                    acc[c + 0] = fmaf(xv[ci], wv[0], acc[c + 0]);
+                    acc[c + 1] = fmaf(xv[ci], wv[1], acc[c + 1]);
+                    acc[c + 2] = fmaf(xv[ci], wv[2], acc[c + 2]);
+                    acc[c + 3] = fmaf(xv[ci], wv[3], acc[c + 3]);
+                }
+            }
+        }
+    }
+    float* out = p.y + (size_t)m * COUT;
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = acc[c + q] * ssc[c + q] + ssh[c + q];
+            if (p.act) t = t > 0.f ? t : 0.1f * t;
+            v[q] = t;
+        }
+        *reinterpret_cast<f32x4*>(out + c) = v;
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
+int launch_mfma(hipStream_t stream, const ConvArgs& a) {
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT>;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    static bool attr_set = false;  // per instantiation; benign race (idempotent)
+    if (!attr_set) {
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int nbm = (a.M + BM - 1) / BM;
+    const int nbn = (a.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), lds, stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+template <int KS, bool UPCAT>
+int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
+    if (a.Cout <= 32) return launch_mfma<128, 32, 4, 1, KS, UPCAT>(stream, a);
+    if (a.Cout <= 64) return launch_mfma<128, 64, 4, 1, KS, UPCAT>(stream, a);
+    return launch_mfma<128, 128, 2, 2, KS, UPCAT>(stream, a);
+}
+
+}  // namespace
+
+int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
+                   const float* w, const float* scale, const float* shift, const float* residual,
+                   float* y) {
+    Y3_CHECK_ARG(d && x && w && scale && shift && y, "y3_conv2d_fwd: null pointer argument");
+    Y3_CHECK_ARG(d->k == 1 || d->k == 3, "y3_conv2d_fwd: kernel_size must be 1 or 3 (got %d)", d->k);
+    Y3_CHECK_ARG(d->stride == 1 || d->stride == 2, "y3_conv2d_fwd: stride must be 1 or 2 (got %d)",
+                 d->stride);
+    Y3_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0,
+                 "y3_conv2d_fwd: non-positive dimension");
+    Y3_CHECK_ARG(!(d->stride == 2 && (d->h % 2 || d->w % 2)),
+                 "y3_conv2d_fwd: stride-2 conv needs even H,W (got %dx%d)", d->h, d->w);
+    Y3_CHECK_ARG((x_up != nullptr) == (d->c_up > 0), "y3_conv2d_fwd: x_up and c_up must agree");
+    ConvArgs a;
+    a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
+    a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
+    a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
+    const long long M = (long long)d->n * a.Ho * a.Wo;
+    Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 31) && M * d->cout < (1LL << 31),
+                 "y3_conv2d_fwd: tensor exceeds 2^31 elements");
+    a.M = (int)M;
+
+    if (d->cin == 3) {
+        Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && !x_up && !residual,
+                     "y3_conv2d_fwd: Cin=3 is supported only as the 3x3 3->32 stem conv");
+        hipLaunchKernelGGL(conv_stem_kernel<32>, dim3((a.M + 255) / 256), dim3(256), 0, stream, a);
+        Y3_CHECK_HIP(hipGetLastError());
+        return Y3_OK;
+    }
+    Y3_CHECK_ARG(d->cin % BK == 0, "y3_conv2d_fwd: Cin must be 3 or a multiple of %d (got %d)", BK,
+                 d->cin);
+    if (x_up) {
+        Y3_CHECK_ARG(d->k == 1 && d->stride == 1, "y3_conv2d_fwd: fused upsample+concat needs a 1x1 s1 conv");
+        Y3_CHECK_ARG(d->c_up % BK == 0 && d->c_up < d->cin && d->h % 2 == 0 && d->w % 2 == 0,
+                     "y3_conv2d_fwd: bad c_up=%d for cin=%d", d->c_up, d->cin);
+        return dispatch_bn<1, true>(stream, a);
+    }
+    if (d->k == 1) {
+        Y3_CHECK_ARG(d->stride == 1, "y3_conv2d_fwd: 1x1 conv must have stride 1");
+        return dispatch_bn<1, false>(stream, a);
+    }
+    return dispatch_bn<3, false>(stream, a);
+}

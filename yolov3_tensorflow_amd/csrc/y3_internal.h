@@ -1,0 +1,39 @@
+// Internal declarations shared by the HIP translation units of libyolo355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/yolo355.h"
+
+struct y3_ctx {
+    int device;
+    hipStream_t stream;
+};
+
+void y3_set_error(const char* fmt, ...);
+
+#define Y3_CHECK_ARG(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            y3_set_error(__VA_ARGS__);         \
+            return Y3_EINVAL;                  \
+        }                                      \
+    } while (0)
+
+#define Y3_CHECK_HIP(expr)                                                          \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            y3_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                         __FILE__, __LINE__);                                       \
+            return Y3_EHIP;                                                         \
+        }                                                                           \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Launchers implemented in the .hip files (all asynchronous on `stream`).
+int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
+                   const float* w, const float* scale, const float* shift, const float* residual,
+                   float* y);

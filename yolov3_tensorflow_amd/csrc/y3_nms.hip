@@ -1,0 +1,300 @@
+// Per-class non-maximum suppression for gfx950 — both definitions the reference carries:
+//   Y3_NMS_TF : utils/nms_utils.py:8-48 `gpu_nms` (80x {boolean_mask, tf.image.non_max_suppression,
+//               gather}); IoU without +1, degenerate boxes give IoU 0, suppress when IoU > thresh.
+//   Y3_NMS_PY : utils/nms_utils.py:51-123 `py_nms`/`cpu_nms`; +1 on the intersection w/h only,
+//               a candidate survives only while ovr <= thresh (NaN does not survive).
+//
+// Formulation (no sort): greedy NMS == repeatedly take the best-scoring live candidate, then kill every
+// live candidate that overlaps it.  One workgroup per (image, class); the kill pass and the search for
+// the next best are fused in ONE sweep over the candidates per selected box; the arg-max is a 64-bit key
+// {orderable score bits, ~box index} reduced with wave shuffles, which also fixes the tie-break to
+// (score descending, box index ascending) deterministically.  Candidate records live in LDS when the
+// class has <= KCAP candidates (always, outside adversarial inputs) and are re-derived from global memory
+// otherwise.  All IoU arithmetic is plain fp32 in the reference's operation order (compiled with
+// -ffp-contract=off) so selections are bit-exact against the CPU oracle.
+//
+// Pipeline: collect (threshold + per-class compaction, LDS-aggregated atomics) -> select -> gather.
+#include "y3_internal.h"
+
+namespace {
+
+constexpr int KCAP = 1536;  // candidates per (image,class) cached in LDS: 1536 * 28 B = 42 KB
+
+struct NmsWs {
+    int32_t* cand_count;  // [n*C]
+    int32_t* cand_idx;    // [n*C][B]
+    int32_t* sel_count;   // [n*C]
+    int32_t* sel_idx;     // [n*C][max_boxes]
+};
+
+__global__ void __launch_bounds__(256) nms_collect_kernel(const float* __restrict__ scores, int B, int C,
+                                                          float thresh, int boxes_per_block,
+                                                          int32_t* cand_count, int32_t* cand_idx) {
+    extern __shared__ int lds_i[];
+    int* lcount = lds_i;      // [C]
+    int* lbase = lds_i + C;   // [C]
+    const int n = blockIdx.y;
+    const int b0 = blockIdx.x * boxes_per_block;
+    const int nb = min(boxes_per_block, B - b0);
+    const float* tile = scores + ((size_t)n * B + b0) * C;
+    const int total = nb * C;
+    for (int c = threadIdx.x; c < C; c += 256) lcount[c] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += 256)
+        if (tile[e] >= thresh) atomicAdd(&lcount[e % C], 1);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int k = lcount[c];
+        lbase[c] = k ? atomicAdd(&cand_count[n * C + c], k) : 0;
+        lcount[c] = 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += 256) {
+        if (tile[e] >= thresh) {
+            const int c = e % C;
+            const int slot = lbase[c] + atomicAdd(&lcount[c], 1);
+            cand_idx[((size_t)n * C + c) * B + slot] = b0 + e / C;
+        }
+    }
+}
+
+struct Cand {
+    float c0, c1, c2, c3;  // TF mode: normalised (min0,min1,max0,max1); PY mode: x1,y1,x2,y2
+    float area;
+    float score;
+    int idx;               // box index; < 0 once dead (stored as ~idx)
+};
+
+template <int MODE>
+__device__ __forceinline__ void make_cand(const float* boxes_n, const float* scores_n, int C, int c,
+                                          int idx, Cand& k) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(boxes_n + (size_t)idx * 4);
+    if (MODE == Y3_NMS_TF) {
+        // tf.image.non_max_suppression: coordinates are normalised per box before use
+        k.c0 = fminf(b[0], b[2]); k.c1 = fminf(b[1], b[3]);
+        k.c2 = fmaxf(b[0], b[2]); k.c3 = fmaxf(b[1], b[3]);
+    } else {
+        k.c0 = b[0]; k.c1 = b[1]; k.c2 = b[2]; k.c3 = b[3];
+    }
+    k.area = (k.c2 - k.c0) * (k.c3 - k.c1);   // utils/nms_utils.py:68 (no +1) / TF area
+    k.score = scores_n[(size_t)idx * C + c];
+    k.idx = idx;
+}
+
+// true -> candidate j must be removed after selecting i
+template <int MODE>
+__device__ __forceinline__ bool suppressed(const Cand& i, const Cand& j, float thr) {
+    if (MODE == Y3_NMS_TF) {
+        if (i.area <= 0.f || j.area <= 0.f) return false;  // IoU defined as 0
+        const float h = fmaxf(fminf(i.c2, j.c2) - fmaxf(i.c0, j.c0), 0.f);
+        const float w = fmaxf(fminf(i.c3, j.c3) - fmaxf(i.c1, j.c1), 0.f);
+        const float inter = h * w;
+        const float iou = inter / (i.area + j.area - inter);
+        return iou > thr;
+    } else {
+        // utils/nms_utils.py:75-85
+        const float xx1 = fmaxf(i.c0, j.c0), yy1 = fmaxf(i.c1, j.c1);
+        const float xx2 = fminf(i.c2, j.c2), yy2 = fminf(i.c3, j.c3);
+        const float w = fmaxf(0.f, xx2 - xx1 + 1.f);
+        const float h = fmaxf(0.f, yy2 - yy1 + 1.f);
+        const float inter = w * h;
+        const float ovr = inter / (i.area + j.area - inter);
+        return !(ovr <= thr);
+    }
+}
+
+__device__ __forceinline__ unsigned long long make_key(float score, int idx) {
+    unsigned u = __float_as_uint(score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // total order on floats
+    return ((unsigned long long)u << 32) | (unsigned)(~idx);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// Block-wide arg-max.  Each thread passes its local best (key, position); returns the winning position
+// (or -1 if none) to every thread.
+__device__ __forceinline__ int block_argmax(unsigned long long key, int pos, unsigned long long* skey,
+                                            int* spos) {
+    const unsigned long long wmax = wave_max_u64(key);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the lane holding the wave maximum publishes its position (keys are unique per candidate)
+    if (key == wmax && key != 0ull) spos[wave] = pos;
+    if (lane == 0) {
+        skey[wave] = wmax;
+        if (wmax == 0ull) spos[wave] = -1;
+    }
+    __syncthreads();
+    unsigned long long best = skey[0];
+    int bpos = spos[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (skey[w] > best) { best = skey[w]; bpos = spos[w]; }
+    __syncthreads();
+    return bpos;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) nms_select_kernel(const float* __restrict__ boxes,
+                                                         const float* __restrict__ scores, int B, int C,
+                                                         int max_boxes, float iou_thr, NmsWs ws) {
+    __shared__ Cand lcand[KCAP];
+    __shared__ unsigned long long skey[4];
+    __shared__ int spos[4];
+    __shared__ Cand sel;
+
+    const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+    const int K = ws.cand_count[blockIdx.x];
+    int32_t* cidx = ws.cand_idx + (size_t)blockIdx.x * B;
+    int32_t* sidx = ws.sel_idx + (size_t)blockIdx.x * max_boxes;
+    if (K == 0) {
+        if (threadIdx.x == 0) ws.sel_count[blockIdx.x] = 0;
+        return;
+    }
+    const float* boxes_n = boxes + (size_t)n * B * 4;
+    const float* scores_n = scores + (size_t)n * B * C;
+    const bool in_lds = K <= KCAP;
+
+    // ---- load candidates and find the first best ---------------------------------------------------
+    unsigned long long lkey = 0ull;
+    int lpos = -1;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        Cand k;
+        make_cand<MODE>(boxes_n, scores_n, C, c, cidx[j], k);
+        if (in_lds) lcand[j] = k;
+        const unsigned long long key = make_key(k.score, k.idx);
+        if (key > lkey) { lkey = key; lpos = j; }
+    }
+    int best = block_argmax(lkey, lpos, skey, spos);
+
+    int nsel = 0;
+    while (best >= 0 && nsel < max_boxes) {
+        if (threadIdx.x == 0) {
+            Cand k;
+            if (in_lds) k = lcand[best];
+            else make_cand<MODE>(boxes_n, scores_n, C, c, cidx[best], k);
+            sel = k;
+            sidx[nsel] = k.idx;
+            // retire the selected candidate
+            if (in_lds) lcand[best].idx = ~k.idx;
+            else cidx[best] = ~k.idx;
+        }
+        ++nsel;
+        __syncthreads();
+        const Cand s = sel;
+        lkey = 0ull;
+        lpos = -1;
+        if (nsel < max_boxes) {
+            for (int j = threadIdx.x; j < K; j += 256) {
+                Cand k;
+                if (in_lds) {
+                    k = lcand[j];
+                    if (k.idx < 0) continue;
+                } else {
+                    const int id = cidx[j];
+                    if (id < 0) continue;
+                    make_cand<MODE>(boxes_n, scores_n, C, c, id, k);
+                }
+                if (suppressed<MODE>(s, k, iou_thr)) {
+                    if (in_lds) lcand[j].idx = ~k.idx;
+                    else cidx[j] = ~k.idx;
+                } else {
+                    const unsigned long long key = make_key(k.score, k.idx);
+                    if (key > lkey) { lkey = key; lpos = j; }
+                }
+            }
+        }
+        best = block_argmax(lkey, lpos, skey, spos);
+    }
+    if (threadIdx.x == 0) ws.sel_count[blockIdx.x] = nsel;
+}
+
+__global__ void __launch_bounds__(256) nms_gather_kernel(const float* __restrict__ boxes,
+                                                         const float* __restrict__ scores, int B, int C,
+                                                         int max_boxes, NmsWs ws, float* out_boxes,
+                                                         float* out_scores, int32_t* out_labels,
+                                                         int32_t* out_index, int32_t* out_counts) {
+    extern __shared__ int lds_i[];
+    int* off = lds_i;  // [C+1] exclusive prefix of the per-class selection counts
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < C; ++c) {
+            off[c] = acc;
+            acc += ws.sel_count[n * C + c];
+        }
+        off[C] = acc;
+        out_counts[n] = acc;
+    }
+    __syncthreads();
+    const size_t cap = (size_t)C * max_boxes;
+    for (int e = threadIdx.x; e < C * max_boxes; e += 256) {
+        const int c = e / max_boxes, k = e - c * max_boxes;
+        if (k < off[c + 1] - off[c]) {
+            const int idx = ws.sel_idx[((size_t)n * C + c) * max_boxes + k];
+            const size_t o = (size_t)n * cap + off[c] + k;
+            *reinterpret_cast<f32x4*>(out_boxes + o * 4) =
+                *reinterpret_cast<const f32x4*>(boxes + ((size_t)n * B + idx) * 4);
+            out_scores[o] = scores[((size_t)n * B + idx) * C + c];
+            out_labels[o] = c;
+            if (out_index) out_index[o] = idx;
+        }
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t y3_nms_workspace_bytes(int n, int num_boxes, int class_num, int max_boxes) {
+    if (n <= 0 || num_boxes <= 0 || class_num <= 0 || max_boxes <= 0) return 0;
+    const size_t nc = (size_t)n * class_num;
+    return align256(nc * 4) * 2 + align256(nc * num_boxes * 4) + align256(nc * max_boxes * 4);
+}
+
+extern "C" int y3_nms(y3_ctx* ctx, int mode, const float* boxes, const float* scores, int n, int num_boxes,
+                      int class_num, int max_boxes, float score_thresh, float iou_thresh, void* workspace,
+                      size_t workspace_bytes, float* out_boxes, float* out_scores, int32_t* out_labels,
+                      int32_t* out_index, int32_t* out_counts) {
+    Y3_CHECK_ARG(ctx && boxes && scores && workspace && out_boxes && out_scores && out_labels && out_counts,
+                 "y3_nms: null argument");
+    Y3_CHECK_ARG(mode == Y3_NMS_TF || mode == Y3_NMS_PY, "y3_nms: unknown mode %d", mode);
+    Y3_CHECK_ARG(n > 0 && num_boxes > 0 && class_num > 0 && max_boxes > 0, "y3_nms: non-positive dimension");
+    Y3_CHECK_ARG(workspace_bytes >= y3_nms_workspace_bytes(n, num_boxes, class_num, max_boxes),
+                 "y3_nms: workspace too small (%zu < %zu)", workspace_bytes,
+                 y3_nms_workspace_bytes(n, num_boxes, class_num, max_boxes));
+    Y3_CHECK_ARG(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)out_boxes & 15) == 0,
+                 "y3_nms: boxes/out_boxes must be 16-byte aligned");
+    const size_t nc = (size_t)n * class_num;
+    char* p = static_cast<char*>(workspace);
+    NmsWs ws;
+    ws.cand_count = reinterpret_cast<int32_t*>(p); p += align256(nc * 4);
+    ws.sel_count = reinterpret_cast<int32_t*>(p);  p += align256(nc * 4);
+    ws.cand_idx = reinterpret_cast<int32_t*>(p);   p += align256(nc * num_boxes * 4);
+    ws.sel_idx = reinterpret_cast<int32_t*>(p);
+    hipStream_t st = ctx->stream;
+    Y3_CHECK_HIP(hipMemsetAsync(ws.cand_count, 0, nc * 4, st));
+    const int bpb = 64;  // boxes per collect block
+    hipLaunchKernelGGL(nms_collect_kernel, dim3((num_boxes + bpb - 1) / bpb, n), dim3(256),
+                       2 * class_num * sizeof(int), st, scores, num_boxes, class_num, score_thresh, bpb,
+                       ws.cand_count, ws.cand_idx);
+    Y3_CHECK_HIP(hipGetLastError());
+    if (mode == Y3_NMS_TF)
+        hipLaunchKernelGGL(nms_select_kernel<Y3_NMS_TF>, dim3((unsigned)nc), dim3(256), 0, st, boxes, scores,
+                           num_boxes, class_num, max_boxes, iou_thresh, ws);
+    else
+        hipLaunchKernelGGL(nms_select_kernel<Y3_NMS_PY>, dim3((unsigned)nc), dim3(256), 0, st, boxes, scores,
+                           num_boxes, class_num, max_boxes, iou_thresh, ws);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(n), dim3(256), (class_num + 1) * sizeof(int), st, boxes,
+                       scores, num_boxes, class_num, max_boxes, ws, out_boxes, out_scores, out_labels,
+                       out_index, out_counts);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}

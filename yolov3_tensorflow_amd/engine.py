@@ -1,0 +1,90 @@
+"""Host-side glue between named Variables and the C ABI: parameter preparation (re-pack + BN fold, cached
+per variable version) and thin Python wrappers over the per-op entry points."""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import framework as fw
+
+BN_EPS = 1e-5  # model.py:37
+
+_param_cache = {}  # weights op_name -> (version key, w_dev, scale, shift)
+
+
+def prepare_conv_params(w_var, bn_vars=None, bias_var=None):
+    """Return (w_packed, scale, shift) device tensors for one conv layer.
+
+    w_var: HWIO kernel variable.  bn_vars: (gamma, beta, moving_mean, moving_variance) or None.
+    bias_var: bias variable or None.  Packing/folding run as HIP kernels through the C ABI and are cached
+    until one of the variables is re-assigned.
+    """
+    vers = (w_var.version,) + tuple(v.version for v in (bn_vars or ())) + \
+        ((bias_var.version,) if bias_var is not None else ())
+    hit = _param_cache.get(w_var.op_name)
+    if hit is not None and hit[0] == vers:
+        return hit[1], hit[2], hit[3]
+    L = _lib.lib()
+    ctx = fw.context()
+    k, _, cin, cout = w_var.shape
+    w = w_var.tensor
+    if cin == 3:
+        w_dev = w  # the stem kernel consumes HWIO [27][32] directly
+    else:
+        w_dev = torch.empty(k * k * cout * cin, dtype=torch.float32, device=w.device)
+        _lib.check(L.y3_pack_conv_weights(ctx, fw.ptr(w), k, cin, cout, fw.ptr(w_dev)))
+    if bn_vars is not None:
+        gamma, beta, mean, var = (v.tensor for v in bn_vars)
+        scale = torch.empty(cout, dtype=torch.float32, device=w.device)
+        shift = torch.empty(cout, dtype=torch.float32, device=w.device)
+        _lib.check(L.y3_bn_fold(ctx, fw.ptr(gamma), fw.ptr(beta), fw.ptr(mean), fw.ptr(var),
+                                ctypes.c_float(BN_EPS), cout, fw.ptr(scale), fw.ptr(shift)))
+    else:
+        scale = torch.ones(cout, dtype=torch.float32, device=w.device)
+        shift = bias_var.tensor if bias_var is not None else torch.zeros(cout, dtype=torch.float32,
+                                                                         device=w.device)
+    _param_cache[w_var.op_name] = (vers, w_dev, scale, shift)
+    return w_dev, scale, shift
+
+
+def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up=None):
+    """y = act(conv(x) * scale + shift) + residual on NHWC fp32 device tensors (y3_conv2d_fwd)."""
+    n, h, w, cx = x.shape
+    c_up = 0
+    if x_up is not None:
+        c_up = x_up.shape[3]
+        if tuple(x_up.shape[:3]) != (n, h // 2, w // 2):
+            raise ValueError("x_up must be [N, H/2, W/2, C] for the fused upsample+concat input")
+    d = _lib.ConvDesc(n, h, w, cx + c_up, c_up, cout, k, stride, 1 if act else 0)
+    y = torch.empty((n, h // stride, w // stride, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().y3_conv2d_fwd(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(x_up),
+                                        fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
+                                        fw.ptr(y)))
+    return y
+
+
+def upsample_nearest(x, out_h, out_w):
+    n, h, w, c = x.shape
+    y = torch.empty((n, out_h, out_w, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().y3_upsample_nearest(fw.context(x.device), fw.ptr(x), n, h, w, c, out_h, out_w,
+                                              fw.ptr(y)))
+    return y
+
+
+def concat_channels(a, b):
+    if a.shape[:3] != b.shape[:3]:
+        raise ValueError("concat: spatial shapes differ: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    n, h, w, ca = a.shape
+    cb = b.shape[3]
+    y = torch.empty((n, h, w, ca + cb), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().y3_concat_channels(fw.context(a.device), fw.ptr(a), ca, fw.ptr(b), cb, n * h * w,
+                                             fw.ptr(y)))
+    return y
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise ValueError("add: shapes differ: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    y = torch.empty_like(a)
+    _lib.check(_lib.lib().y3_add(fw.context(a.device), fw.ptr(a), fw.ptr(b), a.numel(), fw.ptr(y)))
+    return y

@@ -1,0 +1,250 @@
+# coding=utf-8
+"""Mirror of the reference's model.py: class yolov3 with forward / reorg_layer / predict /
+loss_layer / box_iou / compute_loss (reference model.py:12-365).  Same constructor, same method
+signatures, same return arities; tensors are NHWC fp32 device tensors (torch owns the memory), and all
+arithmetic runs in HIP kernels behind include/yolo355.h.
+"""
+from __future__ import division, print_function
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import engine
+from . import framework as fw
+from .utils.layer_utils import conv2d, darknet53_body, yolo_block, upsample_layer, _conv_layer
+
+N_BODY_CONVS = 52  # utils/layer_utils.py:24-68
+
+
+class yolov3(object):
+
+    def __init__(self, class_num, anchors, use_label_smooth=False, use_focal_loss=False,
+                 batch_norm_decay=0.999, weight_decay=5e-4, use_static_shape=True):
+        # reference model.py:14-28
+        self.class_num = class_num
+        self.anchors = anchors
+        self.batch_norm_decay = batch_norm_decay
+        self.use_label_smooth = use_label_smooth
+        self.use_focal_loss = use_focal_loss
+        self.weight_decay = weight_decay
+        self.use_static_shape = use_static_shape
+        self._nets = {}   # (ctx key, scope) -> dict(handle, version, keepalive, workspace)
+        self.img_size = None
+
+    # ------------------------------------------------------------------------------------------
+    # variables
+    # ------------------------------------------------------------------------------------------
+    def _layer_table(self, net_handle):
+        L = _lib.lib()
+        n = L.y3_net_num_layers(net_handle)
+        out = []
+        for i in range(n):
+            k, s, cin, cout, bn = (ctypes.c_int() for _ in range(5))
+            _lib.check(L.y3_net_layer_info(net_handle, i, ctypes.byref(k), ctypes.byref(s),
+                                           ctypes.byref(cin), ctypes.byref(cout), ctypes.byref(bn)))
+            out.append((k.value, s.value, cin.value, cout.value, bool(bn.value)))
+        return out
+
+    def _ensure_variables(self, scope, table):
+        """Create (or fetch) the 366 variables in the reference's creation order:
+        <scope>/darknet53_body/Conv[_k]/{weights,BatchNorm/...}, <scope>/yolov3_head/Conv[_k]/..."""
+        layers = []
+        for i, (k, s, cin, cout, bn) in enumerate(table):
+            sub, j = ('darknet53_body', i) if i < N_BODY_CONVS else ('yolov3_head', i - N_BODY_CONVS)
+            base = (scope + '/' if scope else '') + sub + '/' + ('Conv' if j == 0 else 'Conv_%d' % j)
+            w = fw.get_variable(base + '/weights', (k, k, cin, cout), fw.xavier_uniform)
+            if bn:
+                bnv = (fw.get_variable(base + '/BatchNorm/gamma', (cout,), fw.ones),
+                       fw.get_variable(base + '/BatchNorm/beta', (cout,), fw.zeros),
+                       fw.get_variable(base + '/BatchNorm/moving_mean', (cout,), fw.zeros, trainable=False),
+                       fw.get_variable(base + '/BatchNorm/moving_variance', (cout,), fw.ones,
+                                       trainable=False))
+                layers.append((w, bnv, None))
+            else:
+                layers.append((w, None, fw.get_variable(base + '/biases', (cout,), fw.zeros)))
+        return layers
+
+    def _get_net(self, device):
+        ctx = fw.context(device)
+        scope = fw.current_scope_name()
+        key = (ctx.value, scope)
+        ent = self._nets.get(key)
+        L = _lib.lib()
+        if ent is None:
+            h = ctypes.c_void_p()
+            _lib.check(L.y3_net_create(ctx, int(self.class_num), ctypes.byref(h)))
+            table = self._layer_table(h)
+            ent = dict(handle=h, table=table, version=-1, keep=None, ws=None, ws_bytes=0,
+                       layers=self._ensure_variables(scope, table))
+            self._nets[key] = ent
+        if ent['version'] != fw.global_version():
+            keep = []
+            for i, (w, bnv, bias) in enumerate(ent['layers']):
+                wp, sc, sh = engine.prepare_conv_params(w, bn_vars=bnv, bias_var=bias)
+                _lib.check(L.y3_net_set_layer(ent['handle'], i, fw.ptr(wp), fw.ptr(sc), fw.ptr(sh)))
+                keep.append((wp, sc, sh))
+            ent['keep'] = keep   # the library holds raw pointers: keep the tensors alive
+            ent['version'] = fw.global_version()
+        return ent
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inputs, is_training=False, reuse=False):
+        """reference model.py:30-80.  inputs: [N,H,W,3] fp32 (numpy or device tensor), H,W % 32 == 0.
+        Returns (feature_map_1 [N,H/32,W/32,3*(5+C)], feature_map_2 (/16), feature_map_3 (/8))."""
+        x = fw.as_device_f32(inputs)
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError("inputs must be [N, H, W, 3], got %s" % (tuple(x.shape),))
+        n, h, w, _ = x.shape
+        # the input img_size, form: [height, weight]
+        self.img_size = [int(h), int(w)]
+        if is_training:
+            from . import training
+            return training.forward_train(self, x)
+        ent = self._get_net(x.device)
+        L = _lib.lib()
+        need = L.y3_net_workspace_bytes(ent['handle'], n, h, w)
+        if need == 0:
+            _lib.check(_lib.Y3_EINVAL)
+        if ent['ws'] is None or ent['ws_bytes'] < need:
+            ent['ws'] = torch.empty(need, dtype=torch.uint8, device=x.device)
+            ent['ws_bytes'] = need
+        det = 3 * (5 + self.class_num)
+        fms = [torch.empty((n, h // s, w // s, det), dtype=torch.float32, device=x.device) for s in (32, 16, 8)]
+        _lib.check(L.y3_net_forward(ent['handle'], fw.ptr(x), n, h, w, fw.ptr(ent['ws']),
+                                    ctypes.c_size_t(ent['ws_bytes']), fw.ptr(fms[0]), fw.ptr(fms[1]),
+                                    fw.ptr(fms[2])))
+        return fms[0], fms[1], fms[2]
+
+    def forward_composed(self, inputs):
+        """The same graph built op by op exactly as reference model.py:50-78 composes it (unfused
+        upsample/concat/add kernels).  Exists to cross-check the fused launch plan."""
+        x = fw.as_device_f32(inputs)
+        self.img_size = [int(x.shape[1]), int(x.shape[2])]
+        det = 3 * (5 + self.class_num)
+        with fw.variable_scope('darknet53_body'):
+            route_1, route_2, route_3 = darknet53_body(x)
+
+        with fw.variable_scope('yolov3_head'):
+            inter1, net = yolo_block(route_3, 512)
+            feature_map_1 = _conv_layer(net, det, 1, 1, use_bn=False, activation=False)
+
+            inter1 = conv2d(inter1, 256, 1)
+            inter1 = upsample_layer(inter1, list(route_2.shape))
+            concat1 = engine.concat_channels(inter1, route_2)
+
+            inter2, net = yolo_block(concat1, 256)
+            feature_map_2 = _conv_layer(net, det, 1, 1, use_bn=False, activation=False)
+
+            inter2 = conv2d(inter2, 128, 1)
+            inter2 = upsample_layer(inter2, list(route_1.shape))
+            concat2 = engine.concat_channels(inter2, route_1)
+
+            _, feature_map_3 = yolo_block(concat2, 128)
+            feature_map_3 = _conv_layer(feature_map_3, det, 1, 1, use_bn=False, activation=False)
+
+        return feature_map_1, feature_map_2, feature_map_3
+
+    def layer_times_ms(self, inputs, iters=5):
+        """Per-layer hipEvent timing of the fused plan (for profiles/ and DESIGN.md tables)."""
+        x = fw.as_device_f32(inputs)
+        ent = self._get_net(x.device)
+        L = _lib.lib()
+        self.forward(x)
+        _lib.check(L.y3_net_set_profiling(ent['handle'], 1))
+        nl = len(ent['table'])
+        acc = np.zeros(nl)
+        buf = (ctypes.c_float * nl)()
+        for _ in range(iters):
+            self.forward(x)
+            _lib.check(L.y3_net_get_layer_ms(ent['handle'], buf, nl))
+            acc += np.frombuffer(buf, dtype=np.float32)
+        _lib.check(L.y3_net_set_profiling(ent['handle'], 0))
+        return acc / iters, ent['table']
+
+    # ------------------------------------------------------------------------------------------
+    # decode
+    # ------------------------------------------------------------------------------------------
+    def reorg_layer(self, feature_map, anchors):
+        '''
+        reference model.py:82-137.
+        feature_map: a feature_map from [feature_map_1, feature_map_2, feature_map_3] returned
+            from `forward` function
+        anchors: shape: [3, 2]
+        returns x_y_offset [g,g,1,2], boxes [N,g,g,3,4] (cx,cy,w,h), conf_logits [N,g,g,3,1],
+                prob_logits [N,g,g,3,class_num]
+        '''
+        fm = fw.as_device_f32(feature_map)
+        n, gh, gw, ch = fm.shape
+        if ch != 3 * (5 + self.class_num):
+            raise ValueError("feature map has %d channels, expected %d" % (ch, 3 * (5 + self.class_num)))
+        if self.img_size is None:
+            raise ValueError("reorg_layer needs img_size: call forward() first")
+        anc = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(3, 2))
+        boxes = torch.empty((n, gh, gw, 3, 4), dtype=torch.float32, device=fm.device)
+        _lib.check(_lib.lib().y3_reorg_boxes(fw.context(fm.device), fw.ptr(fm), n, gh, gw, int(self.class_num),
+                                             int(self.img_size[0]), int(self.img_size[1]),
+                                             anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                             fw.ptr(boxes)))
+        fm5 = fm.view(n, gh, gw, 3, 5 + self.class_num)
+        conf_logits = fm5[..., 4:5]
+        prob_logits = fm5[..., 5:]
+        # meshgrid of integer cell coordinates, last dim (x, y) (model.py:108-115); index plumbing only
+        gx = torch.arange(gw, device=fm.device, dtype=torch.float32).view(1, gw, 1, 1).expand(gh, gw, 1, 1)
+        gy = torch.arange(gh, device=fm.device, dtype=torch.float32).view(gh, 1, 1, 1).expand(gh, gw, 1, 1)
+        x_y_offset = torch.cat([gx, gy], dim=-1)
+        return x_y_offset, boxes, conf_logits, prob_logits
+
+    def predict(self, feature_maps, with_scores=False):
+        '''
+        reference model.py:140-190.
+        Receive the returned feature_maps from `forward` function,
+        the produce the output predictions at the test stage.
+        returns boxes [N,B,4] (x_min,y_min,x_max,y_max), confs [N,B,1], probs [N,B,class_num]
+        (with_scores=True additionally returns scores = confs*probs, test_single_image.py:55, fused
+        into the same pass).
+        '''
+        fm1, fm2, fm3 = (fw.as_device_f32(f) for f in feature_maps)
+        n, g1h, g1w, ch = fm1.shape
+        if ch != 3 * (5 + self.class_num):
+            raise ValueError("feature map has %d channels, expected %d" % (ch, 3 * (5 + self.class_num)))
+        if self.img_size is None:
+            raise ValueError("predict needs img_size: call forward() first")
+        h, w = self.img_size
+        for f, s in ((fm1, 32), (fm2, 16), (fm3, 8)):
+            if tuple(f.shape) != (n, h // s, w // s, ch):
+                raise ValueError("feature map shape %s does not match input size %dx%d / %d" %
+                                 (tuple(f.shape), h, w, s))
+        B = 3 * sum((h // s) * (w // s) for s in (32, 16, 8))
+        C = int(self.class_num)
+        dev = fm1.device
+        boxes = torch.empty((n, B, 4), dtype=torch.float32, device=dev)
+        confs = torch.empty((n, B, 1), dtype=torch.float32, device=dev)
+        probs = torch.empty((n, B, C), dtype=torch.float32, device=dev)
+        scores = torch.empty((n, B, C), dtype=torch.float32, device=dev) if with_scores else None
+        anc = np.ascontiguousarray(np.asarray(self.anchors, np.float32).reshape(9, 2))
+        _lib.check(_lib.lib().y3_decode(fw.context(dev), fw.ptr(fm1), fw.ptr(fm2), fw.ptr(fm3), n, h, w, C,
+                                        anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), fw.ptr(boxes),
+                                        fw.ptr(confs), fw.ptr(probs), fw.ptr(scores)))
+        if with_scores:
+            return boxes, confs, probs, scores
+        return boxes, confs, probs
+
+    # ------------------------------------------------------------------------------------------
+    # loss (training path)
+    # ------------------------------------------------------------------------------------------
+    def loss_layer(self, feature_map_i, y_true, anchors):
+        from . import training
+        return training.loss_layer(self, feature_map_i, y_true, anchors)
+
+    def box_iou(self, pred_boxes, valid_true_boxes):
+        from . import training
+        return training.box_iou(pred_boxes, valid_true_boxes)
+
+    def compute_loss(self, y_pred, y_true):
+        from . import training
+        return training.compute_loss(self, y_pred, y_true)

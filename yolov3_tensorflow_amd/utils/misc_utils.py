@@ -1,0 +1,186 @@
+# coding: utf-8
+"""Mirror of the reference's utils/misc_utils.py for the pieces on the hot path:
+load_weights (darknet .weights loader), parse_anchors, read_class_names, AverageMeter,
+config_learning_rate, config_optimizer.  save_weights (the inverse of load_weights) is an addition used
+to produce synthetic checkpoints in the exact darknet format.
+"""
+from __future__ import division, print_function
+
+import math
+
+import numpy as np
+
+
+class AverageMeter(object):
+    """Running mean with the attribute names the training/eval loops read (utils/misc_utils.py:14-28)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val, self.average, self.sum, self.count = 0, 0, 0, 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.average = self.sum / float(self.count)
+
+
+def parse_anchors(anchor_path):
+    """Comma-separated anchor file -> float32 [N, 2] of (w, h) pairs (utils/misc_utils.py:31-37)."""
+    with open(anchor_path, 'r') as f:
+        flat = np.asarray(f.read().split(','), np.float32)
+    return flat.reshape(-1, 2)
+
+
+def read_class_names(class_name_path):
+    """One class name per line -> {id: name} (utils/misc_utils.py:40-45)."""
+    with open(class_name_path, 'r') as f:
+        return {i: line.strip('\n') for i, line in enumerate(f)}
+
+
+class AssignOp(object):
+    """What load_weights returns in place of tf.assign ops: run() copies the array into the variable
+    with shape validation (tf.assign(validate_shape=True), utils/misc_utils.py:99,110,123)."""
+
+    def __init__(self, var, value):
+        self.var, self.value = var, value
+
+    def run(self):
+        self.var.assign(self.value, validate_shape=True)
+        return self.var
+
+    __call__ = run
+
+
+def run_ops(ops):
+    """sess.run(load_ops) equivalent (convert_weight.py:31)."""
+    for op in ops:
+        op.run()
+
+
+def _layer_key(var):
+    # the loader keys on the second-to-last path component of the variable name (utils/misc_utils.py:88-102)
+    return var.name.split('/')[-2]
+
+
+def _conv_groups(var_list):
+    """Walk a creation-ordered variable list the way the reference loader does and yield, per conv layer,
+    (kernel_var, (gamma, beta, mean, var) or None, bias_var or None).  The walk stops one short of the end
+    like the reference (`while i < len(var_list) - 1`), so a trailing lone variable is ignored."""
+    i, n = 0, len(var_list)
+    while i < n - 1:
+        head, nxt = var_list[i], var_list[i + 1]
+        if 'Conv' not in _layer_key(head):
+            i += 1   # (the reference would spin forever here; such lists never occur)
+            continue
+        if 'BatchNorm' in _layer_key(nxt):
+            yield head, tuple(var_list[i + 1:i + 5]), None
+            i += 5
+        elif 'Conv' in _layer_key(nxt):
+            yield head, None, nxt
+            i += 2
+        else:
+            yield head, None, None
+            i += 1
+
+
+def load_weights(var_list, weights_file):
+    """Darknet .weights -> assign ops for `var_list` (reference utils/misc_utils.py:70-126).
+
+    var_list: network variables in creation order (e.g. global_variables(scope='yolov3')).
+    File: 5 x int32 header (ignored), then a float32 stream; per conv layer
+      BN'd : beta, gamma, moving_mean, moving_variance (FILE order; the variable order is gamma first)
+      else : bias
+      then the kernel as (Cout, Cin, kh, kw), transposed here to HWIO.
+    Like the reference, the stream length is not checked against the variables.
+    Returns a list of AssignOp; execute with run_ops(ops).
+    """
+    with open(weights_file, "rb") as fp:
+        np.fromfile(fp, dtype=np.int32, count=5)
+        stream = np.fromfile(fp, dtype=np.float32)
+
+    pos = [0]
+
+    def take(shape):
+        count = int(np.prod(shape))
+        chunk = stream[pos[0]:pos[0] + count]
+        pos[0] += count
+        return chunk
+
+    ops = []
+    for kernel, bn, bias in _conv_groups(var_list):
+        if bn is not None:
+            gamma, beta, mean, variance = bn
+            for v in (beta, gamma, mean, variance):
+                ops.append(AssignOp(v, take(v.shape.as_list()).reshape(v.shape.as_list())))
+        elif bias is not None:
+            ops.append(AssignOp(bias, take(bias.shape.as_list()).reshape(bias.shape.as_list())))
+        kh, kw, cin, cout = kernel.shape.as_list()
+        oihw = take((cout, cin, kh, kw)).reshape(cout, cin, kh, kw)
+        ops.append(AssignOp(kernel, np.transpose(oihw, (2, 3, 1, 0))))
+    return ops
+
+
+def save_weights(var_list, weights_file, header=(0, 2, 0, 0, 0)):
+    """Inverse of load_weights: write the variables as a darknet .weights file (same traversal)."""
+    chunks = []
+    for kernel, bn, bias in _conv_groups(var_list):
+        if bn is not None:
+            gamma, beta, mean, variance = bn
+            chunks.extend(v.numpy().astype(np.float32).ravel() for v in (beta, gamma, mean, variance))
+        elif bias is not None:
+            chunks.append(bias.numpy().astype(np.float32).ravel())
+        hwio = kernel.numpy().astype(np.float32)
+        chunks.append(np.ascontiguousarray(np.transpose(hwio, (3, 2, 0, 1))).ravel())
+    with open(weights_file, "wb") as fp:
+        np.asarray(header, np.int32).tofile(fp)
+        np.concatenate(chunks).astype(np.float32).tofile(fp)
+
+
+def config_learning_rate(args, global_step):
+    """reference utils/misc_utils.py:129-148, evaluated eagerly: returns the python float learning rate
+    for `global_step` (float).  Raises ValueError for an unknown lr_type like the reference."""
+    if args.lr_type == 'exponential':
+        # tf.train.exponential_decay(staircase=True) then max with the lower bound
+        lr_tmp = args.learning_rate_init * args.lr_decay_factor ** math.floor(global_step / args.lr_decay_freq)
+        return max(lr_tmp, args.lr_lower_bound)
+    elif args.lr_type == 'cosine_decay':
+        train_steps = (args.total_epoches - float(args.use_warm_up) * args.warm_up_epoch) * args.train_batch_num
+        return args.lr_lower_bound + 0.5 * (args.learning_rate_init - args.lr_lower_bound) * \
+            (1 + math.cos(global_step / train_steps * np.pi))
+    elif args.lr_type == 'cosine_decay_restart':
+        # tf.train.cosine_decay_restarts(lr, step, first_decay_steps, t_mul=2.0, m_mul=1.0, alpha=0)
+        first, t_mul = float(args.lr_decay_freq), 2.0
+        completed = global_step / first
+        i_restart = math.floor(math.log(1.0 - completed * (1.0 - t_mul)) / math.log(t_mul))
+        sum_r = (1.0 - t_mul ** i_restart) / (1.0 - t_mul)
+        completed_fraction = (completed - sum_r) / t_mul ** i_restart
+        return args.learning_rate_init * 0.5 * (1.0 + math.cos(math.pi * completed_fraction))
+    elif args.lr_type == 'fixed':
+        return float(args.learning_rate_init)
+    elif args.lr_type == 'piecewise':
+        # tf.train.piecewise_constant: values[i] for boundaries[i-1] < step <= boundaries[i]
+        for b, v in zip(args.pw_boundaries, args.pw_values):
+            if global_step <= b:
+                return float(v)
+        return float(args.pw_values[-1])
+    else:
+        raise ValueError('Unsupported learning rate type!')
+
+
+def config_optimizer(optimizer_name, learning_rate, decay=0.9, momentum=0.9):
+    """reference utils/misc_utils.py:151-161: returns an optimizer object for the train step
+    (yolov3_tensorflow_amd.training)."""
+    from .. import training
+    if optimizer_name == 'momentum':
+        return training.Optimizer('momentum', learning_rate, momentum=momentum)
+    elif optimizer_name == 'rmsprop':
+        return training.Optimizer('rmsprop', learning_rate, decay=decay, momentum=momentum)
+    elif optimizer_name == 'adam':
+        return training.Optimizer('adam', learning_rate)
+    elif optimizer_name == 'sgd':
+        return training.Optimizer('sgd', learning_rate)
+    else:
+        raise ValueError('Unsupported optimizer type!')
