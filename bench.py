@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py — the YOLOv3 hot path on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Darknet-53 + 3-scale head forward (75 fused conv launches) on a
+batch of 32 synthetic 416x416 fp32 images per GPU, random weights, input resident in HBM.  One "step" = one
+forward over one batch.  Inference shards by image with no data-path collective: every rank
+runs an independent replica on its own stream; torch.distributed (RCCL) is used only for the two barriers
+and the max-over-ranks of the elapsed time.  Prints ONE JSON line on rank 0.
+
+roofline: the dominant kernel family is the 3x3 implicit-GEMM MFMA conv (conv_mfma_f32_kernel<...,3,false>,
+37 of the 75 launches, 89.6 % of the FLOPs); it is matrix-pipe bound in fp32, so
+achieved = algorithmic FLOPs of those launches / their hipEvent-measured duration (events recorded on the
+launch stream between layers, inside the timed region), peak = 157.3 TFLOP/s (fp32 MFMA).
+cpu_baseline: the CPU oracle's torch-fp32 restatement of the same graph ("port"; the literal TF-CPU
+reference cannot run here: no TensorFlow), same weights, a bounded sample, rank 0 and N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 32
+SIZE = 416
+CLASS_NUM = 80
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip-level table
+ANCHORS = np.array([10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326],
+                   np.float32).reshape(9, 2)
+
+
+def random_init(seed):
+    """Random weights of the reference architecture with tame activations: He-normal kernels, BN close to
+    identity, residual-branch gamma damped (so 23 residual adds do not blow the scale up)."""
+    import torch
+    import yolov3_tensorflow_amd as y3
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    closers = set()
+    idx = 2
+    for blocks in (1, 2, 8, 8, 4):
+        for _ in range(blocks):
+            closers.add(idx + 1)
+            idx += 2
+        idx += 1
+    for v in y3.global_variables(scope='yolov3'):
+        parts = v.op_name.split('/')
+        leaf = parts[-1]
+        shape = tuple(v.shape)
+        if leaf == 'weights':
+            k, _, cin, cout = shape
+            t = torch.randn(shape, generator=g) * float(np.sqrt(2.0 / (k * k * cin)))
+            if cout == 3 * (5 + CLASS_NUM):
+                t = t * 0.25
+        elif leaf == 'gamma':
+            t = torch.rand(shape, generator=g) * 0.4 + 0.8
+            conv = parts[-3]
+            ci = 0 if conv == 'Conv' else int(conv.split('_')[1])
+            if parts[-4] == 'darknet53_body' and ci in closers:
+                t = t * 0.25
+        elif leaf in ('beta', 'moving_mean'):
+            t = torch.randn(shape, generator=g) * 0.05
+        elif leaf == 'moving_variance':
+            t = torch.rand(shape, generator=g) * 0.4 + 0.8
+        elif leaf == 'biases':
+            t = torch.randn(shape, generator=g) * 0.1
+        else:
+            raise AssertionError(v.op_name)
+        v.assign(t)
+
+
+def conv_flops(table, n, h, w):
+    """Algorithmic FLOPs per layer for one forward (2*k^2*Cin*Cout*Hout*Wout*N), following the graph."""
+    # spatial divisor of each layer's OUTPUT: replay the strides in creation order
+    flops = []
+    div = 1
+    sdiv_of = []
+    # body: divisors follow the stride-2 convs; head: 13-grid block, then 26, then 52
+    head_divs = [32] * 8 + [16] * 8 + [8] * 7
+    for i, (k, s, cin, cout, bn) in enumerate(table):
+        if i < 52:
+            div *= s
+            d = div
+        else:
+            d = head_divs[i - 52]
+        sdiv_of.append(d)
+        flops.append(2.0 * k * k * cin * cout * (h // d) * (w // d) * n)
+    return np.array(flops)
+
+
+def cpu_baseline(model_vars, budget_s=20.0):
+    """Time the oracle's torch-CPU fp32 forward on a bounded sample (checker code, never the product)."""
+    import torch
+    from oracle import yolo_ref
+    params = {v.op_name: v.numpy() for v in model_vars}
+    threads = torch.get_num_threads()
+    x = np.random.RandomState(123).rand(2, SIZE, SIZE, 3).astype(np.float32)
+    yolo_ref.forward(params, x[:1])                       # warm-up (thread pool, oneDNN primitives)
+    t0 = time.time()
+    yolo_ref.forward(params, x)
+    per_batch = time.time() - t0
+    reps = int(max(1, min(8, budget_s / max(per_batch, 1e-3))))
+    t0 = time.time()
+    for _ in range(reps):
+        yolo_ref.forward(params, x)
+    dt = time.time() - t0
+    return {"value": round(2 * reps / dt, 3), "unit": "images/s", "cores": int(threads), "kind": "port",
+            "sample": "oracle.yolo_ref.forward (torch-CPU fp32 restatement of the reference graph; "
+                      "TF-CPU itself is not installable here), %d x batch of 2 images %dx%d, same weights"
+                      % (reps, SIZE, SIZE)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import yolov3_tensorflow_amd as y3
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    y3.set_default_device('cuda:%d' % local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    model = y3.yolov3(CLASS_NUM, ANCHORS)
+    x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda',
+                   generator=torch.Generator(device='cuda').manual_seed(100 + rank))
+    with y3.variable_scope('yolov3'):
+        model.forward(torch.zeros((1, 64, 64, 3), device='cuda'))      # create the variables
+        random_init(seed=1)
+        for _ in range(args.warmup):
+            fms = model.forward(x, False)
+        model.set_layer_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fms = model.forward(x, False)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        layer_ms, table = model.read_layer_ms()
+        model.set_layer_profiling(False)
+        # p50 of single-step latency (separate short loop; each step synchronised)
+        lat = []
+        for _ in range(min(args.steps, 10)):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.forward(x, False)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+    assert all(torch.isfinite(f).all().item() for f in fms), "non-finite feature maps"
+
+    if distributed:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * BATCH * args.steps / elapsed
+        flops = conv_flops(table, BATCH, SIZE, SIZE)
+        is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
+        dom_ms = float(layer_ms[is3].sum())
+        dom_flops = float(flops[is3].sum())
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        whole = float(flops.sum()) / (float(layer_ms.sum()) * 1e-3) / 1e12
+        out = {
+            "metric": "images/sec at 416x416 bs=32 (Darknet-53 + 3-scale head forward)",
+            "value": round(value, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_image_p50": round(float(np.median(lat)) * 1e3 / BATCH, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: Darknet-53 + 3-scale head forward, random weights, "
+                                   "416x416 bs=32 fp32 per GPU, input resident in HBM",
+                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE,
+                       "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": None,
+                         "kernel": "conv_mfma_f32_kernel<*,*,*,*,3,false> (3x3 implicit-GEMM conv, 37 launches/step)",
+                         "launches_per_step": int(is3.sum()),
+                         "avg_launch_ms": round(dom_ms / int(is3.sum()), 4),
+                         "algorithmic_gflop_per_launch": round(dom_flops / int(is3.sum()) / 1e9, 3),
+                         "whole_forward_tflops": round(whole, 2),
+                         "sum_layer_ms": round(float(layer_ms.sum()), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(y3.global_variables(scope='yolov3'))
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

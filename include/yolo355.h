@@ -142,8 +142,9 @@ size_t y3_net_workspace_bytes(const y3_net* net, int n, int h, int w);
 /* x [n,h,w,3] -> fm1 [n,h/32,w/32,3*(5+C)], fm2 (/16), fm3 (/8).  h,w multiples of 32. */
 int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* workspace,
                    size_t workspace_bytes, float* fm1, float* fm2, float* fm3);
-/* Optional per-layer timing with hipEvents on the context stream: after a forward with
- * profiling enabled, ms[i] holds layer i's elapsed time (synchronises the stream). */
+/* Optional per-layer timing with hipEvents on the context stream.  While enabled, every forward (up to
+ * 256) records one event per layer boundary; y3_net_get_layer_ms synchronises on the last event, writes
+ * the per-layer elapsed ms averaged over the forwards recorded since the previous call, and resets. */
 int y3_net_set_profiling(y3_net* net, int enabled);
 int y3_net_get_layer_ms(y3_net* net, float* ms, int count);
 

@@ -1,0 +1,151 @@
+"""GPU parity: y3_conv2d_fwd (through the C ABI) against an fp64 torch-CPU convolution of the same op, on
+every distinct conv shape of the network at reduced spatial size, plus true-size cases.
+Tolerance (stated here, fp32 accumulate over K <= 4608): |d| <= 1e-4 + 1e-4*|ref|."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (k, stride, cin, cout, bn(act), residual)
+DISTINCT = [
+    (3, 1, 3, 32, True, False), (3, 2, 32, 64, True, False), (1, 1, 64, 32, True, False),
+    (3, 1, 32, 64, True, True), (3, 2, 64, 128, True, False), (1, 1, 128, 64, True, False),
+    (3, 1, 64, 128, True, True), (3, 2, 128, 256, True, False), (1, 1, 256, 128, True, False),
+    (3, 1, 128, 256, True, True), (3, 2, 256, 512, True, False), (1, 1, 512, 256, True, False),
+    (3, 1, 256, 512, True, True), (3, 2, 512, 1024, True, False), (1, 1, 1024, 512, True, False),
+    (3, 1, 512, 1024, True, True), (3, 1, 512, 1024, True, False), (1, 1, 1024, 255, False, False),
+    (1, 1, 512, 255, False, False), (1, 1, 256, 255, False, False), (3, 1, 256, 512, True, False),
+    (3, 1, 128, 256, True, False), (1, 1, 1024, 18, False, False),
+]
+
+
+def ref_conv(x, w_hwio, scale, shift, k, stride, act, resid=None):
+    """fp64 restatement: explicit pad for stride 2 (utils/layer_utils.py:10-21), SAME for stride 1."""
+    xd = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wd = torch.from_numpy(w_hwio).double().permute(3, 2, 0, 1)
+    if stride > 1:
+        p = (k - 1) // 2
+        xd = F.pad(xd, (p, k - 1 - p, p, k - 1 - p))
+        y = F.conv2d(xd, wd, stride=stride)
+    else:
+        y = F.conv2d(xd, wd, padding=k // 2)
+    y = y * torch.from_numpy(scale).double().view(1, -1, 1, 1) + torch.from_numpy(shift).double().view(1, -1, 1, 1)
+    if act:
+        y = torch.where(y > 0, y, 0.1 * y)
+    y = y.permute(0, 2, 3, 1)
+    if resid is not None:
+        y = y + torch.from_numpy(resid).double()
+    return y.numpy()
+
+
+def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None):
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    import ctypes
+    dev = fw.default_device()
+    L = _lib.lib()
+    cin_total = w_hwio.shape[2]
+    cout = w_hwio.shape[3]
+    w = torch.from_numpy(w_hwio).to(dev)
+    if cin_total == 3:
+        wp = w
+    else:
+        wp = torch.empty(k * k * cout * cin_total, device=dev)
+        _lib.check(L.y3_pack_conv_weights(fw.context(), fw.ptr(w), k, cin_total, cout, fw.ptr(wp)))
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    y = engine.conv2d_fwd(t(x), wp, t(scale), t(shift), k, stride, cout, act, residual=t(resid), x_up=t(x_up))
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def make_case(rng, n, h, w, k, cin, cout):
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, cout).astype(np.float32)
+    return x, wt, scale, shift
+
+
+def check(got, want, what):
+    err = np.abs(got - want)
+    tol = 1e-4 + 1e-4 * np.abs(want)
+    assert got.shape == want.shape, what
+    assert np.isfinite(got).all(), what
+    assert (err <= tol).all(), '%s: max err %.3e (max |ref| %.2f)' % (what, err.max(), np.abs(want).max())
+
+
+@pytest.mark.parametrize('k,stride,cin,cout,act,resid', DISTINCT)
+def test_distinct_shapes_reduced_spatial(k, stride, cin, cout, act, resid):
+    rng = np.random.RandomState(hash((k, stride, cin, cout, resid)) % (2 ** 31))
+    n, h, w = 3, 20, 28                       # M = 1680 or 420: ragged last tile, non-square map
+    x, wt, scale, shift = make_case(rng, n, h, w, k, cin, cout)
+    r = rng.standard_normal((n, h // stride, w // stride, cout)).astype(np.float32) if resid else None
+    got = run_gpu(x, wt, scale, shift, k, stride, act, r)
+    check(got, ref_conv(x, wt, scale, shift, k, stride, act, r), 'k%d s%d %d->%d' % (k, stride, cin, cout))
+
+
+@pytest.mark.parametrize('c_up,c_route,cout', [(256, 512, 256), (128, 256, 128), (32, 32, 64)])
+def test_fused_upsample_concat_input(c_up, c_route, cout):
+    rng = np.random.RandomState(c_up)
+    n, h, w = 2, 26, 26
+    xu = rng.standard_normal((n, h // 2, w // 2, c_up)).astype(np.float32)
+    xr = rng.standard_normal((n, h, w, c_route)).astype(np.float32)
+    _, wt, scale, shift = make_case(rng, 1, 1, 1, 1, c_up + c_route, cout)
+    got = run_gpu(xr, wt, scale, shift, 1, 1, True, None, x_up=xu)
+    cat = np.concatenate([np.repeat(np.repeat(xu, 2, 1), 2, 2), xr], axis=3)   # upsampled channels first
+    check(got, ref_conv(cat, wt, scale, shift, 1, 1, True), 'upcat %d+%d' % (c_up, c_route))
+
+
+@pytest.mark.parametrize('n,h,w,k,stride,cin,cout', [
+    (2, 52, 52, 3, 1, 128, 256),     # true-size 52x52 residual-stage conv
+    (1, 416, 416, 3, 1, 3, 32),      # stem at full resolution
+    (2, 104, 104, 3, 2, 128, 256),   # true-size downsample
+    (1, 13, 13, 3, 1, 512, 1024),    # M = 169: two ragged M tiles, K = 4608
+    (1, 19, 19, 1, 1, 1024, 255),    # 608-input head, odd map
+    (5, 2, 2, 3, 1, 64, 64),         # map smaller than the kernel footprint
+])
+def test_true_size_and_edge_cases(n, h, w, k, stride, cin, cout):
+    rng = np.random.RandomState(n * 1000 + h)
+    x, wt, scale, shift = make_case(rng, n, h, w, k, cin, cout)
+    got = run_gpu(x, wt, scale, shift, k, stride, True)
+    check(got, ref_conv(x, wt, scale, shift, k, stride, True), '%dx%dx%d k%d s%d %d->%d' % (n, h, w, k, stride, cin, cout))
+
+
+def test_linearity_and_zero_input_at_full_batch():
+    """Size-independent properties at BASELINE size (bs=32, 52x52x128->256): conv(0) == shift exactly,
+    conv(a*x) == a*conv(x) for a power of two (exact in fp32) with scale=1, shift=0, linear act."""
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    dev = fw.default_device()
+    rng = np.random.RandomState(0)
+    n, h, w, cin, cout, k = 32, 52, 52, 128, 256, 3
+    wt = torch.from_numpy((rng.standard_normal((k, k, cin, cout)) * 0.03).astype(np.float32)).to(dev)
+    wp = torch.empty(k * k * cout * cin, device=dev)
+    _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(), fw.ptr(wt), k, cin, cout, fw.ptr(wp)))
+    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev)
+    x0 = torch.zeros((n, h, w, cin), device=dev)
+    y0 = engine.conv2d_fwd(x0, wp, ones, shift, k, 1, cout, False)
+    assert torch.equal(y0, shift.view(1, 1, 1, -1).expand_as(y0))
+    x = torch.randn((n, h, w, cin), device=dev)
+    y1 = engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False)
+    y4 = engine.conv2d_fwd(x * 4.0, wp, ones, zeros, k, 1, cout, False)
+    assert torch.equal(y4, y1 * 4.0)
+    # batch independence: image 7 alone gives the same bits as image 7 inside the batch
+    y7 = engine.conv2d_fwd(x[7:8].contiguous(), wp, ones, zeros, k, 1, cout, False)
+    assert torch.equal(y7[0], y1[7])
+
+
+def test_bad_arguments_raise_value_error():
+    from yolov3_tensorflow_amd import engine, framework as fw
+    dev = fw.default_device()
+    x = torch.zeros((1, 8, 8, 24), device=dev)       # Cin not a multiple of 32
+    w = torch.zeros(24 * 32, device=dev)
+    s = torch.zeros(32, device=dev)
+    with pytest.raises(ValueError):
+        engine.conv2d_fwd(x, w, s, s, 1, 1, 32, True)
+    x = torch.zeros((1, 7, 7, 32), device=dev)       # odd map with stride 2
+    with pytest.raises(ValueError):
+        engine.conv2d_fwd(x, torch.zeros(9 * 32 * 32, device=dev), s, s, 3, 2, 32, True)
+    with pytest.raises(ValueError):
+        engine.conv2d_fwd(x, torch.zeros(25 * 32 * 32, device=dev), s, s, 5, 1, 32, True)

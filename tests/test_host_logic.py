@@ -1,0 +1,135 @@
+"""CPU tests of the host-side logic that needs no device: the darknet loader's traversal, learning-rate
+schedules, anchors/class-name parsing, AverageMeter, naming/scoping."""
+import os
+import tempfile
+import types
+
+import numpy as np
+import pytest
+
+from yolov3_tensorflow_amd.utils import misc_utils
+from yolov3_tensorflow_amd import framework as fw
+from oracle import yolo_ref
+
+
+class FakeVar(object):
+    """Stands in for a device variable: records assignments on the host."""
+
+    def __init__(self, name, shape):
+        self.name = name + ':0'
+        self.shape = fw._Shape(shape)
+        self.value = None
+
+    def assign(self, value, validate_shape=True):
+        value = np.asarray(value)
+        if validate_shape and tuple(value.shape) != tuple(self.shape):
+            raise ValueError('shape mismatch for %s' % self.name)
+        self.value = value.copy()
+        return self
+
+    def numpy(self):
+        return self.value
+
+
+def test_load_weights_follows_the_darknet_layout():
+    params = yolo_ref.synthetic_params(80, seed=5)
+    path = os.path.join(tempfile.mkdtemp(), 'w.weights')
+    yolo_ref.write_darknet(params, path)
+    var_list = [FakeVar(n, s) for n, s in yolo_ref.variable_specs(80)]
+    ops = misc_utils.load_weights(var_list, path)
+    assert len(ops) == 366
+    misc_utils.run_ops(ops)
+    for v in var_list:
+        np.testing.assert_array_equal(v.value, params[v.name[:-2]], err_msg=v.name)
+
+
+def test_save_weights_is_the_inverse_of_load_weights():
+    params = yolo_ref.synthetic_params(80, seed=6)
+    var_list = [FakeVar(n, s) for n, s in yolo_ref.variable_specs(80)]
+    for v in var_list:
+        v.assign(params[v.name[:-2]])
+    d = tempfile.mkdtemp()
+    misc_utils.save_weights(var_list, os.path.join(d, 'a.weights'))
+    yolo_ref.write_darknet(params, os.path.join(d, 'b.weights'))
+    assert open(os.path.join(d, 'a.weights'), 'rb').read() == open(os.path.join(d, 'b.weights'), 'rb').read()
+
+
+def test_load_weights_validates_shapes():
+    params = yolo_ref.synthetic_params(80, seed=5)
+    path = os.path.join(tempfile.mkdtemp(), 'w.weights')
+    yolo_ref.write_darknet(params, path)
+    specs = yolo_ref.variable_specs(80)
+    var_list = [FakeVar(n, s) for n, s in specs]
+    ops = misc_utils.load_weights(var_list, path)
+    var_list[0].shape = fw._Shape((3, 3, 3, 16))      # variable changed after the ops were built
+    with pytest.raises(ValueError):
+        ops[4].run()                                  # ops[0..3] are BN params, ops[4] the first kernel
+
+
+def test_parse_anchors_and_class_names(anchors):
+    d = tempfile.mkdtemp()
+    p = os.path.join(d, 'anchors.txt')
+    open(p, 'w').write('10,13, 16,30, 33,23, 30,61, 62,45, 59,119, 116,90, 156,198, 373,326')
+    a = misc_utils.parse_anchors(p)
+    assert a.dtype == np.float32 and a.shape == (9, 2)
+    np.testing.assert_array_equal(a, anchors)
+    q = os.path.join(d, 'names.txt')
+    open(q, 'w').write('person\nbicycle\ncar\n')
+    assert misc_utils.read_class_names(q) == {0: 'person', 1: 'bicycle', 2: 'car'}
+
+
+def test_average_meter():
+    m = misc_utils.AverageMeter()
+    m.update(2.0); m.update(4.0, n=3)
+    assert m.val == 4.0 and m.count == 4 and m.sum == 14.0 and m.average == 3.5
+    m.reset()
+    assert m.count == 0 and m.average == 0
+
+
+def _args(**kw):
+    base = dict(learning_rate_init=1e-3, lr_decay_freq=100, lr_decay_factor=0.5, lr_lower_bound=1e-6,
+                total_epoches=10, use_warm_up=True, warm_up_epoch=2, train_batch_num=50,
+                pw_boundaries=[100, 200], pw_values=[1e-3, 1e-4, 1e-5])
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_learning_rate_schedules():
+    lr = misc_utils.config_learning_rate
+    assert lr(_args(lr_type='fixed'), 123.0) == 1e-3
+    # staircase exponential with lower bound
+    assert lr(_args(lr_type='exponential'), 99.0) == pytest.approx(1e-3)
+    assert lr(_args(lr_type='exponential'), 100.0) == pytest.approx(5e-4)
+    assert lr(_args(lr_type='exponential'), 250.0) == pytest.approx(2.5e-4)
+    assert lr(_args(lr_type='exponential', lr_lower_bound=4e-4), 250.0) == pytest.approx(4e-4)
+    # piecewise: value i for boundary[i-1] < step <= boundary[i]
+    a = _args(lr_type='piecewise')
+    assert [lr(a, s) for s in (0.0, 100.0, 101.0, 200.0, 201.0)] == [1e-3, 1e-3, 1e-4, 1e-4, 1e-5]
+    # cosine decay: starts at init, ends at the lower bound after train_steps = (10-2)*50
+    a = _args(lr_type='cosine_decay')
+    assert lr(a, 0.0) == pytest.approx(1e-3)
+    assert lr(a, 400.0) == pytest.approx(1e-6)
+    assert lr(a, 200.0) == pytest.approx(1e-6 + 0.5 * (1e-3 - 1e-6))
+    # cosine restarts: period 100 then 200 (t_mul = 2)
+    a = _args(lr_type='cosine_decay_restart')
+    assert lr(a, 0.0) == pytest.approx(1e-3)
+    assert lr(a, 50.0) == pytest.approx(5e-4)
+    assert lr(a, 100.0) == pytest.approx(1e-3)          # restart
+    assert lr(a, 200.0) == pytest.approx(5e-4)          # middle of the second (200-step) period
+    with pytest.raises(ValueError):
+        lr(_args(lr_type='nope'), 0.0)
+
+
+def test_scope_naming_matches_slim():
+    with fw.variable_scope('yolov3'):
+        with fw.variable_scope('darknet53_body'):
+            names = [fw.unique_layer_name('Conv') for _ in range(3)]
+            assert fw.current_scope_name() == 'yolov3/darknet53_body'
+        with fw.variable_scope('yolov3_head'):
+            again = fw.unique_layer_name('Conv')
+    assert names == ['Conv', 'Conv_1', 'Conv_2'] and again == 'Conv'
+
+
+def test_unknown_optimizer_raises_value_error():
+    with pytest.raises(ValueError):
+        misc_utils.config_optimizer('lion', 1e-3)

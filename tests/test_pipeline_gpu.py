@@ -1,0 +1,54 @@
+"""End-to-end (BASELINE config 3): darknet-format weights -> forward -> predict -> score -> gpu_nms on the
+GPU, against the same pipeline in the CPU oracle.
+  * boxes/confs/probs: |d| <= 1e-3 + 1e-3*|ref| (the north-star tolerance), tighter numbers printed;
+  * NMS index selection: bit-exact on identical inputs (the GPU's decoded boxes/scores fed to the C oracle);
+  * end to end (oracle features -> oracle NMS vs GPU features -> GPU NMS): agreement reported; any
+    difference must be explained by a near-threshold margin."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import blob_images
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_predict_nms_against_oracle(gpu_model, anchors):
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd.utils import nms_utils
+    from oracle import yolo_ref, nms_ref
+    model, params = gpu_model
+    x = blob_images(11, 1, 416)
+    with y3.variable_scope('yolov3'):
+        fms = model.forward(x, False)
+    boxes, confs, probs, scores = model.predict(fms, with_scores=True)
+    rf = yolo_ref.forward(params, x)
+    rb, rc, rp = yolo_ref.predict(rf, anchors, [416, 416], 80)
+    gb, gc, gp = boxes.cpu().numpy(), confs.cpu().numpy(), probs.cpu().numpy()
+    for name, g, r in (('boxes', gb, rb), ('confs', gc, rc), ('probs', gp, rp)):
+        err = np.abs(g - r)
+        print('%s: max abs %.3e, max rel %.3e' % (name, err.max(), (err / np.maximum(np.abs(r), 1.0)).max()))
+        assert (err <= 1e-3 + 1e-3 * np.abs(r)).all(), name
+    gs = scores.cpu().numpy()
+    rs = rc * rp
+    # thresholds chosen as quantiles of the synthetic net's scores so both call-site regimes are exercised:
+    # a sparse one (~150 candidates) and an eval-like one (~6000 candidates)
+    for q, max_boxes in ((1 - 150.0 / gs.size, 200), (1 - 6000.0 / gs.size, 400)):
+        thr = float(np.quantile(gs, q))
+        b, s, l, idx = nms_utils.gpu_nms_batched(boxes, scores, 80, max_boxes, thr, 0.45, return_index=True)[0]
+        # (1) identical inputs -> identical selection, bit for bit
+        ob, osc, ol, oi = nms_ref.c_per_class('tf', gb[0], gs[0], 80, max_boxes, thr, 0.45)
+        np.testing.assert_array_equal(idx.cpu().numpy(), oi)
+        np.testing.assert_array_equal(l.cpu().numpy(), ol)
+        np.testing.assert_array_equal(b.cpu().numpy(), ob)
+        np.testing.assert_array_equal(s.cpu().numpy(), osc)
+        # (2) end to end against the oracle's own features
+        eb, es, el, ei = nms_ref.c_per_class('tf', rb[0], rs[0], 80, max_boxes, thr, 0.45)
+        got = set(zip(l.cpu().tolist(), idx.cpu().tolist()))
+        want = set(zip(el.tolist(), ei.tolist()))
+        agree = len(got & want) / float(max(len(want), 1))
+        print('thr %.4g: %d detections, end-to-end index agreement %.4f' % (thr, len(want), agree))
+        assert agree >= 0.99
+        if got == want:
+            np.testing.assert_allclose(b.cpu().numpy(), eb, rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(s.cpu().numpy(), es, rtol=1e-3, atol=1e-3)

@@ -75,10 +75,10 @@ struct y3_net {
     int pn = 0, ph = 0, pw = 0;
     std::vector<size_t> offsets;  // byte offset of each tensor in the workspace (SIZE_MAX if external)
     size_t plan_bytes = 0;
-    // profiling
+    // profiling: one set of (layers+1) events per profiled forward, averaged by y3_net_get_layer_ms
     bool profiling = false;
-    std::vector<hipEvent_t> events;
-    bool events_valid = false;
+    std::vector<std::vector<hipEvent_t>> event_sets;
+    size_t sets_used = 0;
 
     int add_conv(int src, int cout, int k, int stride = 1, bool bn = true, bool act = true, int resid = -1,
                  int up = -1) {
@@ -214,7 +214,8 @@ struct y3_net {
 };
 
 extern "C" int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out) {
-    Y3_CHECK_ARG(ctx && out, "y3_net_create: null argument");
+    // ctx may be NULL: the graph, layer table and workspace plan are host-only; forward then needs a ctx.
+    Y3_CHECK_ARG(out, "y3_net_create: null out pointer");
     Y3_CHECK_ARG(class_num > 0, "y3_net_create: class_num must be positive");
     y3_net* net = new y3_net;
     net->ctx = ctx;
@@ -226,7 +227,8 @@ extern "C" int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out) {
 
 extern "C" int y3_net_destroy(y3_net* net) {
     if (net) {
-        for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+        for (auto& set : net->event_sets)
+            for (hipEvent_t e : set) (void)hipEventDestroy(e);
         delete net;
     }
     return Y3_OK;
@@ -271,6 +273,10 @@ extern "C" size_t y3_net_workspace_bytes(const y3_net* net, int n, int h, int w)
 extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* workspace,
                               size_t workspace_bytes, float* fm1, float* fm2, float* fm3) {
     Y3_CHECK_ARG(net && x && workspace && fm1 && fm2 && fm3, "y3_net_forward: null argument");
+    if (!net->ctx) {
+        y3_set_error("y3_net_forward: the net was created without a context");
+        return Y3_ESTATE;
+    }
     if (int rc = check_size("y3_net_forward", n, h, w)) return rc;
     net->plan(n, h, w);
     Y3_CHECK_ARG(workspace_bytes >= net->plan_bytes, "y3_net_forward: workspace too small (%zu < %zu)",
@@ -292,13 +298,16 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
     };
     hipStream_t st = net->ctx->stream;
     const size_t nl = net->layers.size();
-    if (net->profiling && net->events.size() != nl + 1) {
-        for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
-        net->events.assign(nl + 1, nullptr);
-        for (size_t i = 0; i <= nl; ++i) Y3_CHECK_HIP(hipEventCreate(&net->events[i]));
+    hipEvent_t* ev = nullptr;
+    if (net->profiling && net->sets_used < 256) {
+        if (net->sets_used == net->event_sets.size()) {
+            std::vector<hipEvent_t> set(nl + 1, nullptr);
+            for (size_t i = 0; i <= nl; ++i) Y3_CHECK_HIP(hipEventCreate(&set[i]));
+            net->event_sets.push_back(set);
+        }
+        ev = net->event_sets[net->sets_used++].data();
+        Y3_CHECK_HIP(hipEventRecord(ev[0], st));
     }
-    net->events_valid = false;
-    if (net->profiling) Y3_CHECK_HIP(hipEventRecord(net->events[0], st));
     for (size_t i = 0; i < nl; ++i) {
         const Layer& l = net->layers[i];
         const Tensor& in = net->tensors[l.src];
@@ -308,15 +317,15 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         const int rc = y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
                                       ptr(l.dst));
         if (rc != Y3_OK) return rc;
-        if (net->profiling) Y3_CHECK_HIP(hipEventRecord(net->events[i + 1], st));
+        if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
     }
-    net->events_valid = net->profiling;
     return Y3_OK;
 }
 
 extern "C" int y3_net_set_profiling(y3_net* net, int enabled) {
     Y3_CHECK_ARG(net, "y3_net_set_profiling: null net");
     net->profiling = enabled != 0;
+    net->sets_used = 0;
     return Y3_OK;
 }
 
@@ -324,12 +333,21 @@ extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, int count) {
     Y3_CHECK_ARG(net && ms, "y3_net_get_layer_ms: null argument");
     Y3_CHECK_ARG(count == (int)net->layers.size(), "y3_net_get_layer_ms: count must be %zu",
                  net->layers.size());
-    if (!net->events_valid) {
+    if (net->sets_used == 0) {
         y3_set_error("y3_net_get_layer_ms: no profiled forward has run");
         return Y3_ESTATE;
     }
-    Y3_CHECK_HIP(hipEventSynchronize(net->events[count]));
-    for (int i = 0; i < count; ++i)
-        Y3_CHECK_HIP(hipEventElapsedTime(&ms[i], net->events[i], net->events[i + 1]));
+    for (int i = 0; i < count; ++i) ms[i] = 0.f;
+    for (size_t s = 0; s < net->sets_used; ++s) {
+        hipEvent_t* ev = net->event_sets[s].data();
+        Y3_CHECK_HIP(hipEventSynchronize(ev[count]));
+        for (int i = 0; i < count; ++i) {
+            float t = 0.f;
+            Y3_CHECK_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[i] += t;
+        }
+    }
+    for (int i = 0; i < count; ++i) ms[i] /= (float)net->sets_used;
+    net->sets_used = 0;
     return Y3_OK;
 }

@@ -149,22 +149,30 @@ class yolov3(object):
 
         return feature_map_1, feature_map_2, feature_map_3
 
+    def set_layer_profiling(self, enabled, device=None):
+        """Turn per-layer hipEvent recording on/off for the fused plan on the current stream."""
+        ent = self._get_net(device if device is not None else fw.default_device())
+        _lib.check(_lib.lib().y3_net_set_profiling(ent['handle'], 1 if enabled else 0))
+
+    def read_layer_ms(self, device=None):
+        """Per-layer ms averaged over the forwards recorded since the last read (synchronises), plus the
+        layer table [(k, stride, cin, cout, has_bn)]."""
+        ent = self._get_net(device if device is not None else fw.default_device())
+        nl = len(ent['table'])
+        buf = (ctypes.c_float * nl)()
+        _lib.check(_lib.lib().y3_net_get_layer_ms(ent['handle'], buf, nl))
+        return np.array(buf[:], dtype=np.float64), ent['table']
+
     def layer_times_ms(self, inputs, iters=5):
         """Per-layer hipEvent timing of the fused plan (for profiles/ and DESIGN.md tables)."""
         x = fw.as_device_f32(inputs)
-        ent = self._get_net(x.device)
-        L = _lib.lib()
         self.forward(x)
-        _lib.check(L.y3_net_set_profiling(ent['handle'], 1))
-        nl = len(ent['table'])
-        acc = np.zeros(nl)
-        buf = (ctypes.c_float * nl)()
+        self.set_layer_profiling(True, x.device)
         for _ in range(iters):
             self.forward(x)
-            _lib.check(L.y3_net_get_layer_ms(ent['handle'], buf, nl))
-            acc += np.frombuffer(buf, dtype=np.float32)
-        _lib.check(L.y3_net_set_profiling(ent['handle'], 0))
-        return acc / iters, ent['table']
+        ms, table = self.read_layer_ms(x.device)
+        self.set_layer_profiling(False, x.device)
+        return ms, table
 
     # ------------------------------------------------------------------------------------------
     # decode
