@@ -17,6 +17,7 @@
 //   * double-buffered LDS with register prefetch of tile t+1 during the MFMAs of tile t: one
 //     barrier per K-step;
 //   * epilogue fused in registers: scale/shift (folded BN or bias), LeakyReLU(0.1), residual add.
+#include <cstdlib>
 #include "y3_internal.h"
 
 namespace {
@@ -38,8 +39,12 @@ struct ConvArgs {
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
+// VAR bit 0: bounds-checked buffer loads (no branches; out-of-range -> 0) instead of predicated global loads
+// VAR bit 1: double-buffered LDS->register fragments (reads of k-group kk+1 issued before the MFMAs of kk)
+// VAR bit 2: epilogue staged through LDS: 16-byte row-contiguous residual loads / output stores
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int VAR>
 __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
+    constexpr bool BUF = (VAR & 1) != 0, PIPE = (VAR & 2) != 0, LDSEPI = (VAR & 4) != 0;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
     constexpr int MI = WTM / 32, NI = WTN / 32;    // 32x32 MFMA tiles per wave
     constexpr int AROWS = BM / 32, BROWS = BN / 32;  // float4 rows each thread stages
@@ -97,35 +102,77 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
     f32x4 ra[AROWS], rb[BROWS];
     int ld_tap = 0, ld_cc = 0;  // coordinates of the NEXT tile to fetch
 
+    // buffer resources (wave-uniform: built from kernel arguments only)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(UPCAT ? p.xu : p.x), 0,
+        (unsigned)(UPCAT ? (size_t)p.N * (p.H >> 1) * (p.W >> 1) * p.Cu * 4 : 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (unsigned)((size_t)KS * KS * p.Cout * p.Cin * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;   // any offset >= num_records reads as 0
+
     auto load_tile = [&]() {
         const int c0 = ld_cc * BK;
         const int ky = (KS == 1) ? 0 : ld_tap / KS;
         const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
-        if (UPCAT) {
-            const bool from_up = c0 < p.Cu;
+        if (BUF) {
+            if (UPCAT) {
+                const bool from_up = c0 < p.Cu;
 #pragma unroll
-            for (int j = 0; j < AROWS; ++j) {
-                const bool ok = a_iy0[j] >= 0;
-                const float* src = from_up ? (p.xu + a_base_u[j] + c0 + c4)
-                                           : (p.x + a_base[j] + (c0 - p.Cu) + c4);
-                ra[j] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < AROWS; ++j) {
+                    const bool ok = a_iy0[j] >= 0;
+                    const unsigned off = from_up ? (unsigned)(a_base_u[j] + c0 + c4) * 4u
+                                                 : (unsigned)(a_base[j] + (c0 - p.Cu) + c4) * 4u;
+                    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                from_up ? rs_u : rs_x, ok ? off : OOB, 0, 0));
+                }
+            } else {
+                const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
+#pragma unroll
+                for (int j = 0; j < AROWS; ++j) {
+                    const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    const unsigned off = (unsigned)(a_base[j] + tap_off) * 4u;
+                    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_x, ok ? off : OOB, 0, 0));
+                }
+            }
+            const unsigned wbase = (unsigned)((ld_tap * p.Cout) * p.Cin + c0 + c4) * 4u;
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) {
+                const int co = n0 + r0 + 32 * j;
+                const unsigned off = wbase + (unsigned)(co * p.Cin) * 4u;
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_w, co < p.Cout ? off : OOB, 0, 0));
             }
         } else {
-            const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
+            if (UPCAT) {
+                const bool from_up = c0 < p.Cu;
 #pragma unroll
-            for (int j = 0; j < AROWS; ++j) {
-                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                ra[j] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[j] + tap_off)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < AROWS; ++j) {
+                    const bool ok = a_iy0[j] >= 0;
+                    const float* src = from_up ? (p.xu + a_base_u[j] + c0 + c4)
+                                               : (p.x + a_base[j] + (c0 - p.Cu) + c4);
+                    ra[j] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+                const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
+#pragma unroll
+                for (int j = 0; j < AROWS; ++j) {
+                    const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    ra[j] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[j] + tap_off)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
-        }
-        const float* wt = p.w + (size_t)ld_tap * p.Cout * p.Cin + c0 + c4;
+            const float* wt = p.w + (size_t)ld_tap * p.Cout * p.Cin + c0 + c4;
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) {
-            const int co = n0 + r0 + 32 * j;
-            rb[j] = (co < p.Cout) ? *reinterpret_cast<const f32x4*>(wt + (size_t)co * p.Cin)
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < BROWS; ++j) {
+                const int co = n0 + r0 + 32 * j;
+                rb[j] = (co < p.Cout) ? *reinterpret_cast<const f32x4*>(wt + (size_t)co * p.Cin)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if (++ld_cc == kchunks) { ld_cc = 0; ++ld_tap; }
     };
@@ -155,23 +202,51 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
     auto compute_tile = [&](int buf) {
         const float* as = As + buf * BM * LDK + (wm * WTM + frag_row) * LDK + frag_k;
         const float* bs = Bs + buf * BN * LDK + (wn * WTN + frag_row) * LDK + frag_k;
+        if (PIPE) {
+            f32x4 a[2][MI], b[2][NI];
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 a[MI], b[NI];
+            for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + kk * 8);
+            for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + kk * 8);
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
+                        a[nxt][mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + (kk + 1) * 8);
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j],
-                                                                           acc[mi][ni], 0, 0, 0);
+                        b[nxt][ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + (kk + 1) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a[cur][mi][j], b[cur][ni][j], acc[mi][ni], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                f32x4 a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + kk * 8);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + kk * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j],
+                                                                               acc[mi][ni], 0, 0, 0);
+            }
         }
     };
 
@@ -190,6 +265,46 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
     // ---- epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
+    if (LDSEPI && (p.Cout & 3) == 0) {
+        // Stage the raw accumulators through LDS (free after the last barrier) so that the residual
+        // loads and the output stores are 16 bytes per lane, row-contiguous (a wave covers whole rows).
+        constexpr int LDC = BN + 4;
+        static_assert(BM * LDC <= 2 * (BM + BN) * LDK, "accumulator tile must fit in the staging LDS");
+        float* cs = smem;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    cs[(wm * WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2)) * LDC + wn * WTN + ni * 32 + col_l] =
+                        acc[mi][ni][r];
+        __syncthreads();
+        constexpr int C4 = BN / 4;             // float4 columns per tile row
+        constexpr int RPP = 256 / C4;          // rows covered per pass
+        const int tc = (tid % C4) * 4, tr = tid / C4;
+        const int col = n0 + tc;
+        if (col < p.Cout) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+            for (int rr = tr; rr < BM; rr += RPP) {
+                const int row = m0 + rr;
+                if (row < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc);
+                    v = v * sc + sh;
+                    if (p.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    }
+                    const size_t o = (size_t)row * p.Cout + col;
+                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    *reinterpret_cast<f32x4*>(p.y + o) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int col = n0 + wn * WTN + ni * 32 + col_l;
@@ -275,9 +390,9 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int VAR>
 int launch_mfma(hipStream_t stream, const ConvArgs& a) {
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, VAR>;
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;  // per instantiation; benign race (idempotent)
     if (!attr_set) {
@@ -292,11 +407,34 @@ int launch_mfma(hipStream_t stream, const ConvArgs& a) {
     return Y3_OK;
 }
 
-template <int KS, bool UPCAT>
+template <int KS, bool UPCAT, int VAR>
 int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
-    if (a.Cout <= 32) return launch_mfma<128, 32, 4, 1, KS, UPCAT>(stream, a);
-    if (a.Cout <= 64) return launch_mfma<128, 64, 4, 1, KS, UPCAT>(stream, a);
-    return launch_mfma<128, 128, 2, 2, KS, UPCAT>(stream, a);
+    if (a.Cout <= 32) return launch_mfma<128, 32, 4, 1, KS, UPCAT, VAR>(stream, a);
+    if (a.Cout <= 64) return launch_mfma<128, 64, 4, 1, KS, UPCAT, VAR>(stream, a);
+    return launch_mfma<128, 128, 2, 2, KS, UPCAT, VAR>(stream, a);
+}
+
+constexpr int DEFAULT_VARIANT = 7;
+
+// Experiment hook: Y3_CONV_VARIANT=<0|1|3|7> selects a kernel variant at run time (tools/conv_bench.py).
+int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("Y3_CONV_VARIANT");
+        v = e ? atoi(e) : DEFAULT_VARIANT;
+        if (v != 0 && v != 1 && v != 3 && v != 7) v = DEFAULT_VARIANT;
+    }
+    return v;
+}
+
+template <int KS, bool UPCAT>
+int dispatch_var(hipStream_t stream, const ConvArgs& a) {
+    switch (conv_variant()) {
+        case 1: return dispatch_bn<KS, UPCAT, 1>(stream, a);
+        case 3: return dispatch_bn<KS, UPCAT, 3>(stream, a);
+        case 7: return dispatch_bn<KS, UPCAT, 7>(stream, a);
+        default: return dispatch_bn<KS, UPCAT, 0>(stream, a);
+    }
 }
 
 }  // namespace
@@ -319,8 +457,8 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
     const long long M = (long long)d->n * a.Ho * a.Wo;
-    Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 31) && M * d->cout < (1LL << 31),
-                 "y3_conv2d_fwd: tensor exceeds 2^31 elements");
+    Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 29) && M * d->cout < (1LL << 29),
+                 "y3_conv2d_fwd: tensor exceeds 2^29 elements (32-bit byte offsets)");
     a.M = (int)M;
 
     if (d->cin == 3) {
@@ -336,11 +474,11 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
         Y3_CHECK_ARG(d->k == 1 && d->stride == 1, "y3_conv2d_fwd: fused upsample+concat needs a 1x1 s1 conv");
         Y3_CHECK_ARG(d->c_up % BK == 0 && d->c_up < d->cin && d->h % 2 == 0 && d->w % 2 == 0,
                      "y3_conv2d_fwd: bad c_up=%d for cin=%d", d->c_up, d->cin);
-        return dispatch_bn<1, true>(stream, a);
+        return dispatch_var<1, true>(stream, a);
     }
     if (d->k == 1) {
         Y3_CHECK_ARG(d->stride == 1, "y3_conv2d_fwd: 1x1 conv must have stride 1");
-        return dispatch_bn<1, false>(stream, a);
+        return dispatch_var<1, false>(stream, a);
     }
-    return dispatch_bn<3, false>(stream, a);
+    return dispatch_var<3, false>(stream, a);
 }
