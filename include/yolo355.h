@@ -81,9 +81,13 @@ typedef struct y3_conv_desc {
     int act;       /* 0 linear, 1 leaky(0.1) */
 } y3_conv_desc;
 
+/* Scratch the stream-K schedule of this conv may use (0 if it never does).  Passing workspace = NULL to
+ * y3_conv2d_fwd is allowed and selects the data-parallel schedule; results of the two schedules differ in
+ * the last bits (the K sum of a split tile is associated differently), each is deterministic. */
+size_t y3_conv_workspace_bytes(const y3_conv_desc* d);
 int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
                   const float* w, const float* scale, const float* shift, const float* residual,
-                  float* y);
+                  float* y, void* workspace, size_t workspace_bytes);
 
 /* ---- unfused graph ops, for callers composing the network op by op (utils/layer_utils.py) ---------
  * y3_net_forward never launches these (it fuses them into the neighbouring convs).

@@ -131,9 +131,14 @@ def test_linearity_and_zero_input_at_full_batch():
     y1 = engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False)
     y4 = engine.conv2d_fwd(x * 4.0, wp, ones, zeros, k, 1, cout, False)
     assert torch.equal(y4, y1 * 4.0)
-    # batch independence: image 7 alone gives the same bits as image 7 inside the batch
-    y7 = engine.conv2d_fwd(x[7:8].contiguous(), wp, ones, zeros, k, 1, cout, False)
-    assert torch.equal(y7[0], y1[7])
+    # batch independence: bit-exact under the data-parallel schedule (fixed K order per output element);
+    # under stream-K the split points of the K sum depend on M, so only to fp32 rounding
+    y7 = engine.conv2d_fwd(x[7:8].contiguous(), wp, ones, zeros, k, 1, cout, False, use_workspace=False)
+    y1d = engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False, use_workspace=False)
+    assert torch.equal(y7[0], y1d[7])
+    assert torch.allclose(y1, y1d, rtol=1e-5, atol=1e-5)
+    # run-to-run determinism of the stream-K schedule
+    assert torch.equal(engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False), y1)
 
 
 def test_bad_arguments_raise_value_error():

@@ -25,8 +25,9 @@ PROTOTYPES = {
     "y3_ctx_destroy": (c_int, [c_void_p]),
     "y3_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "y3_conv_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv2d_fwd": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_void_p, c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_size_t]),
     "y3_upsample_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong, c_void_p]),
     "y3_add": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),

@@ -38,11 +38,13 @@ extern "C" int y3_ctx_destroy(y3_ctx* ctx) {
     return Y3_OK;
 }
 
+extern "C" size_t y3_conv_workspace_bytes(const y3_conv_desc* d) { return y3_conv_workspace_bytes_impl(d); }
+
 extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
                              const float* w, const float* scale, const float* shift,
-                             const float* residual, float* y) {
+                             const float* residual, float* y, void* workspace, size_t workspace_bytes) {
     Y3_CHECK_ARG(ctx, "y3_conv2d_fwd: null context");
-    return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y);
+    return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y, workspace, workspace_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -74,7 +76,9 @@ struct y3_net {
     // cached plan
     int pn = 0, ph = 0, pw = 0;
     std::vector<size_t> offsets;  // byte offset of each tensor in the workspace (SIZE_MAX if external)
-    size_t plan_bytes = 0;
+    size_t plan_bytes = 0;    // arena + conv scratch
+    size_t arena_bytes = 0;   // activations only; the conv (stream-K) scratch follows at this offset
+    size_t scratch_bytes = 0;
     // profiling: one set of (layers+1) events per profiled forward, averaged by y3_net_get_layer_ms
     bool profiling = false;
     std::vector<std::vector<hipEvent_t>> event_sets;
@@ -208,7 +212,15 @@ struct y3_net {
             live[l.dst] = 1;
             peak = std::max(peak, top);
         }
-        plan_bytes = peak;
+        arena_bytes = (peak + 255) & ~(size_t)255;
+        scratch_bytes = 0;
+        for (const Layer& l : layers) {
+            y3_conv_desc d;
+            d.n = n; d.h = h / tensors[l.src].sdiv; d.w = w / tensors[l.src].sdiv;
+            d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
+            scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
+        }
+        plan_bytes = arena_bytes + scratch_bytes;
         pn = n; ph = h; pw = w;
     }
 };
@@ -315,7 +327,7 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         d.n = n; d.h = h / in.sdiv; d.w = w / in.sdiv;
         d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
         const int rc = y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
-                                      ptr(l.dst));
+                                      ptr(l.dst), base + net->arena_bytes, net->scratch_bytes);
         if (rc != Y3_OK) return rc;
         if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
     }

@@ -10,13 +10,21 @@
 //     forward is matrix-pipe bound, so the tile is sized to keep the matrix pipe busy:
 //     128 x {128,64,32} block tile, BK = 32, 4 waves, each wave a grid of 32x32 MFMA tiles;
 //   * NHWC activations give 16-byte-per-lane loads along Cin; weights are pre-packed
-//     [tap][Cout][Cin] so the B tile is loaded exactly like the A tile;
+//     [tap][Cout][Cin] so the B tile is loaded exactly like the A tile; both through bounds-checked
+//     buffer loads (padding, ragged M and ragged Cout read as 0 with no branch);
 //   * LDS tiles are [rows][BK+4] floats: one ds_read_b128 per lane feeds FOUR k-steps of the MFMA
 //     (lane l holds k = 4*(l>>5)+j for step j on both operands) and the +4 pad makes the 16-lane
 //     groups of ds_read_b128 bank-conflict free;
-//   * double-buffered LDS with register prefetch of tile t+1 during the MFMAs of tile t: one
-//     barrier per K-step;
-//   * epilogue fused in registers: scale/shift (folded BN or bias), LeakyReLU(0.1), residual add.
+//   * double-buffered LDS with register prefetch of K-step t+1 during the MFMAs of K-step t: one
+//     barrier per K-step; the prefetch runs across tile boundaries in the persistent form;
+//   * epilogue: raw accumulators staged through the (then free) LDS so that scale/shift (folded BN or
+//     bias), LeakyReLU(0.1), the residual read and the output write are 16 bytes per lane and
+//     row-contiguous;
+//   * two schedules over the same code: data-parallel (one workgroup per output tile) for layers with
+//     many tiles, and stream-K (a persistent grid of 2 workgroups per CU, each owning an equal contiguous
+//     range of (tile, K-step) work items) for the 52x52/26x26/13x13 layers, whose tile counts do not
+//     divide the 512 co-resident workgroups (tail quantisation cost 12-33 % there).  Split tiles are
+//     combined in a fixed order by a second small kernel, so results are deterministic.
 #include <cstdlib>
 #include "y3_internal.h"
 
@@ -30,26 +38,121 @@ struct ConvArgs {
     const float* shift;  // [Cout]
     const float* resid;  // [M,Cout] or nullptr
     float* y;            // [M,Cout]
+    float* partial;      // stream-K scratch: [workers][2][BM*BN] raw accumulators
     int N, H, W, Cin, Cu, Cx;
     int Ho, Wo, Cout;
     int stride, pad, act;
     int M;
+    int workers;         // stream-K grid size (0 = data-parallel)
 };
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+constexpr unsigned OOB = 0x80000000u;  // any offset >= num_records reads as 0 through a buffer load
 
-// VAR bit 0: bounds-checked buffer loads (no branches; out-of-range -> 0) instead of predicated global loads
-// VAR bit 1: double-buffered LDS->register fragments (reads of k-group kk+1 issued before the MFMAs of kk)
-// VAR bit 2: epilogue staged through LDS: 16-byte row-contiguous residual loads / output stores
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int VAR>
-__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
-    constexpr bool BUF = (VAR & 1) != 0, PIPE = (VAR & 2) != 0, LDSEPI = (VAR & 4) != 0;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
-    constexpr int MI = WTM / 32, NI = WTN / 32;    // 32x32 MFMA tiles per wave
-    constexpr int AROWS = BM / 32, BROWS = BN / 32;  // float4 rows each thread stages
+template <int BM, int BN, int WGM, int WGN>
+struct Geo {
+    static constexpr int WTM = BM / WGM, WTN = BN / WGN;  // per-wave output tile
+    static constexpr int MI = WTM / 32, NI = WTN / 32;    // 32x32 MFMA tiles per wave
+    static constexpr int LDC = BN + 4;                    // epilogue staging row stride
+    static constexpr size_t LDS_BYTES = (size_t)2 * (BM + BN) * LDK * sizeof(float);
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    static_assert((size_t)BM * LDC * sizeof(float) <= LDS_BYTES, "accumulator tile must fit in the LDS");
+};
+
+// ---- epilogue shared by the conv kernel and the stream-K fix-up kernel ------------------------------
+// D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
+                                         f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI],
+                                         int m0, int n0) {
+    using G = Geo<BM, BN, WGM, WGN>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    if ((p.Cout & 3) == 0) {
+        float* cs = smem;
+#pragma unroll
+        for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    cs[(wm * G::WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2)) * G::LDC + wn * G::WTN +
+                       ni * 32 + col_l] = acc[mi][ni][r];
+        __syncthreads();
+        constexpr int C4 = BN / 4;     // float4 columns per tile row
+        constexpr int RPP = 256 / C4;  // rows covered per pass
+        const int tc = (tid % C4) * 4, tr = tid / C4;
+        const int col = n0 + tc;
+        if (col < p.Cout) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+            for (int rr = tr; rr < BM; rr += RPP) {
+                const int row = m0 + rr;
+                if (row < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * G::LDC + tc);
+                    v = v * sc + sh;
+                    if (p.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    }
+                    const size_t o = (size_t)row * p.Cout + col;
+                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    *reinterpret_cast<f32x4*>(p.y + o) = v;
+                }
+            }
+        }
+        return;
+    }
+    // Cout not a multiple of 4 (detection heads, 3*(5+C)): rows are not 16-byte aligned -> scalar stores
+#pragma unroll
+    for (int ni = 0; ni < G::NI; ++ni) {
+        const int col = n0 + wn * G::WTN + ni * 32 + col_l;
+        const bool cok = col < p.Cout;
+        const float sc = cok ? p.scale[col] : 0.f;
+        const float sh = cok ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi) {
+            const int rbase = m0 + wm * G::WTM + mi * 32 + row_l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (cok && row < p.M) {
+                    float v = acc[mi][ni][r] * sc + sh;
+                    if (p.act) v = v > 0.f ? v : 0.1f * v;
+                    const size_t o = (size_t)row * p.Cout + col;
+                    if (p.resid) v += p.resid[o];
+                    p.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// Balanced contiguous partition of `items` over `workers`: worker w owns [begin(w), begin(w+1)).
+__device__ __host__ __forceinline__ long long sk_begin(long long items, int workers, int w) {
+    const long long q = items / workers, r = items % workers;
+    return (long long)w * q + (w < r ? w : r);
+}
+__device__ __host__ __forceinline__ int sk_owner(long long items, int workers, long long item) {
+    const long long q = items / workers, r = items % workers;
+    if (item < r * (q + 1)) return (int)(item / (q + 1));
+    return (int)(r + (item - r * (q + 1)) / q);
+}
+// XCD-aware worker id: workgroup b runs on XCD b%8 (observed, speed only); give each XCD a contiguous
+// eighth of the item space so neighbouring tiles share their A halo / B panel in one L2.
+__device__ __forceinline__ int sk_worker_id(int b, int workers) {
+    return (workers & 7) == 0 ? (b & 7) * (workers >> 3) + (b >> 3) : b;
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK>
+__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
+    using G = Geo<BM, BN, WGM, WGN>;
+    constexpr int MI = G::MI, NI = G::NI, WTM = G::WTM, WTN = G::WTN;
+    constexpr int AROWS = BM / 32, BROWS = BN / 32;  // float4 rows each thread stages
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM][LDK]
@@ -61,21 +164,53 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
     const int wm = wave / WGN, wn = wave % WGN;
 
     const int nbn = (p.Cout + BN - 1) / BN;
-    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int kchunks = p.Cin / BK;
+    const int S = KS * KS * kchunks;  // K-steps per output tile
+
+    // ---- this workgroup's range of work items (item = tile * S + kstep) ----------------------------
+    long long item, item_end;
+    int worker = 0;
+    if (STREAMK) {
+        const long long items = (long long)((p.M + BM - 1) / BM) * nbn * S;
+        worker = sk_worker_id(blockIdx.x, p.workers);
+        item = sk_begin(items, p.workers, worker);
+        item_end = sk_begin(items, p.workers, worker + 1);
+    } else {
+        item = (long long)blockIdx.x * S;
+        item_end = item + S;
+    }
+    if (item >= item_end) return;
+    const long long first_tile = item / S;
 
     // ---- per-thread staging coordinates: float4 column c4 of rows r0 + 32*j ---------------------
     const int c4 = (tid & 7) * 4;
     const int r0 = tid >> 3;
 
-    int a_base[AROWS];   // element offset of (n, iy0, ix0, 0) in x (may be negative at the border)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(UPCAT ? p.xu : p.x), 0,
+        (unsigned)(UPCAT ? (size_t)p.N * (p.H >> 1) * (p.W >> 1) * p.Cu * 4 : 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (unsigned)((size_t)KS * KS * p.Cout * p.Cin * 4), 0x00020000);
+
+    // loader state: the tile and K-step the NEXT load_tile() call fetches
+    int a_base[AROWS];  // element offset of (n, iy0, ix0, 0) in x (may be negative at the border)
     int a_iy0[AROWS], a_ix0[AROWS];
     int a_base_u[UPCAT ? AROWS : 1];
-    {
+    int ld_n0 = 0, ld_tap = 0, ld_cc = 0;
+
+    auto set_loader = [&](long long it) {
+        const int tile = (int)(it / S);
+        const int ks = (int)(it - (long long)tile * S);
+        const int bm = tile / nbn, bn = tile - bm * nbn;
+        ld_n0 = bn * BN;
+        ld_tap = ks / kchunks;
+        ld_cc = ks - ld_tap * kchunks;
         const int HoWo = p.Ho * p.Wo;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
-            const int m = m0 + r0 + 32 * j;
+            const int m = bm * BM + r0 + 32 * j;
             if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
@@ -94,85 +229,42 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
                 if (UPCAT) a_base_u[j] = 0;
             }
         }
-    }
-
-    const int kchunks = p.Cin / BK;
-    const int T = KS * KS * kchunks;
+    };
 
     f32x4 ra[AROWS], rb[BROWS];
-    int ld_tap = 0, ld_cc = 0;  // coordinates of the NEXT tile to fetch
-
-    // buffer resources (wave-uniform: built from kernel arguments only)
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cx * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(UPCAT ? p.xu : p.x), 0,
-        (unsigned)(UPCAT ? (size_t)p.N * (p.H >> 1) * (p.W >> 1) * p.Cu * 4 : 16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (unsigned)((size_t)KS * KS * p.Cout * p.Cin * 4), 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;   // any offset >= num_records reads as 0
 
     auto load_tile = [&]() {
         const int c0 = ld_cc * BK;
         const int ky = (KS == 1) ? 0 : ld_tap / KS;
         const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
-        if (BUF) {
-            if (UPCAT) {
-                const bool from_up = c0 < p.Cu;
+        if (UPCAT) {
+            const bool from_up = c0 < p.Cu;
 #pragma unroll
-                for (int j = 0; j < AROWS; ++j) {
-                    const bool ok = a_iy0[j] >= 0;
-                    const unsigned off = from_up ? (unsigned)(a_base_u[j] + c0 + c4) * 4u
-                                                 : (unsigned)(a_base[j] + (c0 - p.Cu) + c4) * 4u;
-                    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                from_up ? rs_u : rs_x, ok ? off : OOB, 0, 0));
-                }
-            } else {
-                const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
-#pragma unroll
-                for (int j = 0; j < AROWS; ++j) {
-                    const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    const unsigned off = (unsigned)(a_base[j] + tap_off) * 4u;
-                    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                rs_x, ok ? off : OOB, 0, 0));
-                }
-            }
-            const unsigned wbase = (unsigned)((ld_tap * p.Cout) * p.Cin + c0 + c4) * 4u;
-#pragma unroll
-            for (int j = 0; j < BROWS; ++j) {
-                const int co = n0 + r0 + 32 * j;
-                const unsigned off = wbase + (unsigned)(co * p.Cin) * 4u;
-                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            rs_w, co < p.Cout ? off : OOB, 0, 0));
+            for (int j = 0; j < AROWS; ++j) {
+                const bool ok = a_iy0[j] >= 0;
+                const unsigned off = from_up ? (unsigned)(a_base_u[j] + c0 + c4) * 4u
+                                             : (unsigned)(a_base[j] + (c0 - p.Cu) + c4) * 4u;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      from_up ? rs_u : rs_x, ok ? off : OOB, 0, 0));
             }
         } else {
-            if (UPCAT) {
-                const bool from_up = c0 < p.Cu;
+            const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
 #pragma unroll
-                for (int j = 0; j < AROWS; ++j) {
-                    const bool ok = a_iy0[j] >= 0;
-                    const float* src = from_up ? (p.xu + a_base_u[j] + c0 + c4)
-                                               : (p.x + a_base[j] + (c0 - p.Cu) + c4);
-                    ra[j] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            } else {
-                const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
-#pragma unroll
-                for (int j = 0; j < AROWS; ++j) {
-                    const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    ra[j] = ok ? *reinterpret_cast<const f32x4*>(p.x + a_base[j] + tap_off)
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+            for (int j = 0; j < AROWS; ++j) {
+                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = (unsigned)(a_base[j] + tap_off) * 4u;
+                ra[j] = __builtin_bit_cast(f32x4,
+                                           __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0));
             }
-            const float* wt = p.w + (size_t)ld_tap * p.Cout * p.Cin + c0 + c4;
+        }
+        const unsigned wbase = (unsigned)((ld_tap * p.Cout) * p.Cin + c0 + c4) * 4u;
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) {
-                const int co = n0 + r0 + 32 * j;
-                rb[j] = (co < p.Cout) ? *reinterpret_cast<const f32x4*>(wt + (size_t)co * p.Cin)
-                                      : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int j = 0; j < BROWS; ++j) {
+            const int co = ld_n0 + r0 + 32 * j;
+            const unsigned off = wbase + (unsigned)(co * p.Cin) * 4u;
+            rb[j] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, co < p.Cout ? off : OOB, 0, 0));
         }
         if (++ld_cc == kchunks) { ld_cc = 0; ++ld_tap; }
     };
@@ -189,144 +281,117 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
     };
 
     f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
     const int frag_row = lane & 31;
     const int frag_k = 4 * (lane >> 5);
 
     auto compute_tile = [&](int buf) {
         const float* as = As + buf * BM * LDK + (wm * WTM + frag_row) * LDK + frag_k;
         const float* bs = Bs + buf * BN * LDK + (wn * WTN + frag_row) * LDK + frag_k;
-        if (PIPE) {
-            f32x4 a[2][MI], b[2][NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK);
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 a[MI], b[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[0][ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK);
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + kk * 8);
 #pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                const int cur = kk & 1, nxt = cur ^ 1;
-                if (kk + 1 < BK / 8) {
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + kk * 8);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        a[nxt][mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + (kk + 1) * 8);
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        b[nxt][ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + (kk + 1) * 8);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                a[cur][mi][j], b[cur][ni][j], acc[mi][ni], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                f32x4 a[MI], b[NI];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * LDK + kk * 8);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * LDK + kk * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j],
-                                                                               acc[mi][ni], 0, 0, 0);
-            }
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j],
+                                                                           acc[mi][ni], 0, 0, 0);
         }
     };
 
-    // ---- main loop: one barrier per K-step ------------------------------------------------------
+    // ---- segments: maximal runs of K-steps of one tile inside this workgroup's item range --------
+    set_loader(item);
     load_tile();
-    store_tile(0);
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const bool more = (t + 1) < T;
-        if (more) load_tile();
-        compute_tile(t & 1);
-        if (more) store_tile((t + 1) & 1);
-        __syncthreads();
-    }
+    while (item < item_end) {
+        const int tile = (int)(item / S);
+        const int ks = (int)(item - (long long)tile * S);
+        const long long tile_end = (long long)(tile + 1) * S;
+        const long long seg_end = tile_end < item_end ? tile_end : item_end;
+        const int nsteps = (int)(seg_end - item);
+        const int bm = tile / nbn, bn = tile - bm * nbn;
+        const int m0 = bm * BM, n0 = bn * BN;
 
-    // ---- epilogue: D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const int col_l = lane & 31;
-    const int row_l = 4 * (lane >> 5);
-    if (LDSEPI && (p.Cout & 3) == 0) {
-        // Stage the raw accumulators through LDS (free after the last barrier) so that the residual
-        // loads and the output stores are 16 bytes per lane, row-contiguous (a wave covers whole rows).
-        constexpr int LDC = BN + 4;
-        static_assert(BM * LDC <= 2 * (BM + BN) * LDK, "accumulator tile must fit in the staging LDS");
-        float* cs = smem;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        store_tile(0);  // the registers hold this segment's first K-step
+        __syncthreads();
+        for (int t = 0; t < nsteps; ++t) {
+            const bool more = (t + 1) < nsteps;
+            if (more) {
+                load_tile();
+            } else if (STREAMK && seg_end < item_end) {
+                set_loader(seg_end);  // prefetch across the tile boundary; stored after the epilogue
+                load_tile();
+            }
+            compute_tile(t & 1);
+            if (more) store_tile((t + 1) & 1);
+            __syncthreads();
+        }
+
+        if (!STREAMK || (ks == 0 && seg_end == tile_end)) {
+            epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0);
+        } else {
+            // partial tile: raw accumulators to this worker's slot (0 = its first tile, 1 = its last)
+            float* slot = p.partial + ((size_t)worker * 2 + (tile == (int)first_tile ? 0 : 1)) * (BM * BN);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    cs[(wm * WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2)) * LDC + wn * WTN + ni * 32 + col_l] =
-                        acc[mi][ni][r];
-        __syncthreads();
-        constexpr int C4 = BN / 4;             // float4 columns per tile row
-        constexpr int RPP = 256 / C4;          // rows covered per pass
-        const int tc = (tid % C4) * 4, tr = tid / C4;
-        const int col = n0 + tc;
-        if (col < p.Cout) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-#pragma unroll 4
-            for (int rr = tr; rr < BM; rr += RPP) {
-                const int row = m0 + rr;
-                if (row < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc);
-                    v = v * sc + sh;
-                    if (p.act) {
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
-                    }
-                    const size_t o = (size_t)row * p.Cout + col;
-                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
-                    *reinterpret_cast<f32x4*>(p.y + o) = v;
-                }
-            }
+                    for (int r = 0; r < 16; ++r) slot[((mi * NI + ni) * 16 + r) * 256 + tid] = acc[mi][ni][r];
         }
-        return;
+        if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
+        item = seg_end;
     }
+}
+
+// Stream-K fix-up: one workgroup per output tile; tiles computed whole by one worker exit at once, split
+// tiles sum their partials in worker (= K) order and run the common epilogue.
+template <int BM, int BN, int WGM, int WGN, int KS>
+__global__ void __launch_bounds__(256) conv_streamk_fixup_kernel(const ConvArgs p) {
+    using G = Geo<BM, BN, WGM, WGN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nbn = (p.Cout + BN - 1) / BN;
+    const int S = KS * KS * (p.Cin / BK);
+    const long long items = (long long)((p.M + BM - 1) / BM) * nbn * S;
+    const int tile = blockIdx.x;
+    const long long t0 = (long long)tile * S, t1 = t0 + S;
+    const int w_lo = sk_owner(items, p.workers, t0), w_hi = sk_owner(items, p.workers, t1 - 1);
+    if (w_lo == w_hi) return;
+    const int tid = threadIdx.x;
+    f32x16 acc[G::MI][G::NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + wn * WTN + ni * 32 + col_l;
-        const bool cok = col < p.Cout;
-        const float sc = cok ? p.scale[col] : 0.f;
-        const float sh = cok ? p.shift[col] : 0.f;
+    for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int rbase = m0 + wm * WTM + mi * 32 + row_l;
+        for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (cok && row < p.M) {
-                    float v = acc[mi][ni][r] * sc + sh;
-                    if (p.act) v = v > 0.f ? v : 0.1f * v;
-                    const size_t o = (size_t)row * p.Cout + col;
-                    if (p.resid) v += p.resid[o];
-                    p.y[o] = v;
-                }
-            }
-        }
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int w = w_lo; w <= w_hi; ++w) {
+        const long long wb = sk_begin(items, p.workers, w);
+        const int first = (int)(wb / S);
+        const float* slot = p.partial + ((size_t)w * 2 + (tile == first ? 0 : 1)) * (BM * BN);
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += slot[((mi * G::NI + ni) * 16 + r) * 256 + tid];
     }
+    const int bm = tile / nbn, bn = tile - bm * nbn;
+    epilogue<BM, BN, WGM, WGN>(p, smem, acc, bm * BM, bn * BN);
 }
 
 // ---- stem conv: 3x3, Cin = 3 -> COUT (=32), stride 1 ------------------------------------------------
@@ -390,58 +455,84 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int VAR>
-int launch_mfma(hipStream_t stream, const ConvArgs& a) {
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, VAR>;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+template <typename K>
+int set_lds_attr(K kern, size_t lds) {
+    Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return Y3_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
+int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
+    using G = Geo<BM, BN, WGM, WGN>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false>;
     static bool attr_set = false;  // per instantiation; benign race (idempotent)
     if (!attr_set) {
-        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
         attr_set = true;
     }
     const int nbm = (a.M + BM - 1) / BM;
     const int nbn = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
 
-template <int KS, bool UPCAT, int VAR>
-int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
-    if (a.Cout <= 32) return launch_mfma<128, 32, 4, 1, KS, UPCAT, VAR>(stream, a);
-    if (a.Cout <= 64) return launch_mfma<128, 64, 4, 1, KS, UPCAT, VAR>(stream, a);
-    return launch_mfma<128, 128, 2, 2, KS, UPCAT, VAR>(stream, a);
-}
-
-constexpr int DEFAULT_VARIANT = 7;
-
-// Experiment hook: Y3_CONV_VARIANT=<0|1|3|7> selects a kernel variant at run time (tools/conv_bench.py).
-int conv_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("Y3_CONV_VARIANT");
-        v = e ? atoi(e) : DEFAULT_VARIANT;
-        if (v != 0 && v != 1 && v != 3 && v != 7) v = DEFAULT_VARIANT;
+template <int KS>
+int launch_streamk(hipStream_t stream, const ConvArgs& a) {
+    constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
+    using G = Geo<BM, BN, WGM, WGN>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true>;
+    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
+        if (int rc = set_lds_attr(fix, G::LDS_BYTES)) return rc;
+        attr_set = true;
     }
-    return v;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), G::LDS_BYTES, stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(fix, dim3(tiles), dim3(256), G::LDS_BYTES, stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
 }
 
 template <int KS, bool UPCAT>
-int dispatch_var(hipStream_t stream, const ConvArgs& a) {
-    switch (conv_variant()) {
-        case 1: return dispatch_bn<KS, UPCAT, 1>(stream, a);
-        case 3: return dispatch_bn<KS, UPCAT, 3>(stream, a);
-        case 7: return dispatch_bn<KS, UPCAT, 7>(stream, a);
-        default: return dispatch_bn<KS, UPCAT, 0>(stream, a);
+int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
+    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT>(stream, a);
+    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT>(stream, a);
+    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT>(stream, a);
+}
+
+constexpr int SK_WORKERS = 512;  // 256 CUs x 2 co-resident 128x128 workgroups (73.7 KB LDS, 176 VGPRs)
+
+// Schedule choice: stream-K for 3x3 convs on 128x128 tiles whose tile count is within a few multiples
+// of the co-resident workgroup count (tail quantisation dominates there); Y3_CONV_STREAMK=0/1 overrides
+// (experiment hook for tools/conv_bench.py).
+bool use_streamk(const ConvArgs& a, int k, bool has_ws) {
+    if (!has_ws || k != 3 || a.Cout < 128 || a.xu) return false;
+    static int force = -2;
+    if (force == -2) {
+        const char* e = getenv("Y3_CONV_STREAMK");
+        force = e ? atoi(e) : -1;
     }
+    if (force == 0) return false;
+    const int tiles = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    if (force == 1) return true;
+    return tiles < 4 * SK_WORKERS;
 }
 
 }  // namespace
 
+size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d) {
+    if (!d || d->k != 3 || d->cout < 128 || d->c_up > 0) return 0;
+    return (size_t)SK_WORKERS * 2 * 128 * 128 * sizeof(float);
+}
+
 int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
                    const float* w, const float* scale, const float* shift, const float* residual,
-                   float* y) {
+                   float* y, void* workspace, size_t workspace_bytes) {
     Y3_CHECK_ARG(d && x && w && scale && shift && y, "y3_conv2d_fwd: null pointer argument");
     Y3_CHECK_ARG(d->k == 1 || d->k == 3, "y3_conv2d_fwd: kernel_size must be 1 or 3 (got %d)", d->k);
     Y3_CHECK_ARG(d->stride == 1 || d->stride == 2, "y3_conv2d_fwd: stride must be 1 or 2 (got %d)",
@@ -453,6 +544,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     Y3_CHECK_ARG((x_up != nullptr) == (d->c_up > 0), "y3_conv2d_fwd: x_up and c_up must agree");
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
+    a.partial = nullptr; a.workers = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -474,11 +566,18 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
         Y3_CHECK_ARG(d->k == 1 && d->stride == 1, "y3_conv2d_fwd: fused upsample+concat needs a 1x1 s1 conv");
         Y3_CHECK_ARG(d->c_up % BK == 0 && d->c_up < d->cin && d->h % 2 == 0 && d->w % 2 == 0,
                      "y3_conv2d_fwd: bad c_up=%d for cin=%d", d->c_up, d->cin);
-        return dispatch_var<1, true>(stream, a);
+        return dispatch_bn<1, true>(stream, a);
     }
     if (d->k == 1) {
         Y3_CHECK_ARG(d->stride == 1, "y3_conv2d_fwd: 1x1 conv must have stride 1");
-        return dispatch_var<1, false>(stream, a);
+        return dispatch_bn<1, false>(stream, a);
     }
-    return dispatch_var<3, false>(stream, a);
+    const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
+                        ((uintptr_t)workspace & 15) == 0;
+    if (use_streamk(a, d->k, has_ws)) {
+        a.partial = static_cast<float*>(workspace);
+        a.workers = SK_WORKERS;
+        return launch_streamk<3>(stream, a);
+    }
+    return dispatch_bn<3, false>(stream, a);
 }

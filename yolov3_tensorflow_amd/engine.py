@@ -47,8 +47,23 @@ def prepare_conv_params(w_var, bn_vars=None, bias_var=None):
     return w_dev, scale, shift
 
 
-def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up=None):
-    """y = act(conv(x) * scale + shift) + residual on NHWC fp32 device tensors (y3_conv2d_fwd)."""
+_scratch = {}
+
+
+def _conv_scratch(device, nbytes):
+    """Per-(device, stream) scratch for the stream-K schedule (kernels on one stream are ordered, so one
+    buffer per stream is enough)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _scratch[key] = t
+    return t
+
+
+def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up=None, use_workspace=True):
+    """y = act(conv(x) * scale + shift) + residual on NHWC fp32 device tensors (y3_conv2d_fwd).
+    use_workspace=False forces the data-parallel schedule (no scratch)."""
     n, h, w, cx = x.shape
     c_up = 0
     if x_up is not None:
@@ -57,9 +72,14 @@ def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up
             raise ValueError("x_up must be [N, H/2, W/2, C] for the fused upsample+concat input")
     d = _lib.ConvDesc(n, h, w, cx + c_up, c_up, cout, k, stride, 1 if act else 0)
     y = torch.empty((n, h // stride, w // stride, cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().y3_conv2d_fwd(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(x_up),
-                                        fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
-                                        fw.ptr(y)))
+    L = _lib.lib()
+    ws, ws_bytes = None, 0
+    if use_workspace:
+        ws_bytes = L.y3_conv_workspace_bytes(ctypes.byref(d))
+        ws = _conv_scratch(x.device, ws_bytes) if ws_bytes else None
+    _lib.check(L.y3_conv2d_fwd(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(x_up),
+                               fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
+                               fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y
 
 
