@@ -194,17 +194,32 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w), 0, (unsigned)((size_t)KS * KS * p.Cout * p.Cin * 4), 0x00020000);
 
-    // loader state: the tile and K-step the NEXT load_tile() call fetches
+    // loader state: the tile and K-step the NEXT load_tile() call fetches.  Per-lane byte offsets (voff) are
+    // recomputed only when the tap changes; inside a tap the channel chunk advances through the scalar
+    // soffset operand of the buffer load, so a K-step costs 8 loads and a handful of scalar instructions.
     int a_base[AROWS];  // element offset of (n, iy0, ix0, 0) in x (may be negative at the border)
     int a_iy0[AROWS], a_ix0[AROWS];
     int a_base_u[UPCAT ? AROWS : 1];
-    int ld_n0 = 0, ld_tap = 0, ld_cc = 0;
+    unsigned a_voff[AROWS], a_voff_u[UPCAT ? AROWS : 1], b_voff[BROWS];
+    int ld_tap = 0, ld_cc = 0;
+
+    auto set_tap = [&]() {
+        const int ky = (KS == 1) ? 0 : ld_tap / KS;
+        const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
+        const int tap_off = (ky * p.W + kx) * p.Cx + c4;
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            a_voff[j] = ok ? (unsigned)(a_base[j] + tap_off) * 4u : OOB;
+            if (UPCAT) a_voff_u[j] = ok ? (unsigned)(a_base_u[j] + c4) * 4u : OOB;
+        }
+    };
 
     auto set_loader = [&](long long it) {
         const int tile = (int)(it / S);
         const int ks = (int)(it - (long long)tile * S);
         const int bm = tile / nbn, bn = tile - bm * nbn;
-        ld_n0 = bn * BN;
         ld_tap = ks / kchunks;
         ld_cc = ks - ld_tap * kchunks;
         const int HoWo = p.Ho * p.Wo;
@@ -229,44 +244,45 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
                 if (UPCAT) a_base_u[j] = 0;
             }
         }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int co = bn * BN + r0 + 32 * j;
+            b_voff[j] = co < p.Cout ? (unsigned)(co * p.Cin + c4) * 4u : OOB;
+        }
+        set_tap();
     };
 
     f32x4 ra[AROWS], rb[BROWS];
 
-    auto load_tile = [&]() {
+    // issue the 8 buffer loads of the prepared K-step (branch-free), then advance the loader by one K-step
+    auto issue_loads = [&]() {
         const int c0 = ld_cc * BK;
-        const int ky = (KS == 1) ? 0 : ld_tap / KS;
-        const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
         if (UPCAT) {
+            // channels [0, Cu) come from the half-resolution tensor, the rest from the route tensor
             const bool from_up = c0 < p.Cu;
+            const unsigned soff = (unsigned)(from_up ? c0 : c0 - p.Cu) * 4u;
 #pragma unroll
-            for (int j = 0; j < AROWS; ++j) {
-                const bool ok = a_iy0[j] >= 0;
-                const unsigned off = from_up ? (unsigned)(a_base_u[j] + c0 + c4) * 4u
-                                             : (unsigned)(a_base[j] + (c0 - p.Cu) + c4) * 4u;
-                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      from_up ? rs_u : rs_x, ok ? off : OOB, 0, 0));
-            }
+            for (int j = 0; j < AROWS; ++j)
+                ra[j] = __builtin_bit_cast(
+                    f32x4, from_up ? __builtin_amdgcn_raw_buffer_load_b128(rs_u, a_voff_u[j], soff, 0)
+                                   : __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], soff, 0));
         } else {
-            const int tap_off = (ky * p.W + kx) * p.Cx + c0 + c4;
+            const unsigned soff = (unsigned)c0 * 4u;
 #pragma unroll
-            for (int j = 0; j < AROWS; ++j) {
-                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const unsigned off = (unsigned)(a_base[j] + tap_off) * 4u;
-                ra[j] = __builtin_bit_cast(f32x4,
-                                           __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0));
-            }
+            for (int j = 0; j < AROWS; ++j)
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], soff, 0));
         }
-        const unsigned wbase = (unsigned)((ld_tap * p.Cout) * p.Cin + c0 + c4) * 4u;
+        const unsigned wsoff = (unsigned)((ld_tap * p.Cout) * p.Cin + c0) * 4u;
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) {
-            const int co = ld_n0 + r0 + 32 * j;
-            const unsigned off = wbase + (unsigned)(co * p.Cin) * 4u;
-            rb[j] = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, co < p.Cout ? off : OOB, 0, 0));
+        for (int j = 0; j < BROWS; ++j)
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff[j], wsoff, 0));
+    };
+    auto advance = [&]() {
+        if (++ld_cc == kchunks) {
+            ld_cc = 0;
+            ++ld_tap;
+            if (KS > 1 && ld_tap < KS * KS) set_tap();
         }
-        if (++ld_cc == kchunks) { ld_cc = 0; ++ld_tap; }
     };
 
     auto store_tile = [&](int buf) {
@@ -307,9 +323,39 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
         }
     };
 
+    // Interleave the memory instructions of one K-step into the shadow of its 64 MFMAs (a wave issues in
+    // order and an MFMA occupies the matrix pipe for 64 cycles, so whatever sits BETWEEN two MFMAs is free,
+    // whatever sits before the first or after the last one is exposed): loads of K-step t+1 behind the
+    // first MFMAs, fragment reads of the second half behind the second quarter, LDS writes behind the last
+    // quarter.
+    auto pipeline_hint = [&]() {
+        constexpr int MF = MI * NI * 4;   // MFMAs per k-group of 8
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);          // fragments of k-groups 0,1
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < AROWS + BROWS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 2 * (MI + NI)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // fragments 2,3
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < AROWS + BROWS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        }
+    };
+
     // ---- segments: maximal runs of K-steps of one tile inside this workgroup's item range --------
+    // Invariant at the top of a segment: ra/rb hold (or are receiving) its first K-step and the loader is
+    // prepared for its second one.
     set_loader(item);
-    load_tile();
+    issue_loads();
+    advance();
     while (item < item_end) {
         const int tile = (int)(item / S);
         const int ks = (int)(item - (long long)tile * S);
@@ -326,20 +372,23 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-        store_tile(0);  // the registers hold this segment's first K-step
+        store_tile(0);
         __syncthreads();
-        for (int t = 0; t < nsteps; ++t) {
-            const bool more = (t + 1) < nsteps;
-            if (more) {
-                load_tile();
-            } else if (STREAMK && seg_end < item_end) {
-                set_loader(seg_end);  // prefetch across the tile boundary; stored after the epilogue
-                load_tile();
-            }
+        for (int t = 0; t + 1 < nsteps; ++t) {
+            issue_loads();               // K-step t+1
             compute_tile(t & 1);
-            if (more) store_tile((t + 1) & 1);
+            store_tile((t + 1) & 1);
+            pipeline_hint();
+            advance();                   // prepare K-step t+2 (scalar branch on a tap change)
             __syncthreads();
         }
+        if (STREAMK && seg_end < item_end) {
+            set_loader(seg_end);         // prefetch across the tile boundary; stored after the epilogue
+            issue_loads();
+            advance();
+        }
+        compute_tile((nsteps - 1) & 1);
+        __syncthreads();
 
         if (!STREAMK || (ks == 0 && seg_end == tile_end)) {
             epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0);
