@@ -72,6 +72,23 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
     const int wm = wave / WGN, wn = wave % WGN;
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     if ((p.Cout & 3) == 0) {
+        constexpr int C4 = BN / 4;     // float4 columns per tile row
+        constexpr int RPP = 256 / C4;  // rows covered per pass
+        constexpr int PASSES = BM / RPP;
+        const int tc = (tid % C4) * 4, tr = tid / C4;
+        const int col = n0 + tc;
+        const bool cok = col < p.Cout;
+        // residual tile first: its HBM/L2 latency overlaps the LDS staging below
+        f32x4 res[PASSES];
+        if (p.resid) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const int row = m0 + tr + i * RPP;
+                res[i] = (cok && row < p.M)
+                             ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)row * p.Cout + col)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         float* cs = smem;
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni)
@@ -82,15 +99,12 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                     cs[(wm * G::WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2)) * G::LDC + wn * G::WTN +
                        ni * 32 + col_l] = acc[mi][ni][r];
         __syncthreads();
-        constexpr int C4 = BN / 4;     // float4 columns per tile row
-        constexpr int RPP = 256 / C4;  // rows covered per pass
-        const int tc = (tid % C4) * 4, tr = tid / C4;
-        const int col = n0 + tc;
-        if (col < p.Cout) {
+        if (cok) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-#pragma unroll 4
-            for (int rr = tr; rr < BM; rr += RPP) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const int rr = tr + i * RPP;
                 const int row = m0 + rr;
                 if (row < p.M) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * G::LDC + tc);
@@ -99,9 +113,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                     }
-                    const size_t o = (size_t)row * p.Cout + col;
-                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
-                    *reinterpret_cast<f32x4*>(p.y + o) = v;
+                    if (p.resid) v += res[i];
+                    *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.Cout + col) = v;
                 }
             }
         }
@@ -149,7 +162,7 @@ __device__ __forceinline__ int sk_worker_id(int b, int workers) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK>
-__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     constexpr int MI = G::MI, NI = G::NI, WTM = G::WTM, WTN = G::WTN;
     constexpr int AROWS = BM / 32, BROWS = BN / 32;  // float4 rows each thread stages
@@ -395,12 +408,16 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
         } else {
             // partial tile: raw accumulators to this worker's slot (0 = its first tile, 1 = its last)
             float* slot = p.partial + ((size_t)worker * 2 + (tile == (int)first_tile ? 0 : 1)) * (BM * BN);
+            f32x4* slot4 = reinterpret_cast<f32x4*>(slot);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) slot[((mi * NI + ni) * 16 + r) * 256 + tid] = acc[mi][ni][r];
+                    for (int g = 0; g < 4; ++g)   // 16 bytes per lane: registers 4g..4g+3
+                        slot4[((mi * NI + ni) * 4 + g) * 256 + tid] =
+                            f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2],
+                                  acc[mi][ni][4 * g + 3]};
         }
         if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
@@ -410,7 +427,7 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvArgs p) {
 // Stream-K fix-up: one workgroup per output tile; tiles computed whole by one worker exit at once, split
 // tiles sum their partials in worker (= K) order and run the common epilogue.
 template <int BM, int BN, int WGM, int WGN, int KS>
-__global__ void __launch_bounds__(256) conv_streamk_fixup_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nbn = (p.Cout + BN - 1) / BN;
@@ -432,12 +449,17 @@ __global__ void __launch_bounds__(256) conv_streamk_fixup_kernel(const ConvArgs 
         const long long wb = sk_begin(items, p.workers, w);
         const int first = (int)(wb / S);
         const float* slot = p.partial + ((size_t)w * 2 + (tile == first ? 0 : 1)) * (BM * BN);
+        const f32x4* slot4 = reinterpret_cast<const f32x4*>(slot);
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += slot[((mi * G::NI + ni) * 16 + r) * 256 + tid];
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = slot4[((mi * G::NI + ni) * 4 + g) * 256 + tid];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mi][ni][4 * g + q] += v[q];
+                }
     }
     const int bm = tile / nbn, bn = tile - bm * nbn;
     epilogue<BM, BN, WGM, WGN>(p, smem, acc, bm * BM, bn * BN);
