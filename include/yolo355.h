@@ -150,7 +150,10 @@ int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* works
  * 256) records one event per layer boundary; y3_net_get_layer_ms synchronises on the last event, writes
  * the per-layer elapsed ms averaged over the forwards recorded since the previous call, and resets. */
 int y3_net_set_profiling(y3_net* net, int enabled);
-int y3_net_get_layer_ms(y3_net* net, float* ms, int count);
+int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int count);
+/* ms_tail (nullable): for layers that launch two kernels (stream-K conv + its fix-up) the part of ms[i]
+ * spent after the main kernel; equals ms[i] for single-kernel layers (their mark precedes the launch). */
+int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w);
 
 #ifdef __cplusplus
 }

@@ -313,8 +313,8 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
     hipEvent_t* ev = nullptr;
     if (net->profiling && net->sets_used < 256) {
         if (net->sets_used == net->event_sets.size()) {
-            std::vector<hipEvent_t> set(nl + 1, nullptr);
-            for (size_t i = 0; i <= nl; ++i) Y3_CHECK_HIP(hipEventCreate(&set[i]));
+            std::vector<hipEvent_t> set(2 * nl + 1, nullptr);   // nl+1 layer boundaries, nl mid-layer marks
+            for (size_t i = 0; i < set.size(); ++i) Y3_CHECK_HIP(hipEventCreate(&set[i]));
             net->event_sets.push_back(set);
         }
         ev = net->event_sets[net->sets_used++].data();
@@ -326,12 +326,26 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         y3_conv_desc d;
         d.n = n; d.h = h / in.sdiv; d.w = w / in.sdiv;
         d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
+        // the mid event is recorded only by two-kernel (stream-K) layers; pre-record it so that it is
+        // always valid, a later record by the launcher supersedes it
+        if (ev) Y3_CHECK_HIP(hipEventRecord(ev[nl + 1 + i], st));
         const int rc = y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
-                                      ptr(l.dst), base + net->arena_bytes, net->scratch_bytes);
+                                      ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
+                                      ev ? ev[nl + 1 + i] : nullptr);
         if (rc != Y3_OK) return rc;
         if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
     }
     return Y3_OK;
+}
+
+extern "C" int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w) {
+    if (!net || i < 0 || i >= (int)net->layers.size() || n <= 0 || h <= 0 || w <= 0) return 0;
+    const Layer& l = net->layers[i];
+    const Tensor& in = net->tensors[l.src];
+    y3_conv_desc d;
+    d.n = n; d.h = h / in.sdiv; d.w = w / in.sdiv;
+    d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
+    return y3_conv_schedule_impl(&d);
 }
 
 extern "C" int y3_net_set_profiling(y3_net* net, int enabled) {
@@ -341,7 +355,7 @@ extern "C" int y3_net_set_profiling(y3_net* net, int enabled) {
     return Y3_OK;
 }
 
-extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, int count) {
+extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int count) {
     Y3_CHECK_ARG(net && ms, "y3_net_get_layer_ms: null argument");
     Y3_CHECK_ARG(count == (int)net->layers.size(), "y3_net_get_layer_ms: count must be %zu",
                  net->layers.size());
@@ -349,7 +363,10 @@ extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, int count) {
         y3_set_error("y3_net_get_layer_ms: no profiled forward has run");
         return Y3_ESTATE;
     }
-    for (int i = 0; i < count; ++i) ms[i] = 0.f;
+    for (int i = 0; i < count; ++i) {
+        ms[i] = 0.f;
+        if (ms_tail) ms_tail[i] = 0.f;
+    }
     for (size_t s = 0; s < net->sets_used; ++s) {
         hipEvent_t* ev = net->event_sets[s].data();
         Y3_CHECK_HIP(hipEventSynchronize(ev[count]));
@@ -357,9 +374,19 @@ extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, int count) {
             float t = 0.f;
             Y3_CHECK_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
             ms[i] += t;
+            if (ms_tail) {
+                // time after the layer's main kernel (stream-K fix-up); 0 for single-kernel layers up to
+                // event granularity, because their mid event was recorded before the launch
+                float u = 0.f;
+                Y3_CHECK_HIP(hipEventElapsedTime(&u, ev[count + 1 + i], ev[i + 1]));
+                ms_tail[i] += u;
+            }
         }
     }
-    for (int i = 0; i < count; ++i) ms[i] /= (float)net->sets_used;
+    for (int i = 0; i < count; ++i) {
+        ms[i] /= (float)net->sets_used;
+        if (ms_tail) ms_tail[i] /= (float)net->sets_used;
+    }
     net->sets_used = 0;
     return Y3_OK;
 }

@@ -550,7 +550,7 @@ int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
 }
 
 template <int KS>
-int launch_streamk(hipStream_t stream, const ConvArgs& a) {
+int launch_streamk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
     auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true>;
@@ -564,6 +564,7 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
+    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));  // profiling: main kernel | fix-up
     hipLaunchKernelGGL(fix, dim3(tiles), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
@@ -596,6 +597,16 @@ bool use_streamk(const ConvArgs& a, int k, bool has_ws) {
 
 }  // namespace
 
+// 1 if y3_launch_conv would pick the stream-K schedule for this conv when given a workspace.
+int y3_conv_schedule_impl(const y3_conv_desc* d) {
+    if (!d || d->k != 3 || d->cin == 3 || d->c_up > 0) return 0;
+    ConvArgs a;
+    a.xu = nullptr;
+    a.Cout = d->cout;
+    a.M = d->n * (d->h / d->stride) * (d->w / d->stride);
+    return use_streamk(a, d->k, true) ? 1 : 0;
+}
+
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d) {
     if (!d || d->k != 3 || d->cout < 128 || d->c_up > 0) return 0;
     return (size_t)SK_WORKERS * 2 * 128 * 128 * sizeof(float);
@@ -603,7 +614,7 @@ size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d) {
 
 int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
                    const float* w, const float* scale, const float* shift, const float* residual,
-                   float* y, void* workspace, size_t workspace_bytes) {
+                   float* y, void* workspace, size_t workspace_bytes, hipEvent_t mid_event) {
     Y3_CHECK_ARG(d && x && w && scale && shift && y, "y3_conv2d_fwd: null pointer argument");
     Y3_CHECK_ARG(d->k == 1 || d->k == 3, "y3_conv2d_fwd: kernel_size must be 1 or 3 (got %d)", d->k);
     Y3_CHECK_ARG(d->stride == 1 || d->stride == 2, "y3_conv2d_fwd: stride must be 1 or 2 (got %d)",
@@ -648,7 +659,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     if (use_streamk(a, d->k, has_ws)) {
         a.partial = static_cast<float*>(workspace);
         a.workers = SK_WORKERS;
-        return launch_streamk<3>(stream, a);
+        return launch_streamk<3>(stream, a, mid_event);
     }
     return dispatch_bn<3, false>(stream, a);
 }

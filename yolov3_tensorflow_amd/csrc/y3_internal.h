@@ -36,5 +36,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Launchers implemented in the .hip files (all asynchronous on `stream`).
 int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
                    const float* w, const float* scale, const float* shift, const float* residual,
-                   float* y, void* workspace, size_t workspace_bytes);
+                   float* y, void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d);
+int y3_conv_schedule_impl(const y3_conv_desc* d);
