@@ -155,6 +155,74 @@ int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int count);
  * spent after the main kernel; equals ms[i] for single-kernel layers (their mark precedes the launch). */
 int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w);
 
+/* graph topology of y3_net (tensor ids: 0 = network input, 1.. = conv outputs in creation order; -1 = none) */
+int y3_net_layer_graph(const y3_net* net, int i, int* src, int* up, int* resid, int* dst, int* act);
+int y3_net_num_tensors(const y3_net* net);
+int y3_net_tensor_info(const y3_net* net, int t, int* channels, int* sdiv, int* ext);
+
+/* ==== training path (train.py:72-115 of the reference) ==========================
+ * All reductions are two-stage with a fixed combination order (no float atomics): deterministic. */
+
+/* K8: batch norm in batch-statistics mode (model.py:35-41 with is_training=True, train.py:74).
+ * z [rows][c] raw conv output.  Computes the batch mean / biased variance over rows, writes mean, inv_std
+ * = rsqrt(var+eps), the folded scale = gamma*inv_std and shift = beta - mean*scale for y3_bn_apply_fwd, and
+ * (if non-NULL) updates the moving statistics in place: moving <- moving*decay + batch*(1-decay), the
+ * UNBIASED variance going into moving_var (TF fused batch norm).  scratch: y3_reduce_scratch_bytes(c). */
+size_t y3_reduce_scratch_bytes(int c);
+int y3_bn_train_stats(y3_ctx* ctx, const float* z, long long rows, int c, const float* gamma, const float* beta,
+                      float eps, float decay, float* mean, float* inv_std, float* scale, float* shift,
+                      float* moving_mean, float* moving_var, float* scratch);
+/* y = act(z*scale + shift) + residual   (act: 1 = LeakyReLU(0.1); residual may be NULL) */
+int y3_bn_apply_fwd(y3_ctx* ctx, const float* z, const float* scale, const float* shift, const float* residual,
+                    long long rows, int c, int act, float* y);
+/* Backward of leaky(BN_train(z)): given dy, writes d gamma, d beta and dz (dz may alias dy).
+ * scratch: y3_bn_bwd_scratch_bytes(c). */
+size_t y3_bn_bwd_scratch_bytes(int c);
+int y3_bn_train_bwd(y3_ctx* ctx, const float* z, const float* dy, const float* gamma, const float* scale,
+                    const float* shift, const float* mean, const float* inv_std, long long rows, int c,
+                    float* dgamma, float* dbeta, float* dz, float* scratch);
+/* d bias = sum over rows of dy [rows][c] (detection convs, model.py:55-57); scratch: 1024*c floats */
+int y3_bias_grad(y3_ctx* ctx, const float* dy, long long rows, int c, float* dbias, float* scratch);
+
+/* K9: conv backward (TF autodiff of slim.conv2d, train.py:112).  `fwd` describes the FORWARD layer
+ * (n,h,w = its input size; c_up must be 0: training materialises the upsample+concat).
+ * dgrad: dx [n,h,w,cin] (+)= data gradient.  dz is [n,h/s,w/s] x dz_stride channels (dz_stride >= cout,
+ *        multiple of 32: the 3*(5+C) detection convs pad to the next multiple), w_d = the HWIO kernel with
+ *        its last axis padded to dz_stride ([k*k][cin][dz_stride]); `ones`/`zeros` are [cin] device vectors.
+ * wgrad: dw_hwio [k][k][cin][cout] = weight gradient; scratch: y3_conv_wgrad_scratch_bytes(fwd). */
+int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride, const float* w_d,
+                    const float* ones, const float* zeros, int accumulate, float* dx, void* workspace,
+                    size_t workspace_bytes);
+size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* fwd);
+int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,
+                  float* dw_hwio, void* scratch, size_t scratch_bytes);
+/* backward routing: 2x2 sum of the gradient of a nearest-upsampled tensor (g has g_channels per pixel, the
+ * first c belong to the upsampled part), channel-slice (accumulate), zero-extension of the channel axis */
+int y3_upsample2x_bwd(y3_ctx* ctx, const float* g, int g_channels, int n, int h, int w, int c, int accumulate,
+                      float* dx);
+int y3_slice_accumulate(y3_ctx* ctx, const float* src, int src_channels, int offset, long long rows, int c,
+                        int accumulate, float* dst);
+int y3_pad_channels(y3_ctx* ctx, const float* src, int c_src, long long rows, int c_dst, float* dst);
+
+/* K10: loss_layer forward + backward for one scale (model.py:192-304, box_iou :307-345).
+ * feature_map [n,gh,gw,3*(5+C)], y_true [n,gh,gw,3,6+C] (utils/data_utils.py:69-113 layout), anchors3 = the
+ * 3 (w,h) pairs of this scale.  loss4 (device, 4 floats: xy, wh, conf, class; each already divided by N)
+ * is overwritten or accumulated; grad [n,gh,gw] x grad_stride receives d(sum of the four)/d(feature_map). */
+size_t y3_loss_scratch_bytes(int n, int gh, int gw);
+int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float* y_true, int n, int gh, int gw,
+                  int class_num, int img_h, int img_w, const float* anchors3_host, int use_label_smooth,
+                  int use_focal_loss, int accumulate, float* loss4, float* grad, int grad_stride, void* scratch,
+                  size_t scratch_bytes);
+
+/* K11: g <- g*grad_scale + weight_decay*w (slim.l2_regularizer, model.py:49) ; g <- tf.clip_by_norm(g, clip)
+ * (train.py:113-114) ; TF1 update rule (utils/misc_utils.py:151-161).  kind: 0 sgd, 1 momentum (slot0 =
+ * accumulator), 2 adam (slot0 = m, slot1 = v, decay = beta1, lr = lr_t), 3 rmsprop (slot0 = ms, slot1 = mom).
+ * scratch: y3_optimizer_scratch_bytes(). */
+size_t y3_optimizer_scratch_bytes(void);
+int y3_clip_update(y3_ctx* ctx, int kind, float* w, float* g, float* slot0, float* slot1, long long n,
+                   float weight_decay, float grad_scale, float clip_norm, float lr, float momentum, float decay,
+                   float beta2, float eps, float* scratch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,234 @@
+"""GPU parity of the training path against the torch-autograd oracle (oracle/train_ref.py, fp64):
+conv weight/data gradients, batch-norm train forward/backward, the YOLO loss and its gradient, and one
+whole train step (loss 5-tuple, clipped gradients, updated variables, BN moving statistics) for each of
+the four optimizers.  Tolerances (stated): per-op 2e-4 relative to the tensor's max magnitude; whole-step
+gradients 1e-2 relative to the tensor's max |grad| (fp32 through 75 layers forward and back, with batch-norm
+statistics over as few as 32 samples at this test size, vs fp64; the fp32 CPU oracle's own deviation from
+fp64 is printed next to it for scale); loss values 1e-4 relative."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import COCO_ANCHORS, blob_images
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, want):
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-12))
+
+
+def _ctx():
+    from yolov3_tensorflow_amd import framework as fw, _lib
+    return fw, _lib, _lib.lib(), fw.context()
+
+
+@pytest.mark.parametrize('n,h,w,k,stride,cin,cout', [
+    (2, 20, 28, 3, 1, 64, 128), (2, 20, 28, 1, 1, 128, 64), (3, 16, 24, 3, 2, 32, 64),
+    (2, 13, 13, 1, 1, 256, 255), (2, 26, 26, 3, 1, 32, 64), (1, 40, 40, 3, 1, 3, 32), (2, 12, 12, 3, 2, 128, 256),
+])
+def test_conv_wgrad_and_dgrad_match_autograd(n, h, w, k, stride, cin, cout):
+    fw, _lib, L, ctx = _ctx()
+    dev = fw.default_device()
+    rng = np.random.RandomState(cin + cout + k)
+    x = torch.tensor(rng.standard_normal((n, h, w, cin)), dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(rng.standard_normal((k, k, cin, cout)) * 0.1, dtype=torch.float64, requires_grad=True)
+    xp = x.permute(0, 3, 1, 2)
+    if stride > 1:
+        xp = F.pad(xp, (1, 1, 1, 1))
+        z = F.conv2d(xp, wt.permute(3, 2, 0, 1), stride=stride)
+    else:
+        z = F.conv2d(xp, wt.permute(3, 2, 0, 1), padding=k // 2)
+    ho, wo = z.shape[2], z.shape[3]
+    dz = rng.standard_normal((n, ho, wo, cout))
+    z.backward(torch.tensor(dz).permute(0, 3, 1, 2))
+    stride_c = ((cout + 31) // 32) * 32
+    dzp = np.zeros((n, ho, wo, stride_c), np.float32)
+    dzp[..., :cout] = dz
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, k, stride, 0)
+    xg = torch.tensor(x.detach().numpy(), dtype=torch.float32, device=dev)
+    dzg = torch.from_numpy(dzp).to(dev)
+    wg = torch.tensor(wt.detach().numpy(), dtype=torch.float32, device=dev)
+    # weight gradient
+    dw = torch.empty((k, k, cin, cout), device=dev)
+    sc = torch.empty(L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xg), fw.ptr(dzg), stride_c, fw.ptr(dw), fw.ptr(sc),
+                               ctypes.c_size_t(sc.numel())))
+    assert rel_err(dw.cpu().numpy(), wt.grad.numpy()) < 2e-4
+    if cin == 3:
+        return
+    # data gradient (overwrite, then accumulate on top)
+    w_d = torch.zeros((k * k * cin, stride_c), device=dev)
+    w_d[:, :cout] = wg.reshape(k * k * cin, cout)
+    ones, zeros = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+    dx = torch.empty((n, h, w, cin), device=dev)
+    ws = torch.empty(512 * 2 * 128 * 128 * 4, dtype=torch.uint8, device=dev)
+    for acc, mult in ((0, 1.0), (1, 2.0)):
+        _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dzg), stride_c, fw.ptr(w_d), fw.ptr(ones),
+                                     fw.ptr(zeros), acc, fw.ptr(dx), fw.ptr(ws), ctypes.c_size_t(ws.numel())))
+        assert rel_err(dx.cpu().numpy(), mult * x.grad.numpy()) < 2e-4, 'accumulate=%d' % acc
+
+
+@pytest.mark.parametrize('rows,c', [(2 * 13 * 13, 1024), (3 * 20 * 28, 64), (5000, 32), (64, 256)])
+def test_bn_train_forward_backward(rows, c):
+    fw, _lib, L, ctx = _ctx()
+    dev = fw.default_device()
+    rng = np.random.RandomState(rows + c)
+    z = torch.tensor(rng.standard_normal((rows, c)) * 2 + rng.standard_normal(c), dtype=torch.float64, requires_grad=True)
+    gamma = torch.tensor(rng.uniform(0.5, 1.5, c), dtype=torch.float64, requires_grad=True)
+    beta = torch.tensor(rng.normal(0, 0.3, c), dtype=torch.float64, requires_grad=True)
+    resid = rng.standard_normal((rows, c))
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    u = (z - mean) * gamma / torch.sqrt(var + 1e-5) + beta
+    y = torch.where(u > 0, u, 0.1 * u) + torch.tensor(resid)
+    dy = rng.standard_normal((rows, c))
+    y.backward(torch.tensor(dy))
+    f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=dev)
+    zg, gg, bg = f32(z.detach().numpy()), f32(gamma.detach().numpy()), f32(beta.detach().numpy())
+    stats = torch.empty((4, c), device=dev)
+    mm, mv = f32(np.full(c, 0.25)), f32(np.full(c, 2.0))
+    sc = torch.empty(L.y3_bn_bwd_scratch_bytes(c), dtype=torch.uint8, device=dev)
+    _lib.check(L.y3_bn_train_stats(ctx, fw.ptr(zg), rows, c, fw.ptr(gg), fw.ptr(bg), ctypes.c_float(1e-5),
+                                   ctypes.c_float(0.9), fw.ptr(stats[0]), fw.ptr(stats[1]), fw.ptr(stats[2]),
+                                   fw.ptr(stats[3]), fw.ptr(mm), fw.ptr(mv), fw.ptr(sc)))
+    yg = torch.empty((rows, c), device=dev)
+    _lib.check(L.y3_bn_apply_fwd(ctx, fw.ptr(zg), fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(f32(resid)), rows, c, 1,
+                                 fw.ptr(yg)))
+    assert rel_err(stats[0].cpu().numpy(), mean.detach().numpy()) < 1e-5
+    assert rel_err(yg.cpu().numpy(), y.detach().numpy()) < 2e-5
+    unb = var.detach().numpy() * rows / (rows - 1.0)
+    np.testing.assert_allclose(mm.cpu().numpy(), 0.25 * 0.9 + mean.detach().numpy() * 0.1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mv.cpu().numpy(), 2.0 * 0.9 + unb * 0.1, rtol=1e-5, atol=1e-6)
+    dyg = f32(dy)
+    dgam, dbet = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    _lib.check(L.y3_bn_train_bwd(ctx, fw.ptr(zg), fw.ptr(dyg), fw.ptr(gg), fw.ptr(stats[2]), fw.ptr(stats[3]),
+                                 fw.ptr(stats[0]), fw.ptr(stats[1]), rows, c, fw.ptr(dgam), fw.ptr(dbet),
+                                 fw.ptr(dyg), fw.ptr(sc)))
+    assert rel_err(dgam.cpu().numpy(), gamma.grad.numpy()) < 2e-4
+    assert rel_err(dbet.cpu().numpy(), beta.grad.numpy()) < 2e-4
+    assert rel_err(dyg.cpu().numpy(), z.grad.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize('smooth,focal', [(False, False), (True, True)])
+def test_loss_and_its_gradient_match_oracle(smooth, focal):
+    import yolov3_tensorflow_amd as y3
+    from oracle import train_ref
+    rng = np.random.RandomState(3)
+    n, size = 3, 160
+    model = y3.yolov3(80, COCO_ANCHORS, use_label_smooth=smooth, use_focal_loss=focal)
+    model.img_size = [size, size]
+    fms = [(rng.standard_normal((n, size // s, size // s, 255)) * 1.5).astype(np.float32) for s in (32, 16, 8)]
+    yts = train_ref.synthetic_targets(9, n, [size, size], 80, COCO_ANCHORS, max_boxes=6)
+    yts[1][1] = 0; yts[1][1][..., -1] = 1          # one image without objects on the 26-grid scale
+    g = train_ref.TrainGraph({}, 80, torch.float64)
+    g.img_size = [size, size]
+    tf = [torch.tensor(f, dtype=torch.float64, requires_grad=True) for f in fms]
+    ref = g.compute_loss(tf, yts, COCO_ANCHORS, smooth, focal)
+    ref[0].backward()
+    got = model.compute_loss(fms, yts)
+    for a, b in zip(got, ref):
+        assert abs(float(a) - float(b)) <= 1e-4 * abs(float(b)) + 1e-6, (float(a), float(b))
+    for gg, t in zip(model._train['fm_grads'], tf):
+        gnp = gg.cpu().numpy()
+        assert np.all(gnp[..., 255:] == 0)
+        assert rel_err(gnp[..., :255], t.grad.numpy()) < 2e-4
+    # the single-scale API of the reference
+    parts = model.loss_layer(fms[0], yts[0], COCO_ANCHORS[6:9])
+    ref0 = g.loss_layer(torch.tensor(fms[0], dtype=torch.float64), yts[0], COCO_ANCHORS[6:9], smooth, focal)
+    for a, b in zip(parts, ref0):
+        assert abs(float(a) - float(b)) <= 1e-4 * abs(float(b)) + 1e-6
+    with pytest.raises(ValueError):
+        model.compute_loss(fms, [yts[0], yts[0], yts[2]])
+
+
+def _fresh_model(params, **kw):
+    import yolov3_tensorflow_amd as y3
+    y3.reset_default_graph()
+    model = y3.yolov3(80, COCO_ANCHORS, **kw)
+    with y3.variable_scope('yolov3'):
+        model.forward(torch.zeros(1, 32, 32, 3))
+    for v in y3.global_variables(scope='yolov3'):
+        v.assign(params[v.op_name])
+    return model
+
+
+@pytest.mark.parametrize('optimizer,update_scopes', [('sgd', None), ('momentum', None), ('adam', None),
+                                                     ('rmsprop', None), ('momentum', ['yolov3/yolov3_head'])])
+def test_one_train_step_matches_oracle(optimizer, update_scopes):
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    from oracle import yolo_ref, train_ref
+    params = yolo_ref.synthetic_params(80, seed=1)
+    n, size = 2, 128
+    x = blob_images(21, n, size)
+    yts = train_ref.synthetic_targets(5, n, [size, size], 80, COCO_ANCHORS, max_boxes=4)
+    lr = 1e-3
+    ref = train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer=optimizer, lr=lr, weight_decay=5e-4,
+                               bn_decay=0.99, update_scopes=update_scopes, dtype=torch.float64, step=1)
+    model = _fresh_model(params, batch_norm_decay=0.99, weight_decay=5e-4)
+    upd = None if update_scopes is None else [v for v in y3.global_variables(scope='yolov3')
+                                              if any(v.op_name.startswith(s) for s in update_scopes)]
+    trainer = training.Trainer(model, config_optimizer(optimizer, lr), update_vars=upd)
+    with y3.variable_scope('yolov3'):
+        loss = trainer.step(x, yts)
+    for a, b in zip(loss, ref['loss']):
+        assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-6, ([float(v) for v in loss], ref['loss'])
+    # clipped gradients (incl. the L2 term), every trainable variable
+    assert set(trainer.views) == set(ref['grads'])
+    worst, errs = 0.0, []
+    for name, g in ref['grads'].items():
+        e = rel_err(trainer.views[name].cpu().numpy(), g)
+        errs.append(e)
+        worst = max(worst, e)
+        assert e < 1e-2, '%s: grad rel err %.3e' % (name, e)
+    msg = '%s: gradient rel err vs fp64 oracle: worst %.2e, median %.2e over %d tensors' % (
+        optimizer, worst, float(np.median(errs)), len(errs))
+    if optimizer == 'sgd':
+        ref32 = train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer=optimizer, lr=lr, weight_decay=5e-4,
+                                     bn_decay=0.99, update_scopes=update_scopes, dtype=torch.float32, step=1)
+        e32 = [rel_err(ref32['grads'][k], ref['grads'][k]) for k in ref['grads']]
+        msg += ' ; CPU fp32 oracle vs fp64: worst %.2e, median %.2e' % (max(e32), float(np.median(e32)))
+    print(msg)
+    # updated variables and BN moving statistics
+    for v in y3.global_variables(scope='yolov3'):
+        want = ref['new_params'][v.op_name]
+        got = v.numpy()
+        scale = max(np.abs(want).max(), 1e-6)
+        diff = np.abs(got - want)
+        if optimizer in ('sgd', 'momentum') or v.op_name not in ref['grads']:
+            assert diff.max() <= 1e-4 * scale, v.op_name
+        else:
+            # adam / rmsprop normalise by sqrt(v): the first step is ~ lr*sign(g), so where the gradient is
+            # numerically zero the sign (hence a 2*lr difference) is noise; elsewhere the step must agree
+            g = np.abs(ref['grads'][v.op_name])
+            solid = g > 1e-2 * g.max()
+            assert diff.max() <= 2.2 * lr + 1e-6, v.op_name
+            assert diff[solid].max() <= 5e-2 * lr + 1e-4 * scale, v.op_name
+    if update_scopes is not None:
+        body_w = 'yolov3/darknet53_body/Conv_5/weights'
+        np.testing.assert_array_equal(dict((v.op_name, v) for v in y3.global_variables())[body_w].numpy(),
+                                      params[body_w])
+
+
+def test_train_step_is_deterministic_and_loss_decreases():
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    from oracle import yolo_ref, train_ref
+    params = yolo_ref.synthetic_params(80, seed=2)
+    x = blob_images(4, 2, 96)
+    yts = train_ref.synthetic_targets(6, 2, [96, 96], 80, COCO_ANCHORS, max_boxes=3)
+    runs = []
+    for _ in range(2):
+        model = _fresh_model(params, batch_norm_decay=0.99)
+        trainer = training.Trainer(model, config_optimizer('momentum', 1e-3))
+        with y3.variable_scope('yolov3'):
+            losses = [float(trainer.step(x, yts)[0]) for _ in range(4)]
+        runs.append((losses, trainer.flat.clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][-1] < runs[0][0][0]

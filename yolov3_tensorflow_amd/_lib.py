@@ -47,6 +47,30 @@ PROTOTYPES = {
     "y3_net_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "y3_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                c_void_p, c_void_p]),
+    "y3_net_layer_graph": (c_int, [c_void_p, c_int] + [POINTER(c_int)] * 5),
+    "y3_net_num_tensors": (c_int, [c_void_p]),
+    "y3_net_tensor_info": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "y3_reduce_scratch_bytes": (c_size_t, [c_int]),
+    "y3_bn_train_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_bn_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "y3_bn_bwd_scratch_bytes": (c_size_t, [c_int]),
+    "y3_bn_train_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_bias_grad": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
+    "y3_conv2d_dgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                c_void_p, c_void_p, c_size_t]),
+    "y3_conv_wgrad_scratch_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "y3_conv_wgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
+    "y3_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "y3_slice_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_int, c_void_p]),
+    "y3_pad_channels": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p]),
+    "y3_loss_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "y3_loss_layer": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                              POINTER(c_float), c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t]),
+    "y3_optimizer_scratch_bytes": (c_size_t, []),
+    "y3_clip_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
+                               c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "y3_net_set_profiling": (c_int, [c_void_p, c_int]),
     "y3_net_get_layer_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), c_int]),
     "y3_net_layer_is_streamk": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),

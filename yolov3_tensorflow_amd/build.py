@@ -20,6 +20,8 @@ SOURCES = [
     ("y3_decode.hip", ["-ffp-contract=off"]),
     ("y3_nms.hip", ["-ffp-contract=off"]),
     ("y3_ops.hip", ["-ffp-contract=off"]),
+    ("y3_train.hip", ["-ffp-contract=off"]),
+    ("y3_wgrad.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -47,6 +47,14 @@ extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y, workspace, workspace_bytes);
 }
 
+extern "C" int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
+                               const float* w_d, const float* ones, const float* zeros, int accumulate,
+                               float* dx, void* workspace, size_t workspace_bytes) {
+    Y3_CHECK_ARG(ctx, "y3_conv2d_dgrad: null context");
+    return y3_launch_conv_dgrad(ctx->stream, fwd, dz, dz_stride, w_d, ones, zeros, accumulate, dx, workspace,
+                                workspace_bytes);
+}
+
 // ------------------------------------------------------------------------------------------------
 // y3_net: the 75-conv graph.  Tensor ids: 0 = network input; 1.. = conv outputs in creation order.
 // ------------------------------------------------------------------------------------------------
@@ -257,6 +265,27 @@ extern "C" int y3_net_layer_info(const y3_net* net, int i, int* k, int* stride, 
     if (cin) *cin = l.cin;
     if (cout) *cout = l.cout;
     if (has_bn) *has_bn = l.bn;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_layer_graph(const y3_net* net, int i, int* src, int* up, int* resid, int* dst, int* act) {
+    Y3_CHECK_ARG(net && i >= 0 && i < (int)net->layers.size(), "y3_net_layer_graph: bad layer index %d", i);
+    const Layer& l = net->layers[i];
+    if (src) *src = l.src;
+    if (up) *up = l.up;
+    if (resid) *resid = l.resid;
+    if (dst) *dst = l.dst;
+    if (act) *act = l.act;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_num_tensors(const y3_net* net) { return net ? (int)net->tensors.size() : 0; }
+
+extern "C" int y3_net_tensor_info(const y3_net* net, int t, int* channels, int* sdiv, int* ext) {
+    Y3_CHECK_ARG(net && t >= 0 && t < (int)net->tensors.size(), "y3_net_tensor_info: bad tensor id %d", t);
+    if (channels) *channels = net->tensors[t].c;
+    if (sdiv) *sdiv = net->tensors[t].sdiv;
+    if (ext) *ext = net->tensors[t].ext;
     return Y3_OK;
 }
 

@@ -44,6 +44,10 @@ struct ConvArgs {
     int stride, pad, act;
     int M;
     int workers;         // stream-K grid size (0 = data-parallel)
+    int wrev;            // 1: walk the weight taps in reverse order (data-gradient = conv with the flipped kernel)
+    int tmode;           // 1: transposed stride-2 gather (data-gradient of a stride-2 conv): x is the coarse
+                         //    [N,H,W,Cx] gradient, the output grid is [N,2H,2W]; tap (ky,kx) of output pixel
+                         //    (oy,ox) reads x[(oy-1+ky)/2, (ox-1+kx)/2] when both are even and in range
 };
 
 constexpr int BK = 32;
@@ -223,6 +227,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+            if (p.tmode) {
+                const bool ok = ((iy | ix) >= 0) && !((iy | ix) & 1) && (iy >> 1) < p.H && (ix >> 1) < p.W;
+                a_voff[j] = ok ? (unsigned)(a_base[j] + ((iy >> 1) * p.W + (ix >> 1)) * p.Cx + c4) * 4u : OOB;
+                continue;
+            }
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             a_voff[j] = ok ? (unsigned)(a_base[j] + tap_off) * 4u : OOB;
             if (UPCAT) a_voff_u[j] = ok ? (unsigned)(a_base_u[j] + c4) * 4u : OOB;
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
                 const int ix0 = ox * p.stride - p.pad;
                 a_iy0[j] = iy0;
                 a_ix0[j] = ix0;
-                a_base[j] = ((n * p.H + iy0) * p.W + ix0) * p.Cx;
+                a_base[j] = p.tmode ? n * p.H * p.W * p.Cx : ((n * p.H + iy0) * p.W + ix0) * p.Cx;
                 if (UPCAT) a_base_u[j] = ((n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.Cu;
             } else {
                 a_iy0[j] = -(1 << 24);
@@ -285,7 +294,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             for (int j = 0; j < AROWS; ++j)
                 ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], soff, 0));
         }
-        const unsigned wsoff = (unsigned)((ld_tap * p.Cout) * p.Cin + c0) * 4u;
+        const int wtap = p.wrev ? KS * KS - 1 - ld_tap : ld_tap;
+        const unsigned wsoff = (unsigned)((wtap * p.Cout) * p.Cin + c0) * 4u;
 #pragma unroll
         for (int j = 0; j < BROWS; ++j)
             rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff[j], wsoff, 0));
@@ -626,7 +636,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     Y3_CHECK_ARG((x_up != nullptr) == (d->c_up > 0), "y3_conv2d_fwd: x_up and c_up must agree");
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
-    a.partial = nullptr; a.workers = 0;
+    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -660,6 +670,45 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
         a.partial = static_cast<float*>(workspace);
         a.workers = SK_WORKERS;
         return launch_streamk<3>(stream, a, mid_event);
+    }
+    return dispatch_bn<3, false>(stream, a);
+}
+
+// Data gradient of a conv layer as a forward conv over dz:
+//   stride 1: dx = conv_same(dz, flip(W)^T)  -> same kernel, weights = the HWIO variable read with reversed taps
+//             ([tap][ci][co] is already "[tap][Cout'=ci][Cin'=co]"), no re-packing;
+//   stride 2: transposed gather (tmode) on the 2x finer output grid.
+// fwd describes the FORWARD layer (n, h, w = its input size).  dz is [N,Ho,Wo] x dz_stride channels
+// (dz_stride >= cout: the detection convs pad 255 -> 256), w_d is [k*k][cin][dz_stride].
+// accumulate != 0 adds into dx (gradient fan-in) instead of overwriting it.
+int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const float* dz, int dz_stride,
+                         const float* w_d, const float* ones, const float* zeros, int accumulate, float* dx,
+                         void* workspace, size_t workspace_bytes) {
+    Y3_CHECK_ARG(fwd && dz && w_d && ones && zeros && dx, "y3_conv2d_dgrad: null pointer argument");
+    Y3_CHECK_ARG(fwd->k == 1 || fwd->k == 3, "y3_conv2d_dgrad: kernel_size must be 1 or 3");
+    Y3_CHECK_ARG(fwd->stride == 1 || (fwd->stride == 2 && fwd->k == 3), "y3_conv2d_dgrad: unsupported stride");
+    Y3_CHECK_ARG(fwd->c_up == 0, "y3_conv2d_dgrad: fused upsample+concat inputs are not supported");
+    Y3_CHECK_ARG(dz_stride >= fwd->cout && dz_stride % BK == 0, "y3_conv2d_dgrad: dz stride must be a multiple of %d", BK);
+    Y3_CHECK_ARG(fwd->cin % 4 == 0, "y3_conv2d_dgrad: Cin must be a multiple of 4");
+    const int Ho = fwd->h / fwd->stride, Wo = fwd->w / fwd->stride;
+    ConvArgs a;
+    a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
+    a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.workers = 0;
+    a.wrev = 1; a.tmode = fwd->stride == 2 ? 1 : 0;
+    a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
+    a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;
+    a.Ho = fwd->h; a.Wo = fwd->w;
+    const long long M = (long long)fwd->n * fwd->h * fwd->w;
+    Y3_CHECK_ARG(M * fwd->cin < (1LL << 29) && (long long)fwd->n * Ho * Wo * dz_stride < (1LL << 29),
+                 "y3_conv2d_dgrad: tensor exceeds 2^29 elements (32-bit byte offsets)");
+    a.M = (int)M;
+    if (fwd->k == 1) return dispatch_bn<1, false>(stream, a);
+    const bool has_ws = workspace != nullptr && workspace_bytes >= (size_t)SK_WORKERS * 2 * 128 * 128 * sizeof(float) &&
+                        ((uintptr_t)workspace & 15) == 0;
+    if (use_streamk(a, 3, has_ws)) {
+        a.partial = static_cast<float*>(workspace);
+        a.workers = SK_WORKERS;
+        return launch_streamk<3>(stream, a, nullptr);
     }
     return dispatch_bn<3, false>(stream, a);
 }

@@ -39,3 +39,6 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
                    float* y, void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d);
 int y3_conv_schedule_impl(const y3_conv_desc* d);
+int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const float* dz, int dz_stride,
+                         const float* w_d, const float* ones, const float* zeros, int accumulate, float* dx,
+                         void* workspace, size_t workspace_bytes);

@@ -1,0 +1,659 @@
+// Training-path kernels other than the convolutions:
+//   batch-norm in batch-statistics mode (forward statistics, apply, backward reduce/apply), the YOLO loss
+//   forward+backward, gradient preparation (L2 term + norm), per-tensor clip + optimizer update, and the
+//   small routing ops of the backward graph (2x2 upsample-backward, channel-slice accumulate, bias grad).
+// All are HBM-bound streaming/reduction kernels: 16-byte-per-lane accesses along the channel axis,
+// per-workgroup partial sums written to a scratch array and combined by a finalize kernel in a FIXED order
+// (fp64 accumulation) so that every statistic and gradient is run-to-run deterministic (no float atomics).
+#include "y3_internal.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;  // partial-sum rows for the column reductions
+
+inline int grid_for(long long work, int cap = 256 * 16) {
+    long long b = (work + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- column reductions over an [M][C] matrix -----------------------------------------------------
+// MODE 0: (sum z, sum z^2)                                       -> BN forward statistics
+// MODE 1: (sum g', sum g'*zhat), g' = dy * leaky'(z*scale+shift) -> BN backward (d beta, d gamma)
+// MODE 2: (sum dy, 0)                                            -> bias gradient
+// Workgroup b handles rows b, b+gridDim, ...; thread t owns float4 column (t % C4) and row lane t / C4.
+template <int MODE>
+__global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ inv_std, long long M, int C,
+                                                         float* __restrict__ partial /*[grid][2][C]*/) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [rows_per_pass][2][C]
+    const int C4 = C >> 2;
+    const int lanes_per_row = C4 < 256 ? C4 : 256;
+    const int rows_per_pass = 256 / lanes_per_row;              // >= 1
+    const int cols_per_thread = (C4 + 255) / 256;               // > 1 only when C > 1024
+    const int tl = threadIdx.x % lanes_per_row, tr = threadIdx.x / lanes_per_row;
+    for (int cc = 0; cc < cols_per_thread; ++cc) {
+        const int c4 = tl + cc * 256;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < C4 && tr < rows_per_pass) {
+            f32x4 sc, sh, mu, is;
+            if (MODE == 1) {
+                sc = *reinterpret_cast<const f32x4*>(scale + 4 * c4);
+                sh = *reinterpret_cast<const f32x4*>(shift + 4 * c4);
+                mu = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
+                is = *reinterpret_cast<const f32x4*>(inv_std + 4 * c4);
+            }
+            for (long long r = (long long)blockIdx.x * rows_per_pass + tr; r < M;
+                 r += (long long)gridDim.x * rows_per_pass) {
+                if (MODE == 0) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * C + 4 * c4);
+                    s0 += v;
+                    s1 += v * v;
+                } else if (MODE == 1) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * C + 4 * c4);
+                    f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + 4 * c4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float u = v[q] * sc[q] + sh[q];
+                        g[q] = u > 0.f ? g[q] : 0.1f * g[q];
+                    }
+                    s0 += g;
+                    s1 += g * ((v - mu) * is);
+                } else {
+                    s0 += *reinterpret_cast<const f32x4*>(dy + r * C + 4 * c4);
+                }
+            }
+        }
+        // combine the row lanes of this workgroup (fixed order)
+        __syncthreads();
+        if (c4 < C4 && tr < rows_per_pass) {
+            *reinterpret_cast<f32x4*>(red + ((size_t)tr * 2 + 0) * C + 4 * c4) = s0;
+            *reinterpret_cast<f32x4*>(red + ((size_t)tr * 2 + 1) * C + 4 * c4) = s1;
+        }
+        __syncthreads();
+        if (c4 < C4 && tr == 0) {
+            for (int k = 1; k < rows_per_pass; ++k) {
+                s0 += *reinterpret_cast<const f32x4*>(red + ((size_t)k * 2 + 0) * C + 4 * c4);
+                s1 += *reinterpret_cast<const f32x4*>(red + ((size_t)k * 2 + 1) * C + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * C + 4 * c4) = s0;
+            *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * C + 4 * c4) = s1;
+        }
+    }
+}
+
+// BN forward finalize: batch mean / biased variance, folded scale & shift for the apply pass, and the
+// moving-statistics update  moving <- moving*decay + batch*(1-decay)  with the UNBIASED variance going
+// into moving_variance (TF fused batch norm).
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float eps, float decay, float* __restrict__ mean,
+                                         float* __restrict__ inv_std, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ moving_mean,
+                                         float* __restrict__ moving_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
+        s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    const double mu = s0 / count;
+    double var = s1 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float muf = (float)mu, varf = (float)var;
+    const float is = 1.0f / sqrtf(varf + eps);
+    mean[c] = muf;
+    inv_std[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - muf * sc;
+    if (moving_mean) {
+        const float unbiased = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        moving_mean[c] = moving_mean[c] * decay + muf * (1.f - decay);
+        moving_var[c] = moving_var[c] * decay + unbiased * (1.f - decay);
+    }
+}
+
+// BN backward finalize: d beta, d gamma (the parameter gradients) and the coefficients of the apply pass.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ inv_std,
+                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                       float* __restrict__ coef /*[3][C]: a, b, c*/) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
+        s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    if (dbeta) dbeta[c] = (float)s0;
+    if (dgamma) dgamma[c] = (float)s1;
+    if (coef) {
+        coef[c] = gamma[c] * inv_std[c];
+        coef[C + c] = (float)(s0 / count);
+        coef[2 * C + c] = (float)(s1 / count);
+    }
+}
+
+// y = leaky(z*scale + shift) (+ residual)
+__global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float* __restrict__ z,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ resid, long long total4,
+                                                           int C4, int act, float* __restrict__ y) {
+    const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(resid);
+    const f32x4* sc4 = reinterpret_cast<const f32x4*>(scale);
+    const f32x4* sh4 = reinterpret_cast<const f32x4*>(shift);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        f32x4 v = z4[i] * sc4[c] + sh4[c];
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+        }
+        if (resid) v += r4[i];
+        y4[i] = v;
+    }
+}
+
+// dz = a * (g' - b - zhat * c),  g' = dy * leaky'(u), u = z*scale+shift, zhat = (z-mean)*inv_std
+__global__ void __launch_bounds__(256) bn_apply_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ inv_std,
+                                                           const float* __restrict__ coef, long long total4,
+                                                           int C4, float* __restrict__ dz) {
+    const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(dy);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dz);
+    const int C = C4 * 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        const f32x4 v = z4[i];
+        f32x4 g = g4[i];
+        f32x4 out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float u = v[q] * scale[c + q] + shift[c + q];
+            const float gp = u > 0.f ? g[q] : 0.1f * g[q];
+            const float zh = (v[q] - mean[c + q]) * inv_std[c + q];
+            out[q] = coef[c + q] * (gp - coef[C + c + q] - zh * coef[2 * C + c + q]);
+        }
+        o4[i] = out;
+    }
+}
+
+// ---- backward routing ----------------------------------------------------------------------------------
+// dx[n,y,x,c] (+)= sum over the 2x2 block of g[n,2y+dy,2x+dx, c]   (g has row stride gC channels)
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const float* __restrict__ g, int gC, int n, int h,
+                                                             int w, int c4n, int accumulate,
+                                                             float* __restrict__ dx) {
+    const long long total = (long long)n * h * w * c4n;
+    f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4n);
+        long long r = i / c4n;
+        const int x = (int)(r % w); r /= w;
+        const int y = (int)(r % h);
+        const int b = (int)(r / h);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx)
+                s += *reinterpret_cast<const f32x4*>(
+                    g + (((long long)b * 2 * h + 2 * y + dyy) * 2 * w + 2 * x + dxx) * gC + 4 * c);
+        o4[i] = accumulate ? o4[i] + s : s;
+    }
+}
+
+// dst[r, 0:c] (+)= src[r, off:off+c]   (src row stride sC)
+__global__ void __launch_bounds__(256) slice_acc_kernel(const float* __restrict__ src, int sC, int off,
+                                                        long long rows, int c4n, int accumulate,
+                                                        float* __restrict__ dst) {
+    const long long total = rows * c4n;
+    f32x4* o4 = reinterpret_cast<f32x4*>(dst);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4n);
+        const long long r = i / c4n;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * sC + off + 4 * c);
+        o4[i] = accumulate ? o4[i] + v : v;
+    }
+}
+
+// ---- loss (model.py:192-365) ---------------------------------------------------------------------------
+struct LossArgs {
+    const float* fm;      // [N,gh,gw,3,5+C] logits
+    const float* y_true;  // [N,gh,gw,3,6+C]
+    float* grad;          // [N,gh,gw,3,5+C] d(total loss)/d(fm)
+    float* gt_boxes;      // scratch [N][cap][4]  (cx,cy,w,h) of the cells with object_mask == 1
+    int* gt_count;        // scratch [N]
+    float* partial;       // [blocks_x * N][4]
+    int N, gh, gw, C, cap, vmax;   // cap = row stride of gt_boxes, vmax = boxes staged in LDS
+    float ratio_h, ratio_w, img_h, img_w;
+    float anc_w[3], anc_h[3];     // anchors of this scale (pixels)
+    float ra_w[3], ra_h[3];       // anchors / ratio
+    int label_smooth, focal;
+    int grad_stride;              // floats per cell-row of 3 anchors in `grad` (>= 3*(5+C); padded for the dgrad)
+};
+
+__global__ void __launch_bounds__(256) loss_collect_gt_kernel(const LossArgs a) {
+    const int n = blockIdx.y;
+    const int cells = a.gh * a.gw * 3;
+    const int T = 6 + a.C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cells; i += gridDim.x * 256) {
+        const float* yt = a.y_true + ((size_t)n * cells + i) * T;
+        if (yt[4] > 0.5f) {                               // tf.cast(object_mask, 'bool')
+            const int slot = atomicAdd(&a.gt_count[n], 1);
+            if (slot < a.cap) {
+                float* o = a.gt_boxes + ((size_t)n * a.cap + slot) * 4;
+                o[0] = yt[0]; o[1] = yt[1]; o[2] = yt[2]; o[3] = yt[3];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x)); }
+// tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
+__device__ __forceinline__ float bce_(float z, float x) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
+
+__global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
+    extern __shared__ float gts[];                         // [V][4] of this image
+    __shared__ float red[4][4];
+    const int n = blockIdx.y;
+    const int cells = a.gh * a.gw * 3;
+    const int F = 5 + a.C, T = 6 + a.C;
+    const int V = min(a.gt_count[n], a.vmax);
+    for (int i = threadIdx.x; i < V * 4; i += 256) gts[i] = a.gt_boxes[(size_t)n * a.cap * 4 + i];
+    __syncthreads();
+    const float invN = 1.f / (float)a.N;
+    float l_xy = 0.f, l_wh = 0.f, l_conf = 0.f, l_cls = 0.f;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cells) {
+        const int anc = i % 3;
+        const int cell = i / 3;
+        const int gy = cell / a.gw, gx = cell - gy * a.gw;
+        const float* f = a.fm + ((size_t)n * cells + i) * F;
+        const float* yt = a.y_true + ((size_t)n * cells + i) * T;
+        float* g = a.grad + ((size_t)n * (cells / 3) + cell) * a.grad_stride + anc * F;
+        // reorg_layer (model.py:96-126)
+        const float sx = sigmoid_(f[0]), sy = sigmoid_(f[1]);
+        const float ex = expf(f[2]), ey = expf(f[3]);
+        const float px = (sx + (float)gx) * a.ratio_w, py = (sy + (float)gy) * a.ratio_h;
+        const float pw = (ex * a.ra_w[anc]) * a.ratio_w, ph = (ey * a.ra_h[anc]) * a.ratio_h;
+        // ignore mask (model.py:220-237): best IoU with this image's GT boxes of THIS scale < 0.5
+        float best = -INFINITY;
+        for (int v = 0; v < V; ++v) {
+            const float tx = gts[4 * v], ty = gts[4 * v + 1], tw = gts[4 * v + 2], th = gts[4 * v + 3];
+            const float iw = fmaxf(fminf(px + pw / 2.f, tx + tw / 2.f) - fmaxf(px - pw / 2.f, tx - tw / 2.f), 0.f);
+            const float ih = fmaxf(fminf(py + ph / 2.f, ty + th / 2.f) - fmaxf(py - ph / 2.f, ty - th / 2.f), 0.f);
+            const float inter = iw * ih;
+            best = fmaxf(best, inter / (pw * ph + tw * th - inter + 1e-10f));
+        }
+        const float ignore = best < 0.5f ? 1.f : 0.f;
+        const float m = yt[4];                       // object_mask
+        const float mixw = yt[T - 1];
+        const float bls = 2.f - (yt[2] / a.img_w) * (yt[3] / a.img_h);
+        const float wgt = m * bls * mixw;
+        // xy (model.py:248-249,276)
+        const float txy0 = yt[0] / a.ratio_w - (float)gx, txy1 = yt[1] / a.ratio_h - (float)gy;
+        const float pxy0 = px / a.ratio_w - (float)gx, pxy1 = py / a.ratio_h - (float)gy;
+        const float d0 = txy0 - pxy0, d1 = txy1 - pxy1;
+        l_xy = (d0 * d0 + d1 * d1) * wgt;
+        g[0] = -2.f * d0 * wgt * sx * (1.f - sx) * invN;
+        g[1] = -2.f * d1 * wgt * sy * (1.f - sy) * invN;
+        // wh (model.py:254-262,277)
+        float tt0 = yt[2] / a.anc_w[anc], tt1 = yt[3] / a.anc_h[anc];
+        float pt0 = pw / a.anc_w[anc], pt1 = ph / a.anc_h[anc];
+        tt0 = tt0 == 0.f ? 1.f : tt0; tt1 = tt1 == 0.f ? 1.f : tt1;
+        const bool pz0 = pt0 == 0.f, pz1 = pt1 == 0.f;
+        pt0 = pz0 ? 1.f : pt0; pt1 = pz1 ? 1.f : pt1;
+        const bool in0 = !pz0 && pt0 >= 1e-9f && pt0 <= 1e9f, in1 = !pz1 && pt1 >= 1e-9f && pt1 <= 1e9f;
+        const float e0 = logf(fminf(fmaxf(tt0, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt0, 1e-9f), 1e9f));
+        const float e1 = logf(fminf(fmaxf(tt1, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt1, 1e-9f), 1e9f));
+        l_wh = (e0 * e0 + e1 * e1) * wgt;
+        g[2] = in0 ? -2.f * e0 * wgt * invN : 0.f;   // d log(exp(t)*const)/dt = 1 inside the clip range
+        g[3] = in1 ? -2.f * e1 * wgt * invN : 0.f;
+        // conf (model.py:280-292)
+        const float xc = f[4];
+        const float pc = sigmoid_(xc);
+        const float cmask = m + (1.f - m) * ignore;
+        const float b = bce_(m, xc);
+        float lc = cmask * b;
+        float gc = cmask * (pc - m);
+        if (a.focal) {
+            const float dm = m - pc;
+            const float fo = dm * dm;                                   // alpha=1, gamma=2
+            gc = cmask * ((pc - m) * fo + b * (-2.f * dm * pc * (1.f - pc)));
+            lc *= fo;
+        }
+        l_conf = lc * mixw;
+        g[4] = gc * mixw * invN;
+        // class (model.py:296-302)
+        const float delta = 0.01f;
+        for (int c = 0; c < a.C; ++c) {
+            float tgt = yt[5 + c];
+            if (a.label_smooth) tgt = (1.f - delta) * tgt + delta * 1.f / (float)a.C;
+            const float x = f[5 + c];
+            l_cls += m * bce_(tgt, x) * mixw;
+            g[5 + c] = m * mixw * (sigmoid_(x) - tgt) * invN;
+        }
+    }
+    // workgroup reduction in a fixed order
+    float vals[4] = {l_xy, l_wh, l_conf, l_cls};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = vals[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        a.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;
+    }
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nparts, float invN, int accumulate,
+                                     float* __restrict__ out4) {
+    const int q = threadIdx.x;
+    if (q >= 4) return;
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += (double)partial[(size_t)i * 4 + q];
+    const float v = (float)(s * (double)invN);
+    out4[q] = accumulate ? out4[q] + v : v;
+}
+
+// ---- gradient preparation and optimizer update ---------------------------------------------------------
+// g += wd * w (slim.l2_regularizer gradient) and per-workgroup partial sums of g^2
+__global__ void __launch_bounds__(256) grad_prepare_kernel(float* __restrict__ g, const float* __restrict__ w,
+                                                           float wd, float gscale, long long n,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = g[i] * gscale;
+        if (wd != 0.f) v += wd * w[i];
+        g[i] = v;
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void norm_finalize_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ norm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nparts; ++i) s += (double)partial[i];
+        norm[0] = (float)sqrt(s);
+    }
+}
+
+// tf.clip_by_norm(g, clip) then the TF1 update rule.  kind: 0 sgd, 1 momentum, 2 adam,
+// 3 rmsprop.  hp: lr (or lr_t for adam), momentum, decay/beta1, beta2, eps.
+__global__ void __launch_bounds__(256) optimizer_update_kernel(float* __restrict__ w, float* __restrict__ g,
+                                                               float* __restrict__ s0, float* __restrict__ s1,
+                                                               const float* __restrict__ norm, float clip, int kind,
+                                                               float lr, float momentum, float decay, float beta2,
+                                                               float eps, long long n) {
+    const float nn = norm[0];
+    const float factor = clip / fmaxf(nn, clip);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * factor;
+        g[i] = gi;                                   // the clipped gradient stays observable
+        float wi = w[i];
+        if (kind == 0) {
+            wi -= lr * gi;
+        } else if (kind == 1) {
+            const float acc = s0[i] * momentum + gi;
+            s0[i] = acc;
+            wi -= lr * acc;
+        } else if (kind == 2) {
+            const float m = s0[i] * decay + (1.f - decay) * gi;          // decay = beta1
+            const float v = s1[i] * beta2 + (1.f - beta2) * gi * gi;
+            s0[i] = m; s1[i] = v;
+            wi -= lr * m / (sqrtf(v) + eps);                              // lr = lr_t
+        } else {
+            const float ms = s0[i] * decay + (1.f - decay) * gi * gi;
+            const float mom = s1[i] * momentum + lr * gi / sqrtf(ms + eps);
+            s0[i] = ms; s1[i] = mom;
+            wi -= mom;
+        }
+        w[i] = wi;
+    }
+}
+
+// sum over rows of an [M][C] matrix with arbitrary C (bias gradient of the detection convs, C = 3*(5+classes))
+__global__ void __launch_bounds__(256) col_sum_scalar_kernel(const float* __restrict__ x, long long M, int C,
+                                                             float* __restrict__ partial /*[grid][C]*/) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (long long r = blockIdx.x; r < M; r += gridDim.x) s += x[r * C + c];
+        partial[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+// dst[r][0:c_dst] = src[r][0:c_src] zero-extended (c_dst >= c_src): 16-byte-aligned rows for the 3*(5+C)-wide tensors
+__global__ void __launch_bounds__(256) pad_channels_kernel(const float* __restrict__ src, int cs, long long rows,
+                                                           int cd, float* __restrict__ dst) {
+    const long long total = rows * cd;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cd);
+        const long long r = i / cd;
+        dst[i] = c < cs ? src[r * cs + c] : 0.f;
+    }
+}
+
+__global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
+    out[c] = (float)s;
+}
+
+}  // namespace
+
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+extern "C" size_t y3_reduce_scratch_bytes(int c) { return (size_t)RED_BLOCKS * 2 * (size_t)(c > 0 ? c : 0) * sizeof(float); }
+
+static int reduce_launch(y3_ctx* ctx, int mode, const float* z, const float* dy, const float* scale,
+                         const float* shift, const float* mean, const float* inv_std, long long rows, int c,
+                         float* scratch, int* nblocks_out) {
+    const int C4 = c / 4;
+    const int lanes_per_row = C4 < 256 ? C4 : 256;
+    const int rows_per_pass = 256 / lanes_per_row;
+    long long nb = (rows + rows_per_pass - 1) / rows_per_pass;
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    const size_t lds = (size_t)rows_per_pass * 2 * c * sizeof(float);
+    if (mode == 0)
+        hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
+                           mean, inv_std, rows, c, scratch);
+    else if (mode == 1)
+        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
+                           mean, inv_std, rows, c, scratch);
+    else
+        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
+                           mean, inv_std, rows, c, scratch);
+    Y3_CHECK_HIP(hipGetLastError());
+    *nblocks_out = (int)nb;
+    return Y3_OK;
+}
+
+extern "C" int y3_bn_train_stats(y3_ctx* ctx, const float* z, long long rows, int c, const float* gamma,
+                                 const float* beta, float eps, float decay, float* mean, float* inv_std,
+                                 float* scale, float* shift, float* moving_mean, float* moving_var,
+                                 float* scratch) {
+    Y3_CHECK_ARG(ctx && z && gamma && beta && mean && inv_std && scale && shift && scratch,
+                 "y3_bn_train_stats: null argument");
+    Y3_CHECK_ARG(rows > 0 && c > 0 && c % 4 == 0, "y3_bn_train_stats: bad shape rows=%lld c=%d", rows, c);
+    Y3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "y3_bn_train_stats: moving stats must come in pairs");
+    int nb = 0;
+    if (int rc = reduce_launch(ctx, 0, z, nullptr, nullptr, nullptr, nullptr, nullptr, rows, c, scratch, &nb)) return rc;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, scratch, nb, c,
+                       (double)rows, gamma, beta, eps, decay, mean, inv_std, scale, shift, moving_mean, moving_var);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_bn_apply_fwd(y3_ctx* ctx, const float* z, const float* scale, const float* shift,
+                               const float* residual, long long rows, int c, int act, float* y) {
+    Y3_CHECK_ARG(ctx && z && scale && shift && y, "y3_bn_apply_fwd: null argument");
+    Y3_CHECK_ARG(rows > 0 && c > 0 && c % 4 == 0, "y3_bn_apply_fwd: bad shape");
+    const long long total4 = rows * (c / 4);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, ctx->stream, z, scale, shift,
+                       residual, total4, c / 4, act, y);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_bn_train_bwd(y3_ctx* ctx, const float* z, const float* dy, const float* gamma,
+                               const float* scale, const float* shift, const float* mean, const float* inv_std,
+                               long long rows, int c, float* dgamma, float* dbeta, float* dz, float* scratch) {
+    Y3_CHECK_ARG(ctx && z && dy && gamma && scale && shift && mean && inv_std && dz && scratch,
+                 "y3_bn_train_bwd: null argument");
+    Y3_CHECK_ARG(rows > 0 && c > 0 && c % 4 == 0, "y3_bn_train_bwd: bad shape");
+    int nb = 0;
+    if (int rc = reduce_launch(ctx, 1, z, dy, scale, shift, mean, inv_std, rows, c, scratch, &nb)) return rc;
+    float* coef = scratch + (size_t)RED_BLOCKS * 2 * c;   // scratch has room for 3*C more (see y3_bn_bwd_scratch_bytes)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, scratch, nb, c,
+                       (double)rows, gamma, inv_std, dbeta, dgamma, coef);
+    Y3_CHECK_HIP(hipGetLastError());
+    const long long total4 = rows * (c / 4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, ctx->stream, z, dy, scale, shift,
+                       mean, inv_std, coef, total4, c / 4, dz);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" size_t y3_bn_bwd_scratch_bytes(int c) { return y3_reduce_scratch_bytes(c) + (size_t)3 * (c > 0 ? c : 0) * sizeof(float); }
+
+extern "C" int y3_bias_grad(y3_ctx* ctx, const float* dy, long long rows, int c, float* dbias, float* scratch) {
+    Y3_CHECK_ARG(ctx && dy && dbias && scratch, "y3_bias_grad: null argument");
+    Y3_CHECK_ARG(rows > 0 && c > 0, "y3_bias_grad: bad shape");
+    const int nb = (int)(rows < RED_BLOCKS ? rows : RED_BLOCKS);
+    hipLaunchKernelGGL(col_sum_scalar_kernel, dim3(nb), dim3(256), 0, ctx->stream, dy, rows, c, scratch);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, scratch, nb, c, dbias);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_upsample2x_bwd(y3_ctx* ctx, const float* g, int g_channels, int n, int h, int w, int c,
+                                 int accumulate, float* dx) {
+    Y3_CHECK_ARG(ctx && g && dx, "y3_upsample2x_bwd: null argument");
+    Y3_CHECK_ARG(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && g_channels >= c && g_channels % 4 == 0,
+                 "y3_upsample2x_bwd: bad shape");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 4))), dim3(256), 0,
+                       ctx->stream, g, g_channels, n, h, w, c / 4, accumulate, dx);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_slice_accumulate(y3_ctx* ctx, const float* src, int src_channels, int offset, long long rows,
+                                   int c, int accumulate, float* dst) {
+    Y3_CHECK_ARG(ctx && src && dst, "y3_slice_accumulate: null argument");
+    Y3_CHECK_ARG(rows > 0 && c > 0 && c % 4 == 0 && offset % 4 == 0 && src_channels % 4 == 0 &&
+                     offset + c <= src_channels, "y3_slice_accumulate: bad shape");
+    hipLaunchKernelGGL(slice_acc_kernel, dim3(grid_for(rows * (c / 4))), dim3(256), 0, ctx->stream, src,
+                       src_channels, offset, rows, c / 4, accumulate, dst);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+// ---- loss ---------------------------------------------------------------------------------------------
+extern "C" size_t y3_loss_scratch_bytes(int n, int gh, int gw) {
+    if (n <= 0 || gh <= 0 || gw <= 0) return 0;
+    const size_t cells = (size_t)gh * gw * 3;
+    const size_t blocks = (cells + 255) / 256;
+    return (size_t)n * cells * 4 * sizeof(float) + 256 + (size_t)n * sizeof(int) + 256 +
+           blocks * n * 4 * sizeof(float) + 256;
+}
+
+extern "C" int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float* y_true, int n, int gh, int gw,
+                             int class_num, int img_h, int img_w, const float* anchors3_host, int use_label_smooth,
+                             int use_focal_loss, int accumulate, float* loss4, float* grad, int grad_stride,
+                             void* scratch, size_t scratch_bytes) {
+    Y3_CHECK_ARG(ctx && feature_map && y_true && anchors3_host && loss4 && grad && scratch,
+                 "y3_loss_layer: null argument");
+    Y3_CHECK_ARG(n > 0 && gh > 0 && gw > 0 && class_num > 0 && img_h > 0 && img_w > 0, "y3_loss_layer: bad shape");
+    Y3_CHECK_ARG(scratch_bytes >= y3_loss_scratch_bytes(n, gh, gw), "y3_loss_layer: scratch too small");
+    Y3_CHECK_ARG(grad_stride >= 3 * (5 + class_num), "y3_loss_layer: grad_stride smaller than 3*(5+C)");
+    LossArgs a;
+    a.fm = feature_map; a.y_true = y_true; a.grad = grad;
+    a.N = n; a.gh = gh; a.gw = gw; a.C = class_num;
+    const int cells = gh * gw * 3;
+    a.cap = cells;
+    const int blocks = (cells + 255) / 256;
+    char* p = static_cast<char*>(scratch);
+    a.gt_boxes = reinterpret_cast<float*>(p); p += (((size_t)n * cells * 4 * sizeof(float)) + 255) & ~(size_t)255;
+    a.gt_count = reinterpret_cast<int*>(p);   p += (((size_t)n * sizeof(int)) + 255) & ~(size_t)255;
+    a.partial = reinterpret_cast<float*>(p);
+    a.ratio_h = (float)((double)img_h / gh); a.ratio_w = (float)((double)img_w / gw);
+    a.img_h = (float)img_h; a.img_w = (float)img_w;
+    for (int k = 0; k < 3; ++k) {
+        a.anc_w[k] = anchors3_host[2 * k]; a.anc_h[k] = anchors3_host[2 * k + 1];
+        a.ra_w[k] = a.anc_w[k] / a.ratio_w; a.ra_h[k] = a.anc_h[k] / a.ratio_h;
+    }
+    a.label_smooth = use_label_smooth; a.focal = use_focal_loss; a.grad_stride = grad_stride;
+    Y3_CHECK_HIP(hipMemsetAsync(a.gt_count, 0, (size_t)n * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(loss_collect_gt_kernel, dim3(blocks, n), dim3(256), 0, ctx->stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    // GT boxes of one image are staged in LDS: up to 2048 per scale per image (32 KB) — far above any real
+    // annotation count (the reference's datasets have tens of boxes per image)
+    a.vmax = cells < 2048 ? cells : 2048;
+    const size_t lds = (size_t)a.vmax * 4 * sizeof(float);
+    hipLaunchKernelGGL(loss_kernel, dim3(blocks, n), dim3(256), lds, ctx->stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, a.partial, blocks * n,
+                       1.f / (float)n, accumulate, loss4);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+// ---- optimizer ----------------------------------------------------------------------------------------
+extern "C" size_t y3_optimizer_scratch_bytes(void) { return (size_t)(RED_BLOCKS + 64) * sizeof(float); }
+
+extern "C" int y3_clip_update(y3_ctx* ctx, int kind, float* w, float* g, float* slot0, float* slot1, long long n,
+                              float weight_decay, float grad_scale, float clip_norm, float lr, float momentum,
+                              float decay, float beta2, float eps, float* scratch) {
+    Y3_CHECK_ARG(ctx && w && g && scratch, "y3_clip_update: null argument");
+    Y3_CHECK_ARG(n > 0, "y3_clip_update: empty tensor");
+    Y3_CHECK_ARG(kind >= 0 && kind <= 3, "y3_clip_update: unknown optimizer kind %d", kind);
+    Y3_CHECK_ARG(kind == 0 || slot0, "y3_clip_update: optimizer slot missing");
+    Y3_CHECK_ARG(kind < 2 || slot1, "y3_clip_update: second optimizer slot missing");
+    int nb = grid_for(n, RED_BLOCKS);
+    float* norm = scratch + RED_BLOCKS;
+    hipLaunchKernelGGL(grad_prepare_kernel, dim3(nb), dim3(256), 0, ctx->stream, g, w, weight_decay, grad_scale, n, scratch);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, scratch, nb, norm);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(optimizer_update_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, w, g, slot0, slot1,
+                       norm, clip_norm, kind, lr, momentum, decay, beta2, eps, n);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_pad_channels(y3_ctx* ctx, const float* src, int c_src, long long rows, int c_dst, float* dst) {
+    Y3_CHECK_ARG(ctx && src && dst, "y3_pad_channels: null argument");
+    Y3_CHECK_ARG(rows > 0 && c_src > 0 && c_dst >= c_src, "y3_pad_channels: bad shape");
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(rows * c_dst)), dim3(256), 0, ctx->stream, src, c_src,
+                       rows, c_dst, dst);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}

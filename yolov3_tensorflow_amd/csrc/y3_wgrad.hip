@@ -1,0 +1,269 @@
+// Convolution weight gradient for gfx950 (the TF autodiff of slim.conv2d w.r.t. its kernel,
+// train.py:112 `optimizer.compute_gradients`).
+//
+//   dW[ky][kx][ci][co] = sum over output pixels m of  x[n, oy*s+ky-pad, ox*s+kx-pad, ci] * dz[m, co]
+//
+// As a GEMM:  D[j][co] = sum_m  P[m][j] * dz[m][co],  j = (ky*k+kx)*Cin + ci  — D is exactly the HWIO layout
+// of the kernel variable, so the result needs no transposition.  P (the im2col patch matrix) is never
+// materialised: its rows are gathered from x with bounds-checked buffer loads (padding reads 0).
+// The reduction dimension is the pixel index m (up to 11 M at bs=64): it is split over `nsplit` workgroups
+// per output tile; each split writes its partial tile to scratch and a second kernel adds the splits in a
+// fixed order (deterministic, no float atomics).
+// Tile: 128 (j) x 128 (co), 32 pixels per K-step, 4 waves x (2x2) 32x32 fp32 MFMA tiles — the same
+// matrix-pipe-bound regime as the forward conv (K = M is long, so the prologue/epilogue are negligible).
+#include "y3_internal.h"
+
+namespace {
+
+struct WgradArgs {
+    const float* x;    // [N,H,W,Cin]
+    const float* dz;   // [M][CoP]  (CoP = row stride of dz, >= Cout, multiple of 4)
+    float* out;        // nsplit == 1: dW [J][Cout] ; else scratch [nsplit][J][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout, CoP;
+    int k, stride, pad;
+    int M, J;          // J = k*k*Cin
+    int chunk;         // pixels per split (multiple of 32)
+    int nsplit;
+};
+
+constexpr int WBK = 32;          // pixels per K-step
+constexpr int WLD = 128;         // LDS row stride (floats): lanes of a half-wave read consecutive floats
+constexpr unsigned OOB = 0x80000000u;
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][32][128]  patch rows  P[m][j]
+    float* Bs = smem + 2 * WBK * WLD;   // [2][32][128]  dz rows     dz[m][co]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nct = (p.Cout + 127) / 128;
+    const int jt = blockIdx.x / nct, ct = blockIdx.x - jt * nct;
+    const int j0 = jt * 128, co0 = ct * 128;
+    const int split = blockIdx.y;
+    const int m_begin = split * p.chunk;
+    const int m_end = min(m_begin + p.chunk, ((p.M + WBK - 1) / WBK) * WBK);
+    const int T = (m_end - m_begin) / WBK;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dz), 0, (unsigned)((size_t)p.M * p.CoP * 4), 0x00020000);
+
+    // staging coordinates: float4 column c4 (fixed per thread), rows (tid>>5) + 8*i
+    const int c4 = (tid & 31) * 4;
+    const int r0 = tid >> 5;
+    const int j = j0 + c4;
+    const bool j_ok = j < p.J;
+    const int tap = j_ok ? j / p.Cin : 0;
+    const int ci = j - tap * p.Cin;
+    const int ky = tap / p.k, kx = tap - ky * p.k;
+    const bool co_ok = co0 + c4 < p.CoP;
+    const int HoWo = p.Ho * p.Wo;
+
+    f32x4 ra[4], rb[4];
+    auto load_tile = [&](int t) {
+        const int mb = m_begin + t * WBK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb + r0 + 8 * i;
+            unsigned offa = OOB;
+            if (j_ok && m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    offa = (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin + ci) * 4u;
+            }
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, offa, 0, 0));
+            // rows m >= M lie beyond the end of dz: the buffer load returns 0 for them
+            const unsigned offb = co_ok ? (unsigned)(m * p.CoP + co0 + c4) * 4u : OOB;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, offb, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(As + (buf * WBK + r0 + 8 * i) * WLD + c4) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + (buf * WBK + r0 + 8 * i) * WLD + c4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // MFMA operands: A[i][k] = P[m=k][j=i], B[k][n] = dz[m=k][co=n]; lane l holds k = l>>5
+    const int fcol = lane & 31, fk = lane >> 5;
+    auto compute_tile = [&](int buf) {
+        const float* as = As + buf * WBK * WLD + fk * WLD + wm * 64 + fcol;
+        const float* bs = Bs + buf * WBK * WLD + fk * WLD + wn * 64 + fcol;
+#pragma unroll
+        for (int s = 0; s < WBK / 2; ++s) {
+            float a[2], b[2];
+            a[0] = as[(2 * s) * WLD];
+            a[1] = as[(2 * s) * WLD + 32];
+            b[0] = bs[(2 * s) * WLD];
+            b[1] = bs[(2 * s) * WLD + 32];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    if (T > 0) {
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const bool more = t + 1 < T;
+            if (more) load_tile(t + 1);
+            compute_tile(t & 1);
+            if (more) store_tile((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (j)
+    float* out = p.out + (size_t)split * p.J * p.Cout;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int co = co0 + wn * 64 + ni * 32 + (lane & 31);
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int jb = j0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = jb + (r & 3) + 8 * (r >> 2);
+                if (jj < p.J) out[(size_t)jj * p.Cout + co] = acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_sum_splits_kernel(const float* __restrict__ scratch, int nsplit,
+                                                               long long n, float* __restrict__ dw) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += scratch[(size_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+// Stem conv (Cin = 3): D[27][COUT] over all pixels.  Workgroup = a chunk of pixels; thread t owns output
+// row j = t / (COUT/4) and a float4 of output channels.
+template <int COUT>
+__global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                         int N, int H, int W, int M, int chunk,
+                                                         float* __restrict__ partial /*[grid][27][COUT]*/) {
+    constexpr int Q = COUT / 4;
+    const int jrow = threadIdx.x / Q, c4 = (threadIdx.x % Q) * 4;
+    const bool act = jrow < 27;
+    const int tap = jrow / 3, ci = jrow - tap * 3;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int m0 = blockIdx.x * chunk, m1 = min(m0 + chunk, M);
+    if (act) {
+        for (int m = m0; m < m1; ++m) {
+            const int n = m / (H * W);
+            const int rem = m - n * H * W;
+            const int oy = rem / W, ox = rem - oy * W;
+            const int iy = oy - 1 + ky, ix = ox - 1 + kx;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const float xv = x[((size_t)(n * H + iy) * W + ix) * 3 + ci];
+                s += xv * *reinterpret_cast<const f32x4*>(dz + (size_t)m * COUT + c4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 27 + jrow) * COUT + c4) = s;
+    }
+}
+
+}  // namespace
+
+// split heuristic: aim at ~1024 workgroups (2 per CU x 2 rounds), at most 64 splits
+static void wgrad_split(const y3_conv_desc* d, int* nsplit_out, int* chunk_out) {
+    const long long M = (long long)d->n * (d->h / d->stride) * (d->w / d->stride);
+    const int J = d->k * d->k * d->cin;
+    const int tiles = ((J + 127) / 128) * ((d->cout + 127) / 128);
+    const int ksteps = (int)((M + WBK - 1) / WBK);
+    int nsplit = (1024 + tiles - 1) / tiles;
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit > ksteps) nsplit = ksteps;
+    if (nsplit < 1) nsplit = 1;
+    const int chunk = ((ksteps + nsplit - 1) / nsplit) * WBK;
+    *chunk_out = chunk;
+    *nsplit_out = (int)((M + chunk - 1) / chunk);
+}
+
+extern "C" size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* d) {
+    if (!d || d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->stride <= 0) return 0;
+    if (d->cin == 3) return (size_t)4096 * 27 * 32 * sizeof(float);
+    int nsplit, chunk;
+    wgrad_split(d, &nsplit, &chunk);
+    return (size_t)nsplit * d->k * d->k * d->cin * d->cout * sizeof(float) + 256;
+}
+
+extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* dz, int dz_stride,
+                             float* dw_hwio, void* scratch, size_t scratch_bytes) {
+    Y3_CHECK_ARG(ctx && d && x && dz && dw_hwio && scratch, "y3_conv_wgrad: null argument");
+    Y3_CHECK_ARG(d->k == 1 || d->k == 3, "y3_conv_wgrad: kernel_size must be 1 or 3");
+    Y3_CHECK_ARG(d->stride == 1 || d->stride == 2, "y3_conv_wgrad: stride must be 1 or 2");
+    Y3_CHECK_ARG(d->c_up == 0, "y3_conv_wgrad: fused upsample+concat inputs are not supported (materialise the concat)");
+    Y3_CHECK_ARG(dz_stride >= d->cout && dz_stride % 4 == 0, "y3_conv_wgrad: dz row stride must be >= Cout and a multiple of 4");
+    Y3_CHECK_ARG(scratch_bytes >= y3_conv_wgrad_scratch_bytes(d), "y3_conv_wgrad: scratch too small");
+    const int Ho = d->h / d->stride, Wo = d->w / d->stride;
+    const long long M = (long long)d->n * Ho * Wo;
+    Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 29) && M * dz_stride < (1LL << 29),
+                 "y3_conv_wgrad: tensor exceeds 2^29 elements (32-bit byte offsets)");
+    hipStream_t st = ctx->stream;
+    if (d->cin == 3) {
+        Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && dz_stride == 32,
+                     "y3_conv_wgrad: Cin=3 is supported only as the 3x3 3->32 stem conv");
+        int nblk = (int)((M + 2047) / 2048);
+        if (nblk > 4096) nblk = 4096;
+        const int chunk = (int)((M + nblk - 1) / nblk);
+        float* part = static_cast<float*>(scratch);
+        hipLaunchKernelGGL(stem_wgrad_kernel<32>, dim3(nblk), dim3(256), 0, st, x, dz, d->n, d->h, d->w, (int)M,
+                           chunk, part);
+        Y3_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3(4), dim3(256), 0, st, part, nblk, (long long)27 * 32, dw_hwio);
+        Y3_CHECK_HIP(hipGetLastError());
+        return Y3_OK;
+    }
+    Y3_CHECK_ARG(d->cin % 4 == 0, "y3_conv_wgrad: Cin must be 3 or a multiple of 4");
+    WgradArgs a;
+    a.x = x; a.dz = dz;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.CoP = dz_stride;
+    a.k = d->k; a.stride = d->stride; a.pad = d->k / 2; a.M = (int)M; a.J = d->k * d->k * d->cin;
+    const int tiles = ((a.J + 127) / 128) * ((a.Cout + 127) / 128);
+    int nsplit;
+    wgrad_split(d, &nsplit, &a.chunk);
+    a.nsplit = nsplit;
+    a.out = nsplit == 1 ? dw_hwio : static_cast<float*>(scratch);
+    static bool attr_set = false;
+    const size_t lds = (size_t)4 * WBK * WLD * sizeof(float);
+    if (!attr_set) {
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, nsplit), dim3(256), lds, st, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    if (nsplit > 1) {
+        const long long n = (long long)a.J * a.Cout;
+        long long nb = (n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3((int)nb), dim3(256), 0, st, static_cast<float*>(scratch),
+                           nsplit, n, dw_hwio);
+        Y3_CHECK_HIP(hipGetLastError());
+    }
+    return Y3_OK;
+}

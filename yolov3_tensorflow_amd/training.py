@@ -1,41 +1,431 @@
-"""Training path (train.py:72-115 of the reference): BN in batch-statistics mode, loss, backward, clip,
-optimizer update.  Optimizer is the object utils.misc_utils.config_optimizer returns."""
+"""Training path (reference train.py:72-115): yolov3.forward(is_training=True) with batch-statistics BN,
+compute_loss, backward, per-tensor clip, optimizer update, optional data-parallel gradient all-reduce.
+
+Python here only sequences C-ABI calls over caller-owned device buffers (torch = allocator + process group);
+every number is produced by a HIP kernel of csrc/y3_train.hip, y3_wgrad.hip or y3_conv.hip.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import engine
+from . import framework as fw
+
+BN_EPS = 1e-5      # model.py:37
+CLIP_NORM = 100.0  # train.py:113-114
 
 
 class Optimizer(object):
-    """Hyper-parameters of one of the four update rules the reference can select
+    """Hyper-parameters + slot variables of one of the four update rules the reference can select
     (utils/misc_utils.py:151-161; TF1 definitions)."""
 
     KINDS = ('sgd', 'momentum', 'adam', 'rmsprop')
 
-    def __init__(self, kind, learning_rate, momentum=0.9, decay=0.9, beta1=0.9, beta2=0.999,
-                 epsilon=None):
+    def __init__(self, kind, learning_rate, momentum=0.9, decay=0.9, beta1=0.9, beta2=0.999, epsilon=None):
         if kind not in self.KINDS:
             raise ValueError('Unsupported optimizer type!')
         self.kind = kind
-        self.learning_rate = learning_rate   # float, or a callable step -> float
+        self.learning_rate = learning_rate   # float, or a callable global_step -> float
         self.momentum = momentum
         self.decay = decay
         self.beta1, self.beta2 = beta1, beta2
         self.epsilon = epsilon if epsilon is not None else (1e-8 if kind == 'adam' else 1e-10)
-        self.slots = {}                      # variable op_name -> tuple of device tensors
-        self.step = 0
+        self.slots = {}                      # variable op_name -> (slot0, slot1) device tensors
+        self.step = 0                        # number of apply_gradients calls (adam's t)
 
     def lr_at(self, global_step):
-        return self.learning_rate(global_step) if callable(self.learning_rate) else float(self.learning_rate)
+        return float(self.learning_rate(global_step)) if callable(self.learning_rate) else float(self.learning_rate)
+
+    def _slots_for(self, var):
+        s = self.slots.get(var.op_name)
+        if s is None:
+            z = lambda: torch.zeros_like(var.tensor)
+            if self.kind == 'sgd':
+                s = (None, None)
+            elif self.kind == 'momentum':
+                s = (z(), None)
+            elif self.kind == 'adam':
+                s = (z(), z())
+            else:                            # rmsprop: ms initialised to ones, mom to zeros (TF1)
+                s = (torch.ones_like(var.tensor), z())
+            self.slots[var.op_name] = s
+        return s
 
 
+# --------------------------------------------------------------------------------------------------------
+# graph topology (queried from the C++ launch plan: one source of truth)
+# --------------------------------------------------------------------------------------------------------
+class _Topology(object):
+    def __init__(self, class_num):
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        _lib.check(L.y3_net_create(None, int(class_num), ctypes.byref(h)))
+        self.layers = []
+        ci = lambda: ctypes.c_int()
+        for i in range(L.y3_net_num_layers(h)):
+            k, s, cin, cout, bn = ci(), ci(), ci(), ci(), ci()
+            _lib.check(L.y3_net_layer_info(h, i, *[ctypes.byref(v) for v in (k, s, cin, cout, bn)]))
+            src, up, resid, dst, act = ci(), ci(), ci(), ci(), ci()
+            _lib.check(L.y3_net_layer_graph(h, i, *[ctypes.byref(v) for v in (src, up, resid, dst, act)]))
+            self.layers.append(dict(k=k.value, stride=s.value, cin=cin.value, cout=cout.value, bn=bool(bn.value),
+                                    src=src.value, up=up.value, resid=resid.value, dst=dst.value, act=act.value))
+        self.tensors = []
+        for t in range(L.y3_net_num_tensors(h)):
+            c, sd, ext = ci(), ci(), ci()
+            _lib.check(L.y3_net_tensor_info(h, t, ctypes.byref(c), ctypes.byref(sd), ctypes.byref(ext)))
+            self.tensors.append(dict(c=c.value, sdiv=sd.value, ext=ext.value))
+        L.y3_net_destroy(h)
+
+
+def _scratch(state, key, nbytes, device):
+    t = state.setdefault('scratch', {}).get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        state['scratch'][key] = t
+    return t
+
+
+def _train_state(model):
+    st = getattr(model, '_train', None)
+    if st is None:
+        st = dict(topo=_Topology(model.class_num), packed={}, consts={})
+        model._train = st
+    return st
+
+
+def _consts(st, c, device):
+    k = (c, str(device))
+    v = st['consts'].get(k)
+    if v is None:
+        v = (torch.ones(c, device=device), torch.zeros(c, device=device))
+        st['consts'][k] = v
+    return v
+
+
+def _packed_weights(st, wvar):
+    """[tap][Cout][Cin] re-pack of the HWIO variable for the forward conv, refreshed when the variable changes."""
+    hit = st['packed'].get(wvar.op_name)
+    if hit is not None and hit[0] == wvar.version:
+        return hit[1]
+    k, _, cin, cout = wvar.shape
+    if cin == 3:
+        wp = wvar.tensor
+    else:
+        wp = hit[1] if hit is not None else torch.empty(k * k * cout * cin, dtype=torch.float32,
+                                                        device=wvar.tensor.device)
+        _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(wvar.tensor.device), fw.ptr(wvar.tensor), k, cin, cout,
+                                                   fw.ptr(wp)))
+    st['packed'][wvar.op_name] = (wvar.version, wp)
+    return wp
+
+
+# --------------------------------------------------------------------------------------------------------
+# forward in training mode
+# --------------------------------------------------------------------------------------------------------
 def forward_train(model, x):
-    raise NotImplementedError('yolov3.forward(is_training=True): the training kernels are not built yet')
+    """yolov3.forward(inputs, is_training=True): BN normalises with batch statistics in ALL 72 BN layers and
+    updates the moving statistics (decay = model.batch_norm_decay); activations are kept for backward."""
+    st = _train_state(model)
+    topo = st['topo']
+    L = _lib.lib()
+    dev = x.device
+    ctx = fw.context(dev)
+    scope = fw.current_scope_name()
+    layer_vars = model._ensure_variables(scope, [(l['k'], l['stride'], l['cin'], l['cout'], l['bn'])
+                                                 for l in topo.layers])
+    n, h, w, _ = x.shape
+    tens = {0: x}
+    saved = []
+    det_pad = ((3 * (5 + model.class_num) + 31) // 32) * 32
+    for i, l in enumerate(topo.layers):
+        wvar, bnv, bias = layer_vars[i]
+        xin = tens[l['src']]
+        if l['up'] >= 0:   # training materialises concat([upsample(up), route]) (model.py:61-62,71-72)
+            upt = engine.upsample_nearest(tens[l['up']], xin.shape[1], xin.shape[2])
+            xin = engine.concat_channels(upt, xin)
+        cout = l['cout']
+        ones, zeros = _consts(st, cout, dev)
+        wp = _packed_weights(st, wvar)
+        rec = dict(xin=xin)
+        if l['bn']:
+            z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False)
+            rows = z.numel() // cout
+            stats = torch.empty((4, cout), dtype=torch.float32, device=dev)   # mean, inv_std, scale, shift
+            sc = _scratch(st, 'reduce', L.y3_reduce_scratch_bytes(cout), dev)
+            gamma, beta, mmean, mvar = bnv
+            _lib.check(L.y3_bn_train_stats(ctx, fw.ptr(z), rows, cout, fw.ptr(gamma.tensor), fw.ptr(beta.tensor),
+                                           ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay),
+                                           fw.ptr(stats[0]), fw.ptr(stats[1]), fw.ptr(stats[2]), fw.ptr(stats[3]),
+                                           fw.ptr(mmean.tensor), fw.ptr(mvar.tensor), fw.ptr(sc)))
+            y = torch.empty_like(z)
+            resid = tens[l['resid']] if l['resid'] >= 0 else None
+            _lib.check(L.y3_bn_apply_fwd(ctx, fw.ptr(z), fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(resid), rows,
+                                         cout, 1, fw.ptr(y)))
+            rec.update(z=z, stats=stats)
+        else:              # detection conv: bias, linear (model.py:55-57)
+            y = engine.conv2d_fwd(xin, wp, ones, bias.tensor, l['k'], l['stride'], cout, False)
+        tens[l['dst']] = y
+        saved.append(rec)
+    fms = [tens[t] for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0]
+    fms.sort(key=lambda f: f.shape[1])                          # ext slots 0,1,2 = 13-, 26-, 52-grid
+    st.update(saved=saved, tens=tens, layer_vars=layer_vars, fm_grads=None, det_pad=det_pad, batch=n)
+    return fms[0], fms[1], fms[2]
+
+
+# --------------------------------------------------------------------------------------------------------
+# loss (model.py:192-365)
+# --------------------------------------------------------------------------------------------------------
+def _loss_one_scale(model, fm, y_true, anchors, loss4, accumulate, grad):
+    L = _lib.lib()
+    fm = fw.as_device_f32(fm)
+    y_true = fw.as_device_f32(y_true)
+    n, gh, gw, ch = fm.shape
+    C = int(model.class_num)
+    if ch != 3 * (5 + C):
+        raise ValueError("feature map has %d channels, expected %d" % (ch, 3 * (5 + C)))
+    if tuple(y_true.shape) != (n, gh, gw, 3, 6 + C):
+        raise ValueError("y_true shape %s does not match the feature map (expected %s)" %
+                         (tuple(y_true.shape), (n, gh, gw, 3, 6 + C)))
+    if model.img_size is None:
+        raise ValueError("loss needs img_size: call forward() first")
+    st = _train_state(model)
+    sc = _scratch(st, 'loss', L.y3_loss_scratch_bytes(n, gh, gw), fm.device)
+    anc = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(3, 2))
+    _lib.check(L.y3_loss_layer(fw.context(fm.device), fw.ptr(fm), fw.ptr(y_true), n, gh, gw, C,
+                               int(model.img_size[0]), int(model.img_size[1]),
+                               anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                               1 if model.use_label_smooth else 0, 1 if model.use_focal_loss else 0,
+                               1 if accumulate else 0, fw.ptr(loss4), fw.ptr(grad), int(grad.shape[-1]),
+                               fw.ptr(sc), ctypes.c_size_t(sc.numel())))
 
 
 def loss_layer(model, feature_map_i, y_true, anchors):
-    raise NotImplementedError('loss_layer: the training kernels are not built yet')
-
-
-def box_iou(pred_boxes, valid_true_boxes):
-    raise NotImplementedError('box_iou: the training kernels are not built yet')
+    """reference model.py:192-304: returns (xy_loss, wh_loss, conf_loss, class_loss) device scalars."""
+    fm = fw.as_device_f32(feature_map_i)
+    loss4 = torch.zeros(4, dtype=torch.float32, device=fm.device)
+    grad = torch.zeros(tuple(fm.shape[:3]) + (fm.shape[3],), dtype=torch.float32, device=fm.device)
+    _loss_one_scale(model, fm, y_true, anchors, loss4, False, grad)
+    return loss4[0], loss4[1], loss4[2], loss4[3]
 
 
 def compute_loss(model, y_pred, y_true):
-    raise NotImplementedError('compute_loss: the training kernels are not built yet')
+    """reference model.py:348-365: [total, xy, wh, conf, class] over the three scales (anchors [6:9], [3:6],
+    [0:3]).  Also leaves d(total)/d(feature_map_i) in the model's train state for the backward pass."""
+    anchors = np.asarray(model.anchors, np.float32).reshape(9, 2)
+    groups = [anchors[6:9], anchors[3:6], anchors[0:3]]
+    st = _train_state(model)
+    dev = fw.as_device_f32(y_pred[0]).device
+    loss4 = torch.zeros(4, dtype=torch.float32, device=dev)
+    det_pad = ((3 * (5 + model.class_num) + 31) // 32) * 32
+    grads = []
+    for i in range(3):
+        fm = fw.as_device_f32(y_pred[i])
+        g = torch.zeros(tuple(fm.shape[:3]) + (det_pad,), dtype=torch.float32, device=dev)   # pad lanes stay 0
+        _loss_one_scale(model, fm, y_true[i], groups[i], loss4, i > 0, g)
+        grads.append(g)
+    st['fm_grads'] = grads
+    total = loss4.sum()
+    return [total, loss4[0], loss4[1], loss4[2], loss4[3]]
+
+
+def box_iou(pred_boxes, valid_true_boxes):
+    raise NotImplementedError('box_iou is fused into the loss kernel (y3_loss_layer); no stand-alone entry yet')
+
+
+# --------------------------------------------------------------------------------------------------------
+# backward + update
+# --------------------------------------------------------------------------------------------------------
+class Trainer(object):
+    """One object = the train op of train.py:105-115: gradients of loss[0] + l2_loss w.r.t. update_vars,
+    per-tensor clip_by_norm(100), optimizer.apply_gradients; with torch.distributed initialised, gradients
+    are summed over ranks (RCCL all-reduce of ONE flat buffer) and averaged before clipping."""
+
+    def __init__(self, model, optimizer, update_vars=None, clip_norm=CLIP_NORM, process_group=None,
+                 global_step=0.0):
+        self.model, self.opt = model, optimizer
+        self.update_names = None if update_vars is None else set(v.op_name for v in update_vars)
+        self.clip_norm = float(clip_norm)
+        self.pg = process_group
+        self.global_step = float(global_step)
+        self.flat = None
+        self.views = None
+
+    def _trainable(self, var):
+        return var.trainable and (self.update_names is None or var.op_name in self.update_names)
+
+    def _alloc_grads(self, layer_vars, dev):
+        if self.flat is not None:
+            return
+        order = []
+        for wvar, bnv, bias in layer_vars:
+            order.append(wvar)
+            if bnv is not None:
+                order.extend(bnv[:2])
+            else:
+                order.append(bias)
+        order = [v for v in order if self._trainable(v)]
+        offs, total = {}, 0
+        for v in order:
+            offs[v.op_name] = total
+            total += (v.tensor.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.flat = torch.zeros(max(total, 4), dtype=torch.float32, device=dev)
+        self.views = {v.op_name: self.flat[offs[v.op_name]:offs[v.op_name] + v.tensor.numel()].view(v.tensor.shape)
+                      for v in order}
+        self.order = order
+
+    def backward(self):
+        model = self.model
+        st = _train_state(model)
+        if st.get('fm_grads') is None or st.get('saved') is None:
+            raise RuntimeError('backward needs forward(is_training=True) and compute_loss first')
+        topo, saved, tens, layer_vars = st['topo'], st['saved'], st['tens'], st['layer_vars']
+        L = _lib.lib()
+        dev = tens[0].device
+        ctx = fw.context(dev)
+        self._alloc_grads(layer_vars, dev)
+        n = st['batch']
+        # earliest layer holding a trainable variable: gradients need not flow below it
+        first = None
+        for i, (wvar, bnv, bias) in enumerate(layer_vars):
+            vs = [wvar] + (list(bnv[:2]) if bnv is not None else [bias])
+            if any(self._trainable(v) for v in vs):
+                first = i
+                break
+        if first is None:
+            return
+        needs = lambda t: t > 0 and (t - 1) >= first         # tensor t is produced by layer t-1
+        grads, have = {}, set()
+        fm_ids = sorted([t for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0],
+                        key=lambda t: topo.tensors[t]['ext'])
+        for t, g in zip(fm_ids, st['fm_grads']):
+            grads[t] = g
+            have.add(t)
+        sk_ws = _scratch(st, 'streamk', 512 * 2 * 128 * 128 * 4, dev)
+
+        def accumulate_into(t, src, src_channels, offset, c):
+            rows = src.numel() // src_channels
+            if t not in have:
+                grads[t] = torch.empty(tuple(tens[t].shape), dtype=torch.float32, device=dev)
+            _lib.check(L.y3_slice_accumulate(ctx, fw.ptr(src), src_channels, offset, rows, c, 1 if t in have else 0,
+                                             fw.ptr(grads[t])))
+            have.add(t)
+
+        for i in range(len(topo.layers) - 1, first - 1, -1):
+            l = topo.layers[i]
+            wvar, bnv, bias = layer_vars[i]
+            rec = saved[i]
+            dst = l['dst']
+            if dst not in have:
+                continue
+            dy = grads[dst]
+            cout = l['cout']
+            xin = rec['xin']
+            if l['bn']:
+                rows = dy.numel() // cout
+                if l['resid'] >= 0 and needs(l['resid']):
+                    accumulate_into(l['resid'], dy, cout, 0, cout)
+                gamma, beta = bnv[0], bnv[1]
+                stats = rec['stats']
+                tmp = torch.empty((2, cout), dtype=torch.float32, device=dev)
+                dgam = self.views.get(gamma.op_name)
+                dbet = self.views.get(beta.op_name)
+                sc = _scratch(st, 'bnbwd', L.y3_bn_bwd_scratch_bytes(cout), dev)
+                _lib.check(L.y3_bn_train_bwd(ctx, fw.ptr(rec['z']), fw.ptr(dy), fw.ptr(gamma.tensor),
+                                             fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(stats[0]), fw.ptr(stats[1]),
+                                             rows, cout, fw.ptr(dgam if dgam is not None else tmp[0]),
+                                             fw.ptr(dbet if dbet is not None else tmp[1]), fw.ptr(dy), fw.ptr(sc)))
+                dz, dz_stride, w_d = dy, cout, wvar.tensor
+            else:
+                dz_stride = int(dy.shape[-1])
+                rows = dy.numel() // dz_stride
+                if self._trainable(bias):
+                    tmp = torch.empty(dz_stride, dtype=torch.float32, device=dev)
+                    sc = _scratch(st, 'bias', 1024 * dz_stride * 4, dev)
+                    _lib.check(L.y3_bias_grad(ctx, fw.ptr(dy), rows, dz_stride, fw.ptr(tmp), fw.ptr(sc)))
+                    self.views[bias.op_name].copy_(tmp[:cout])
+                dz = dy
+                # the data gradient reads the kernel as [k*k][cin][dz_stride]: zero-extend its last axis
+                k, _, cin, _ = wvar.shape
+                w_d = torch.empty(k * k * cin * dz_stride, dtype=torch.float32, device=dev)
+                _lib.check(L.y3_pad_channels(ctx, fw.ptr(wvar.tensor), cout, k * k * cin, dz_stride, fw.ptr(w_d)))
+            d = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), int(xin.shape[3]), 0, cout, l['k'],
+                              l['stride'], 0)
+            if self._trainable(wvar):
+                wsb = L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d))
+                sc = _scratch(st, 'wgrad', wsb, dev)
+                _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
+                                           fw.ptr(self.views[wvar.op_name]), fw.ptr(sc), ctypes.c_size_t(sc.numel())))
+            src, up = l['src'], l['up']
+            need_src = needs(src)
+            need_up = up >= 0 and needs(up)
+            if not (need_src or need_up):
+                continue
+            cin = int(xin.shape[3])
+            ones, zeros = _consts(st, cin, dev)
+            if up >= 0:
+                dcat = torch.empty(tuple(xin.shape), dtype=torch.float32, device=dev)
+                _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_d), fw.ptr(ones),
+                                             fw.ptr(zeros), 0, fw.ptr(dcat), fw.ptr(sk_ws),
+                                             ctypes.c_size_t(sk_ws.numel())))
+                cu = topo.tensors[up]['c']
+                if need_up:
+                    ut = tens[up]
+                    if up not in have:
+                        grads[up] = torch.empty(tuple(ut.shape), dtype=torch.float32, device=dev)
+                    _lib.check(L.y3_upsample2x_bwd(ctx, fw.ptr(dcat), cin, n, int(ut.shape[1]), int(ut.shape[2]), cu,
+                                                   1 if up in have else 0, fw.ptr(grads[up])))
+                    have.add(up)
+                if need_src:
+                    accumulate_into(src, dcat, cin, cu, cin - cu)
+            else:
+                if src not in have:
+                    grads[src] = torch.empty(tuple(tens[src].shape), dtype=torch.float32, device=dev)
+                _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_d), fw.ptr(ones),
+                                             fw.ptr(zeros), 1 if src in have else 0, fw.ptr(grads[src]),
+                                             fw.ptr(sk_ws), ctypes.c_size_t(sk_ws.numel())))
+                have.add(src)
+            grads.pop(dst, None)      # free the consumed gradient
+        st['saved'] = None
+        st['fm_grads'] = None
+
+    def apply_gradients(self):
+        """all-reduce (mean over ranks) -> + weight_decay*w on conv kernels -> clip_by_norm -> update."""
+        L = _lib.lib()
+        dev = self.flat.device
+        ctx = fw.context(dev)
+        world = 1
+        if self.pg is not None or torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(self.pg)
+            if world > 1:
+                torch.distributed.all_reduce(self.flat, group=self.pg)
+        self.opt.step += 1
+        lr = self.opt.lr_at(self.global_step)
+        kind = Optimizer.KINDS.index(self.opt.kind)
+        if self.opt.kind == 'adam':
+            t = self.opt.step
+            lr = lr * np.sqrt(1.0 - self.opt.beta2 ** t) / (1.0 - self.opt.beta1 ** t)
+        decay = self.opt.beta1 if self.opt.kind == 'adam' else self.opt.decay
+        st = _train_state(self.model)
+        sc = _scratch(st, 'opt', L.y3_optimizer_scratch_bytes(), dev)
+        for v in self.order:
+            g = self.views[v.op_name]
+            s0, s1 = self.opt._slots_for(v)
+            wd = float(self.model.weight_decay) if v.op_name.endswith('/weights') else 0.0
+            _lib.check(L.y3_clip_update(ctx, kind, fw.ptr(v.tensor), fw.ptr(g), fw.ptr(s0), fw.ptr(s1),
+                                        v.tensor.numel(), ctypes.c_float(wd), ctypes.c_float(1.0 / world),
+                                        ctypes.c_float(self.clip_norm), ctypes.c_float(lr),
+                                        ctypes.c_float(self.opt.momentum), ctypes.c_float(decay),
+                                        ctypes.c_float(self.opt.beta2), ctypes.c_float(self.opt.epsilon), fw.ptr(sc)))
+            v.version += 1
+        fw._bump_global_version()
+        self.global_step += 1.0
+
+    def step(self, images, y_true):
+        """One training step on a batch; returns [total, xy, wh, conf, class] (device scalars)."""
+        fms = self.model.forward(images, is_training=True)
+        loss = compute_loss(self.model, fms, y_true)
+        self.backward()
+        self.apply_gradients()
+        return loss
