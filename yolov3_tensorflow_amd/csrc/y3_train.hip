@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int RED_BLOCKS = 1024;  // partial-sum rows for the column reductions
+constexpr int RED_BLOCKS = 512;   // partial-sum rows for the column reductions (2 workgroups per CU)
 
 inline int grid_for(long long work, int cap = 256 * 16) {
     long long b = (work + 255) / 256;
@@ -86,22 +86,39 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict
     }
 }
 
+// Sum partial[(b*stride_b) + idx] over b = 0..nblocks-1 in a FIXED order with one 256-thread workgroup:
+// thread t accumulates b = t, t+256, ... in fp64, then a binary tree over the 256 lanes (deterministic).
+__device__ __forceinline__ double block_sum_fixed(const float* __restrict__ partial, int nblocks, size_t stride_b,
+                                                  size_t idx, double* sh /*[256]*/) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)partial[(size_t)b * stride_b + idx];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
 // BN forward finalize: batch mean / biased variance, folded scale & shift for the apply pass, and the
 // moving-statistics update  moving <- moving*decay + batch*(1-decay)  with the UNBIASED variance going
 // into moving_variance (TF fused batch norm).
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double count,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float eps, float decay, float* __restrict__ mean,
-                                         float* __restrict__ inv_std, float* __restrict__ scale,
-                                         float* __restrict__ shift, float* __restrict__ moving_mean,
-                                         float* __restrict__ moving_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
-        s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
+__global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                                double count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float decay,
+                                                                float* __restrict__ mean, float* __restrict__ inv_std,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ moving_mean,
+                                                                float* __restrict__ moving_var) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x;   // one workgroup per channel
+    const double s0 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)c, sh);
+    const double s1 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)C + c, sh);
+    if (threadIdx.x != 0) return;
     const double mu = s0 / count;
     double var = s1 / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -120,17 +137,16 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int 
 }
 
 // BN backward finalize: d beta, d gamma (the parameter gradients) and the coefficients of the apply pass.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ inv_std,
-                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                       float* __restrict__ coef /*[3][C]: a, b, c*/) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
-        s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ inv_std,
+                                                              float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                              float* __restrict__ coef /*[3][C]: a, b, c*/) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x;
+    const double s0 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)c, sh);
+    const double s1 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)C + c, sh);
+    if (threadIdx.x != 0) return;
     if (dbeta) dbeta[c] = (float)s0;
     if (dgamma) dgamma[c] = (float)s1;
     if (coef) {
@@ -363,14 +379,15 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
     }
 }
 
-__global__ void loss_finalize_kernel(const float* __restrict__ partial, int nparts, float invN, int accumulate,
-                                     float* __restrict__ out4) {
-    const int q = threadIdx.x;
-    if (q >= 4) return;
-    double s = 0.0;
-    for (int i = 0; i < nparts; ++i) s += (double)partial[(size_t)i * 4 + q];
-    const float v = (float)(s * (double)invN);
-    out4[q] = accumulate ? out4[q] + v : v;
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const float* __restrict__ partial, int nparts, float invN,
+                                                            int accumulate, float* __restrict__ out4) {
+    __shared__ double sh[256];
+    const int q = blockIdx.x;   // 4 workgroups: xy, wh, conf, class
+    const double s = block_sum_fixed(partial, nparts, (size_t)4, (size_t)q, sh);
+    if (threadIdx.x == 0) {
+        const float v = (float)(s * (double)invN);
+        out4[q] = accumulate ? out4[q] + v : v;
+    }
 }
 
 // ---- gradient preparation and optimizer update ---------------------------------------------------------
@@ -393,12 +410,11 @@ __global__ void __launch_bounds__(256) grad_prepare_kernel(float* __restrict__ g
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void norm_finalize_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ norm) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nparts; ++i) s += (double)partial[i];
-        norm[0] = (float)sqrt(s);
-    }
+__global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                                            float* __restrict__ norm) {
+    __shared__ double sh[256];
+    const double s = block_sum_fixed(partial, nparts, (size_t)1, (size_t)0, sh);
+    if (threadIdx.x == 0) norm[0] = (float)sqrt(s);
 }
 
 // tf.clip_by_norm(g, clip) then the TF1 update rule.  kind: 0 sgd, 1 momentum, 2 adam,
@@ -455,12 +471,11 @@ __global__ void __launch_bounds__(256) pad_channels_kernel(const float* __restri
     }
 }
 
-__global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
-    out[c] = (float)s;
+__global__ void __launch_bounds__(256) col_sum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                               float* __restrict__ out) {
+    __shared__ double sh[256];
+    const double s = block_sum_fixed(partial, nblocks, (size_t)C, (size_t)blockIdx.x, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
 }
 
 }  // namespace
@@ -505,7 +520,7 @@ extern "C" int y3_bn_train_stats(y3_ctx* ctx, const float* z, long long rows, in
     Y3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "y3_bn_train_stats: moving stats must come in pairs");
     int nb = 0;
     if (int rc = reduce_launch(ctx, 0, z, nullptr, nullptr, nullptr, nullptr, nullptr, rows, c, scratch, &nb)) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, scratch, nb, c,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, ctx->stream, scratch, nb, c,
                        (double)rows, gamma, beta, eps, decay, mean, inv_std, scale, shift, moving_mean, moving_var);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
@@ -531,7 +546,7 @@ extern "C" int y3_bn_train_bwd(y3_ctx* ctx, const float* z, const float* dy, con
     int nb = 0;
     if (int rc = reduce_launch(ctx, 1, z, dy, scale, shift, mean, inv_std, rows, c, scratch, &nb)) return rc;
     float* coef = scratch + (size_t)RED_BLOCKS * 2 * c;   // scratch has room for 3*C more (see y3_bn_bwd_scratch_bytes)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, scratch, nb, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, ctx->stream, scratch, nb, c,
                        (double)rows, gamma, inv_std, dbeta, dgamma, coef);
     Y3_CHECK_HIP(hipGetLastError());
     const long long total4 = rows * (c / 4);
@@ -549,7 +564,7 @@ extern "C" int y3_bias_grad(y3_ctx* ctx, const float* dy, long long rows, int c,
     const int nb = (int)(rows < RED_BLOCKS ? rows : RED_BLOCKS);
     hipLaunchKernelGGL(col_sum_scalar_kernel, dim3(nb), dim3(256), 0, ctx->stream, dy, rows, c, scratch);
     Y3_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, scratch, nb, c, dbias);
+    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3(c), dim3(256), 0, ctx->stream, scratch, nb, c, dbias);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
@@ -620,7 +635,7 @@ extern "C" int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float*
     const size_t lds = (size_t)a.vmax * 4 * sizeof(float);
     hipLaunchKernelGGL(loss_kernel, dim3(blocks, n), dim3(256), lds, ctx->stream, a);
     Y3_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, a.partial, blocks * n,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(4), dim3(256), 0, ctx->stream, a.partial, blocks * n,
                        1.f / (float)n, accumulate, loss4);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
@@ -641,7 +656,7 @@ extern "C" int y3_clip_update(y3_ctx* ctx, int kind, float* w, float* g, float* 
     float* norm = scratch + RED_BLOCKS;
     hipLaunchKernelGGL(grad_prepare_kernel, dim3(nb), dim3(256), 0, ctx->stream, g, w, weight_decay, grad_scale, n, scratch);
     Y3_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, ctx->stream, scratch, nb, norm);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, scratch, nb, norm);
     Y3_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(optimizer_update_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, w, g, slot0, slot1,
                        norm, clip_norm, kind, lr, momentum, decay, beta2, eps, n);

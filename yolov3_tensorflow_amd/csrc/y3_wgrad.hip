@@ -30,16 +30,24 @@ constexpr int WBK = 32;          // pixels per K-step
 constexpr int WLD = 128;         // LDS row stride (floats): lanes of a half-wave read consecutive floats
 constexpr unsigned OOB = 0x80000000u;
 
+// BNT = output-channel tile (128 / 64 / 32), waves arranged WGM x WGN over (j, co)
+template <int BNT, int WGM, int WGN>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
+    constexpr int WTM = 128 / WGM, WTN = BNT / WGN;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
+    static_assert(WGM * WGN == 4 && MI >= 1 && NI >= 1, "bad wave layout");
+    constexpr int BC4 = BNT / 4;            // float4 columns of a dz row inside the tile
+    constexpr int BRP = 256 / BC4;          // dz rows staged per pass
+    constexpr int BPASS = WBK / BRP;        // passes (128: 4, 64: 2, 32: 1)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][32][128]  patch rows  P[m][j]
-    float* Bs = smem + 2 * WBK * WLD;   // [2][32][128]  dz rows     dz[m][co]
+    float* Bs = smem + 2 * WBK * WLD;   // [2][32][BNT]  dz rows     dz[m][co]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nct = (p.Cout + 127) / 128;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nct = (p.Cout + BNT - 1) / BNT;
     const int jt = blockIdx.x / nct, ct = blockIdx.x - jt * nct;
-    const int j0 = jt * 128, co0 = ct * 128;
+    const int j0 = jt * 128, co0 = ct * BNT;
     const int split = blockIdx.y;
     const int m_begin = split * p.chunk;
     const int m_end = min(m_begin + p.chunk, ((p.M + WBK - 1) / WBK) * WBK);
@@ -50,7 +58,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.dz), 0, (unsigned)((size_t)p.M * p.CoP * 4), 0x00020000);
 
-    // staging coordinates: float4 column c4 (fixed per thread), rows (tid>>5) + 8*i
+    // A (patch) staging: float4 column c4 (fixed per thread), rows (tid>>5) + 8*i
     const int c4 = (tid & 31) * 4;
     const int r0 = tid >> 5;
     const int j = j0 + c4;
@@ -58,62 +66,82 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
     const int tap = j_ok ? j / p.Cin : 0;
     const int ci = j - tap * p.Cin;
     const int ky = tap / p.k, kx = tap - ky * p.k;
-    const bool co_ok = co0 + c4 < p.CoP;
-    const int HoWo = p.Ho * p.Wo;
+    // B (dz) staging: float4 column bc4, rows (tid / BC4) + BRP*i
+    const int bc4 = (tid % BC4) * 4;
+    const int br0 = tid / BC4;
+    const bool co_ok = co0 + bc4 < p.CoP;
 
-    f32x4 ra[4], rb[4];
+    // pixel coordinates of this thread's 4 patch rows, advanced incrementally by 32 pixels per K-step
+    int pn[4], poy[4], pox[4];
+    {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_begin + r0 + 8 * i;
+            pn[i] = m / HoWo;
+            const int rem = m - pn[i] * HoWo;
+            poy[i] = rem / p.Wo;
+            pox[i] = rem - poy[i] * p.Wo;
+        }
+    }
+
+    f32x4 ra[4], rb[BPASS];
     auto load_tile = [&](int t) {
         const int mb = m_begin + t * WBK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = mb + r0 + 8 * i;
             unsigned offa = OOB;
-            if (j_ok && m < p.M) {
-                const int n = m / HoWo;
-                const int rem = m - n * HoWo;
-                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    offa = (unsigned)(((n * p.H + iy) * p.W + ix) * p.Cin + ci) * 4u;
-            }
+            const int iy = poy[i] * p.stride - p.pad + ky, ix = pox[i] * p.stride - p.pad + kx;
+            if (j_ok && pn[i] < p.N && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                offa = (unsigned)(((pn[i] * p.H + iy) * p.W + ix) * p.Cin + ci) * 4u;
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, offa, 0, 0));
+            // advance 32 pixels
+            pox[i] += WBK;
+            while (pox[i] >= p.Wo) {
+                pox[i] -= p.Wo;
+                if (++poy[i] == p.Ho) { poy[i] = 0; ++pn[i]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
             // rows m >= M lie beyond the end of dz: the buffer load returns 0 for them
-            const unsigned offb = co_ok ? (unsigned)(m * p.CoP + co0 + c4) * 4u : OOB;
+            const int m = mb + br0 + BRP * i;
+            const unsigned offb = co_ok ? (unsigned)(m * p.CoP + co0 + bc4) * 4u : OOB;
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, offb, 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(As + (buf * WBK + r0 + 8 * i) * WLD + c4) = ra[i];
-            *reinterpret_cast<f32x4*>(Bs + (buf * WBK + r0 + 8 * i) * WLD + c4) = rb[i];
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + (buf * WBK + r0 + 8 * i) * WLD + c4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            *reinterpret_cast<f32x4*>(Bs + (buf * WBK + br0 + BRP * i) * BNT + bc4) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     // MFMA operands: A[i][k] = P[m=k][j=i], B[k][n] = dz[m=k][co=n]; lane l holds k = l>>5
     const int fcol = lane & 31, fk = lane >> 5;
     auto compute_tile = [&](int buf) {
-        const float* as = As + buf * WBK * WLD + fk * WLD + wm * 64 + fcol;
-        const float* bs = Bs + buf * WBK * WLD + fk * WLD + wn * 64 + fcol;
+        const float* as = As + buf * WBK * WLD + fk * WLD + wm * WTM + fcol;
+        const float* bs = Bs + buf * WBK * BNT + fk * BNT + wn * WTN + fcol;
 #pragma unroll
         for (int s = 0; s < WBK / 2; ++s) {
-            float a[2], b[2];
-            a[0] = as[(2 * s) * WLD];
-            a[1] = as[(2 * s) * WLD + 32];
-            b[0] = bs[(2 * s) * WLD];
-            b[1] = bs[(2 * s) * WLD + 32];
+            float a[MI], b[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi) a[mi] = as[(2 * s) * WLD + mi * 32];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni) b[ni] = bs[(2 * s) * BNT + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     };
@@ -134,12 +162,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
     // D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (j)
     float* out = p.out + (size_t)split * p.J * p.Cout;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int co = co0 + wn * 64 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = co0 + wn * WTN + ni * 32 + (lane & 31);
         if (co >= p.Cout) continue;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int jb = j0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+        for (int mi = 0; mi < MI; ++mi) {
+            const int jb = j0 + wm * WTM + mi * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jj = jb + (r & 3) + 8 * (r >> 2);
@@ -188,14 +216,17 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
 
 }  // namespace
 
-// split heuristic: aim at ~1024 workgroups (2 per CU x 2 rounds), at most 64 splits
+static int wgrad_co_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
+
+// split heuristic: aim at ~1024 workgroups (2 per CU x 2 rounds), at most 512 splits
 static void wgrad_split(const y3_conv_desc* d, int* nsplit_out, int* chunk_out) {
     const long long M = (long long)d->n * (d->h / d->stride) * (d->w / d->stride);
     const int J = d->k * d->k * d->cin;
-    const int tiles = ((J + 127) / 128) * ((d->cout + 127) / 128);
+    const int bnt = wgrad_co_tile(d->cout);
+    const int tiles = ((J + 127) / 128) * ((d->cout + bnt - 1) / bnt);
     const int ksteps = (int)((M + WBK - 1) / WBK);
     int nsplit = (1024 + tiles - 1) / tiles;
-    if (nsplit > 64) nsplit = 64;
+    if (nsplit > 512) nsplit = 512;
     if (nsplit > ksteps) nsplit = ksteps;
     if (nsplit < 1) nsplit = 1;
     const int chunk = ((ksteps + nsplit - 1) / nsplit) * WBK;
@@ -243,19 +274,26 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     a.x = x; a.dz = dz;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.CoP = dz_stride;
     a.k = d->k; a.stride = d->stride; a.pad = d->k / 2; a.M = (int)M; a.J = d->k * d->k * d->cin;
-    const int tiles = ((a.J + 127) / 128) * ((a.Cout + 127) / 128);
+    const int bnt = wgrad_co_tile(a.Cout);
+    const int tiles = ((a.J + 127) / 128) * ((a.Cout + bnt - 1) / bnt);
     int nsplit;
     wgrad_split(d, &nsplit, &a.chunk);
     a.nsplit = nsplit;
     a.out = nsplit == 1 ? dw_hwio : static_cast<float*>(scratch);
     static bool attr_set = false;
-    const size_t lds = (size_t)4 * WBK * WLD * sizeof(float);
     if (!attr_set) {
-        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<128, 2, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(2 * WBK * (WLD + 128) * sizeof(float))));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, nsplit), dim3(256), lds, st, a);
+    const size_t lds = (size_t)2 * WBK * (WLD + bnt) * sizeof(float);
+    if (bnt == 128)
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2>), dim3(tiles, nsplit), dim3(256), lds, st, a);
+    else if (bnt == 64)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2>), dim3(tiles, nsplit), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 4, 1>), dim3(tiles, nsplit), dim3(256), lds, st, a);
     Y3_CHECK_HIP(hipGetLastError());
     if (nsplit > 1) {
         const long long n = (long long)a.J * a.Cout;
