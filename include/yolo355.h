@@ -214,6 +214,11 @@ int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float* y_true, in
                   int use_focal_loss, int accumulate, float* loss4, float* grad, int grad_stride, void* scratch,
                   size_t scratch_bytes);
 
+/* box_iou (model.py:307-345): pred_boxes [num_pred][4], true_boxes [num_true][4], both (cx,cy,w,h);
+ * iou [num_pred][num_true] = inter / (area_p + area_t - inter + 1e-10). */
+int y3_box_iou(y3_ctx* ctx, const float* pred_boxes, long long num_pred, const float* true_boxes, int num_true,
+               float* iou);
+
 /* K11: g <- g*grad_scale + weight_decay*w (slim.l2_regularizer, model.py:49) ; g <- tf.clip_by_norm(g, clip)
  * (train.py:113-114) ; TF1 update rule (utils/misc_utils.py:151-161).  kind: 0 sgd, 1 momentum (slot0 =
  * accumulator), 2 adam (slot0 = m, slot1 = v, decay = beta1, lr = lr_t), 3 rmsprop (slot0 = ms, slot1 = mom).

@@ -478,7 +478,24 @@ __global__ void __launch_bounds__(256) col_sum_finalize_kernel(const float* __re
     if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
 }
 
+// box_iou (model.py:307-345): IoU of every predicted box (cx,cy,w,h) with every ground-truth box (cx,cy,w,h)
+__global__ void __launch_bounds__(256) box_iou_kernel(const float* __restrict__ pred, long long np,
+                                                      const float* __restrict__ gt, int v, float* __restrict__ iou) {
+    const long long total = np * v;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pi = i / v;
+        const int gi = (int)(i - pi * v);
+        const float px = pred[pi * 4], py = pred[pi * 4 + 1], pw = pred[pi * 4 + 2], ph = pred[pi * 4 + 3];
+        const float tx = gt[gi * 4], ty = gt[gi * 4 + 1], tw = gt[gi * 4 + 2], th = gt[gi * 4 + 3];
+        const float iw = fmaxf(fminf(px + pw / 2.f, tx + tw / 2.f) - fmaxf(px - pw / 2.f, tx - tw / 2.f), 0.f);
+        const float ih = fmaxf(fminf(py + ph / 2.f, ty + th / 2.f) - fmaxf(py - ph / 2.f, ty - th / 2.f), 0.f);
+        const float inter = iw * ih;
+        iou[i] = inter / (pw * ph + tw * th - inter + 1e-10f);
+    }
+}
+
 }  // namespace
+
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -669,6 +686,16 @@ extern "C" int y3_pad_channels(y3_ctx* ctx, const float* src, int c_src, long lo
     Y3_CHECK_ARG(rows > 0 && c_src > 0 && c_dst >= c_src, "y3_pad_channels: bad shape");
     hipLaunchKernelGGL(pad_channels_kernel, dim3(grid_for(rows * c_dst)), dim3(256), 0, ctx->stream, src, c_src,
                        rows, c_dst, dst);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_box_iou(y3_ctx* ctx, const float* pred_boxes, long long num_pred, const float* true_boxes,
+                          int num_true, float* iou) {
+    Y3_CHECK_ARG(ctx && pred_boxes && true_boxes && iou, "y3_box_iou: null argument");
+    Y3_CHECK_ARG(num_pred > 0 && num_true > 0, "y3_box_iou: empty input");
+    hipLaunchKernelGGL(box_iou_kernel, dim3(grid_for(num_pred * num_true)), dim3(256), 0, ctx->stream, pred_boxes,
+                       num_pred, true_boxes, num_true, iou);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

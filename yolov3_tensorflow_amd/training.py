@@ -231,7 +231,18 @@ def compute_loss(model, y_pred, y_true):
 
 
 def box_iou(pred_boxes, valid_true_boxes):
-    raise NotImplementedError('box_iou is fused into the loss kernel (y3_loss_layer); no stand-alone entry yet')
+    """reference model.py:307-345: pred_boxes [g,g,3,4] (cx,cy,w,h), valid_true_boxes [V,4] -> iou [g,g,3,V].
+    (Inside compute_loss the same arithmetic is fused into the loss kernel.)"""
+    pb = fw.as_device_f32(pred_boxes)
+    tb = fw.as_device_f32(valid_true_boxes).reshape(-1, 4)
+    if pb.shape[-1] != 4:
+        raise ValueError("pred_boxes must end in 4 (cx, cy, w, h)")
+    v = int(tb.shape[0])
+    out = torch.empty(tuple(pb.shape[:-1]) + (v,), dtype=torch.float32, device=pb.device)
+    if v == 0 or pb.numel() == 0:
+        return out
+    _lib.check(_lib.lib().y3_box_iou(fw.context(pb.device), fw.ptr(pb), pb.numel() // 4, fw.ptr(tb), v, fw.ptr(out)))
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------
