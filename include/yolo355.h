@@ -214,6 +214,14 @@ int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float* y_true, in
                   int use_focal_loss, int accumulate, float* loss4, float* grad, int grad_stride, void* scratch,
                   size_t scratch_bytes);
 
+/* ---- next row 8(f)#1: target assignment on the device (utils/data_utils.py:51-115 `process_box`) ------------
+ * boxes [n][kmax][5] = (x_min,y_min,x_max,y_max,mix_weight) in resized-image pixels, labels [n][kmax] int32,
+ * counts [n] int32 (boxes actually present per image), anchors: 9 (w,h) pairs.  Writes the three y_true
+ * tensors [n][g][g][3][6+C] (zero, mix weight 1, then the per-box entries in box order). */
+int y3_process_box(y3_ctx* ctx, const float* boxes, const int32_t* labels, const int32_t* counts, int n, int kmax,
+                   int class_num, int img_w, int img_h, const float* anchors_host18, float* y_true_13,
+                   float* y_true_26, float* y_true_52);
+
 /* box_iou (model.py:307-345): pred_boxes [num_pred][4], true_boxes [num_true][4], both (cx,cy,w,h);
  * iou [num_pred][num_true] = inter / (area_p + area_t - inter + 1e-10). */
 int y3_box_iou(y3_ctx* ctx, const float* pred_boxes, long long num_pred, const float* true_boxes, int num_true,

@@ -133,3 +133,24 @@ def test_scope_naming_matches_slim():
 def test_unknown_optimizer_raises_value_error():
     with pytest.raises(ValueError):
         misc_utils.config_optimizer('lion', 1e-3)
+
+
+def test_letterbox_resize_matches_the_reference_geometry():
+    """SURVEY App. B.9: messi.jpg is 1296x729 -> ratio 0.32098..., resized 416x234, dw=0, dh=91, pad 128;
+    nearest sampling src = min(floor(dst*src/dst_size), src-1)."""
+    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (729, 1296, 3)).astype(np.uint8)
+    out, ratio, dw, dh = letterbox_resize(img, 416, 416)
+    assert out.shape == (416, 416, 3) and out.dtype == np.uint8
+    assert abs(ratio - 416 / 1296) < 1e-12 and (dw, dh) == (0, 91)
+    assert (out[:91] == 128).all() and (out[91 + 234:] == 128).all()
+    # explicit nearest-neighbour mapping
+    sy = min(int(np.floor(10 * 729 / 234.0)), 728)
+    sx = min(int(np.floor(100 * 1296 / 416.0)), 1295)
+    assert (out[91 + 10, 100] == img[sy, sx]).all()
+    # dog.jpg 768x576 -> 416x312, dh=52 ; kite 1352x900 -> 416x276, dh=70
+    assert letterbox_resize(np.zeros((576, 768, 3), np.uint8), 416, 416)[2:] == (0, 52)
+    assert letterbox_resize(np.zeros((900, 1352, 3), np.uint8), 416, 416)[2:] == (0, 70)
+    with pytest.raises(ValueError):
+        letterbox_resize(img, 416, 416, interp=1)

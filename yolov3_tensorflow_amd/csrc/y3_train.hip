@@ -494,7 +494,57 @@ __global__ void __launch_bounds__(256) box_iou_kernel(const float* __restrict__ 
     }
 }
 
+// ---- target assignment (utils/data_utils.py:51-115 `process_box`) ---------------------------------------
+// One thread per image walks its boxes IN ORDER (later boxes overwrite earlier ones in the same cell/anchor;
+// class one-hots are not cleared on overwrite, exactly like the reference).  fp32 arithmetic in numpy's order.
+struct TargetArgs {
+    const float* boxes;   // [N][kmax][5]  x0,y0,x1,y1,mix_w
+    const int* labels;    // [N][kmax]
+    const int* counts;    // [N]
+    float* y[3];          // y_true_13 / 26 / 52 : [N][g][g][3][6+C]
+    int N, kmax, C, img_w, img_h;
+    float anc_w[9], anc_h[9];
+};
+
+__global__ void __launch_bounds__(256) target_fill_kernel(float* __restrict__ y, long long cells, int T) {
+    // zeros, with the trailing mix-up weight preset to 1 (utils/data_utils.py:70-77)
+    const long long total = cells * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        y[i] = (i % T) == T - 1 ? 1.f : 0.f;
+}
+
+__global__ void target_assign_kernel(const TargetArgs a) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const int T = 6 + a.C;
+    const int K = min(a.counts[n], a.kmax);
+    for (int i = 0; i < K; ++i) {
+        const float* b = a.boxes + ((size_t)n * a.kmax + i) * 5;
+        const float cx = (b[0] + b[2]) / 2.f, cy = (b[1] + b[3]) / 2.f;
+        const float bw = b[2] - b[0], bh = b[3] - b[1];
+        int best = 0;
+        float best_iou = -INFINITY;
+        for (int k = 0; k < 9; ++k) {
+            const float w = fminf(bw / 2.f, a.anc_w[k] / 2.f) - fmaxf(-bw / 2.f, -a.anc_w[k] / 2.f);
+            const float h = fminf(bh / 2.f, a.anc_h[k] / 2.f) - fmaxf(-bh / 2.f, -a.anc_h[k] / 2.f);
+            const float iou = (w * h) / (bw * bh + a.anc_w[k] * a.anc_h[k] - w * h + 1e-10f);
+            if (iou > best_iou) { best_iou = iou; best = k; }      // np.argmax: first maximum
+        }
+        const int group = 2 - best / 3;                              // 0 -> 13-grid
+        const float stride = best / 3 == 0 ? 8.f : (best / 3 == 1 ? 16.f : 32.f);
+        const int gx = (int)floorf(cx / stride), gy = (int)floorf(cy / stride);
+        const int gw = a.img_w / (int)stride, gh = a.img_h / (int)stride;
+        if (gx < 0 || gy < 0 || gx >= gw || gy >= gh) continue;     // numpy would raise IndexError here
+        float* y = a.y[group] + ((((size_t)n * gh + gy) * gw + gx) * 3 + best % 3) * T;
+        y[0] = cx; y[1] = cy; y[2] = bw; y[3] = bh; y[4] = 1.f;
+        const int c = a.labels[(size_t)n * a.kmax + i];
+        if (c >= 0 && c < a.C) y[5 + c] = 1.f;
+        y[T - 1] = b[4];
+    }
+}
+
 }  // namespace
+
 
 
 
@@ -696,6 +746,31 @@ extern "C" int y3_box_iou(y3_ctx* ctx, const float* pred_boxes, long long num_pr
     Y3_CHECK_ARG(num_pred > 0 && num_true > 0, "y3_box_iou: empty input");
     hipLaunchKernelGGL(box_iou_kernel, dim3(grid_for(num_pred * num_true)), dim3(256), 0, ctx->stream, pred_boxes,
                        num_pred, true_boxes, num_true, iou);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+extern "C" int y3_process_box(y3_ctx* ctx, const float* boxes, const int32_t* labels, const int32_t* counts, int n,
+                              int kmax, int class_num, int img_w, int img_h, const float* anchors_host18,
+                              float* y_true_13, float* y_true_26, float* y_true_52) {
+    Y3_CHECK_ARG(ctx && boxes && labels && counts && anchors_host18 && y_true_13 && y_true_26 && y_true_52,
+                 "y3_process_box: null argument");
+    Y3_CHECK_ARG(n > 0 && kmax > 0 && class_num > 0, "y3_process_box: non-positive dimension");
+    Y3_CHECK_ARG(img_w > 0 && img_h > 0 && img_w % 32 == 0 && img_h % 32 == 0,
+                 "y3_process_box: image size must be a positive multiple of 32");
+    TargetArgs a;
+    a.boxes = boxes; a.labels = labels; a.counts = counts;
+    a.y[0] = y_true_13; a.y[1] = y_true_26; a.y[2] = y_true_52;
+    a.N = n; a.kmax = kmax; a.C = class_num; a.img_w = img_w; a.img_h = img_h;
+    for (int k = 0; k < 9; ++k) { a.anc_w[k] = anchors_host18[2 * k]; a.anc_h[k] = anchors_host18[2 * k + 1]; }
+    const int T = 6 + class_num;
+    const int strides[3] = {32, 16, 8};
+    for (int s = 0; s < 3; ++s) {
+        const long long cells = (long long)n * (img_h / strides[s]) * (img_w / strides[s]) * 3;
+        hipLaunchKernelGGL(target_fill_kernel, dim3(grid_for(cells * T)), dim3(256), 0, ctx->stream, a.y[s], cells, T);
+        Y3_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(target_assign_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

@@ -252,6 +252,16 @@ class yolov3(object):
             return boxes, confs, probs, scores
         return boxes, confs, probs
 
+    def detect(self, inputs, max_boxes=200, score_thresh=0.3, nms_thresh=0.45):
+        """SURVEY §8(f) row 2 — the whole inference path for a batch with everything resident on the device:
+        forward -> predict (+ fused conf*prob) -> per-class NMS for all N images in one launch set.  Replaces
+        the per-image `sess.run` round trips of eval.py:114-123 / utils/eval_utils.py:237-261.
+        Returns a list of N tuples (boxes [K,4], scores [K], labels [K] int32) of device tensors."""
+        from .utils import nms_utils
+        fms = self.forward(inputs, False)
+        boxes, _, _, scores = self.predict(fms, with_scores=True)
+        return nms_utils.gpu_nms_batched(boxes, scores, self.class_num, max_boxes, score_thresh, nms_thresh)
+
     # ------------------------------------------------------------------------------------------
     # loss (training path)
     # ------------------------------------------------------------------------------------------
