@@ -45,9 +45,11 @@ struct ConvArgs {
     int M;
     int workers;         // stream-K grid size (0 = data-parallel)
     int wrev;            // 1: walk the weight taps in reverse order (data-gradient = conv with the flipped kernel)
-    int tmode;           // 1: transposed stride-2 gather (data-gradient of a stride-2 conv): x is the coarse
-                         //    [N,H,W,Cx] gradient, the output grid is [N,2H,2W]; tap (ky,kx) of output pixel
-                         //    (oy,ox) reads x[(oy-1+ky)/2, (ox-1+kx)/2] when both are even and in range
+    int tmode;           // 1: data gradient of a stride-2 3x3 conv, ONE output parity class (cy,cx) per launch:
+                         //    x is the coarse gradient [N,H,W,Cx], the output grid is [N,2H,2W]; rows enumerate
+                         //    the class pixels (2y'+cy, 2x'+cx); only the taps whose parity matches contribute
+                         //    (1, 2, 2 or 4 of the 9), reading x[y'+dy, x'+dx] with dy,dx in {0,1}
+    int cy, cx, ntaps;   // tmode only
 };
 
 constexpr int BK = 32;
@@ -75,6 +77,15 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    // output pixel of GEMM row `row`: the row itself, or (tmode) pixel (2y'+cy, 2x'+cx) of the 2x finer grid
+    auto out_pixel = [&](int row) -> size_t {
+        if (!p.tmode) return (size_t)row;
+        const int hw = p.H * p.W;
+        const int n = row / hw;
+        const int rem = row - n * hw;
+        const int y = rem / p.W, x = rem - y * p.W;
+        return ((size_t)(n * 2 * p.H + 2 * y + p.cy)) * (2 * p.W) + 2 * x + p.cx;
+    };
     if ((p.Cout & 3) == 0) {
         constexpr int C4 = BN / 4;     // float4 columns per tile row
         constexpr int RPP = 256 / C4;  // rows covered per pass
@@ -89,7 +100,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
             for (int i = 0; i < PASSES; ++i) {
                 const int row = m0 + tr + i * RPP;
                 res[i] = (cok && row < p.M)
-                             ? *reinterpret_cast<const f32x4*>(p.resid + (size_t)row * p.Cout + col)
+                             ? *reinterpret_cast<const f32x4*>(p.resid + out_pixel(row) * p.Cout + col)
                              : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -118,7 +129,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                     }
                     if (p.resid) v += res[i];
-                    *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.Cout + col) = v;
+                    *reinterpret_cast<f32x4*>(p.y + out_pixel(row) * p.Cout + col) = v;
                 }
             }
         }
@@ -140,7 +151,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                 if (cok && row < p.M) {
                     float v = acc[mi][ni][r] * sc + sh;
                     if (p.act) v = v > 0.f ? v : 0.1f * v;
-                    const size_t o = (size_t)row * p.Cout + col;
+                    const size_t o = out_pixel(row) * p.Cout + col;
                     if (p.resid) v += p.resid[o];
                     p.y[o] = v;
                 }
@@ -187,7 +198,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
     const int nbn = (p.Cout + BN - 1) / BN;
     const int nbm = (p.M + BM - 1) / BM;
     const int kchunks = p.Cin / BK;
-    const int S = KS * KS * kchunks;  // K-steps per output tile
+    const int taps = p.tmode ? p.ntaps : KS * KS;
+    const int S = taps * kchunks;  // K-steps per output tile
 
     // ---- this workgroup's range of work items (item = tile * S + kstep) ----------------------------
     long long item, item_end;
@@ -232,19 +244,28 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
     unsigned a_voff[AROWS], a_voff_u[UPCAT ? AROWS : 1], b_voff[BROWS];
     int ld_tap = 0, ld_cc = 0;
 
+    int ld_wtap = 0;   // index of the weight tap plane of the prepared K-step
     auto set_tap = [&]() {
-        const int ky = (KS == 1) ? 0 : ld_tap / KS;
-        const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
-        const int tap_off = (ky * p.W + kx) * p.Cx + c4;
+        int ky, kx, dy, dx;
+        if (p.tmode) {
+            const int nkx = p.cx ? 2 : 1;
+            const int ty = ld_tap / nkx, tx = ld_tap - ty * nkx;
+            ky = p.cy ? 2 * ty : 1;
+            kx = p.cx ? 2 * tx : 1;
+            dy = (p.cy + ky - 1) >> 1;     // source row = y' + dy
+            dx = (p.cx + kx - 1) >> 1;
+        } else {
+            ky = (KS == 1) ? 0 : ld_tap / KS;
+            kx = (KS == 1) ? 0 : ld_tap - ky * KS;
+            dy = ky;
+            dx = kx;
+        }
+        ld_wtap = p.wrev ? KS * KS - 1 - (ky * KS + kx) : ky * KS + kx;
+        const int tap_off = (dy * p.W + dx) * p.Cx + c4;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int mk = a_msk[j];
-            const bool ok = ((mk >> ky) & (mk >> (4 + kx)) & 1) != 0;
-            if (p.tmode) {
-                const int dy = (ky + ((mk >> 8) & 1)) >> 1, dx = (kx + ((mk >> 9) & 1)) >> 1;
-                a_voff[j] = ok ? (unsigned)(a_base[j] + (dy * p.W + dx) * p.Cx + c4) * 4u : OOB;
-                continue;
-            }
+            const bool ok = ((mk >> dy) & (mk >> (4 + dx)) & 1) != 0;
             a_voff[j] = ok ? (unsigned)(a_base[j] + tap_off) * 4u : OOB;
             if (UPCAT) a_voff_u[j] = ok ? (unsigned)(a_base_u[j] + c4) * 4u : OOB;
         }
@@ -256,7 +277,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         const int bn = tile / nbm, bm = tile - bn * nbm;
         ld_tap = ks / kchunks;
         ld_cc = ks - ld_tap * kchunks;
-        const int HoWo = p.Ho * p.Wo;
+        const int HoWo = p.tmode ? p.H * p.W : p.Ho * p.Wo;
+        const int Wrow = p.tmode ? p.W : p.Wo;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int m = bm * BM + r0 + 32 * j;
@@ -264,29 +286,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                const int iy0 = oy * p.stride - p.pad;
-                const int ix0 = ox * p.stride - p.pad;
-                if (p.tmode) {
-                    // source pixel of tap (ky,kx): ((iy0+ky)/2, (ix0+kx)/2) when both sums are even and in range
-                    const int hy = iy0 >> 1, hx = ix0 >> 1, py = iy0 & 1, px = ix0 & 1;
+                const int oy = rem / Wrow;
+                const int ox = rem - oy * Wrow;
+                // first source pixel of the row (tmode: (y', x'); else (oy*stride - pad, ox*stride - pad))
+                const int iy0 = p.tmode ? oy : oy * p.stride - p.pad;
+                const int ix0 = p.tmode ? ox : ox * p.stride - p.pad;
 #pragma unroll
-                    for (int t = 0; t < KS; ++t) {
-                        const int sy = hy + ((t + py) >> 1), sx = hx + ((t + px) >> 1);
-                        if (!((t + py) & 1) && (unsigned)sy < (unsigned)p.H) mk |= 1 << t;
-                        if (!((t + px) & 1) && (unsigned)sx < (unsigned)p.W) mk |= 1 << (4 + t);
-                    }
-                    mk |= (py << 8) | (px << 9);
-                    base = ((n * p.H + hy) * p.W + hx) * p.Cx;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < KS; ++t) {
-                        if ((unsigned)(iy0 + t) < (unsigned)p.H) mk |= 1 << t;
-                        if ((unsigned)(ix0 + t) < (unsigned)p.W) mk |= 1 << (4 + t);
-                    }
-                    base = ((n * p.H + iy0) * p.W + ix0) * p.Cx;
+                for (int t = 0; t < KS; ++t) {
+                    if ((unsigned)(iy0 + t) < (unsigned)p.H) mk |= 1 << t;
+                    if ((unsigned)(ix0 + t) < (unsigned)p.W) mk |= 1 << (4 + t);
                 }
+                base = ((n * p.H + iy0) * p.W + ix0) * p.Cx;
                 if (UPCAT) base_u = ((n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.Cu;
             }
             a_msk[j] = mk;
@@ -321,8 +331,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             for (int j = 0; j < AROWS; ++j)
                 ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], soff, 0));
         }
-        const int wtap = p.wrev ? KS * KS - 1 - ld_tap : ld_tap;
-        const unsigned wsoff = (unsigned)((wtap * p.Cout) * p.Cin + c0) * 4u;
+        const unsigned wsoff = (unsigned)((ld_wtap * p.Cout) * p.Cin + c0) * 4u;
 #pragma unroll
         for (int j = 0; j < BROWS; ++j)
             rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff[j], wsoff, 0));
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         if (++ld_cc == kchunks) {
             ld_cc = 0;
             ++ld_tap;
-            if (KS > 1 && ld_tap < KS * KS) set_tap();
+            if (KS > 1 && ld_tap < taps) set_tap();
         }
     };
 
@@ -468,7 +477,7 @@ __global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvAr
     using G = Geo<BM, BN, WGM, WGN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nbn = (p.Cout + BN - 1) / BN;
-    const int S = KS * KS * (p.Cin / BK);
+    const int S = (p.tmode ? p.ntaps : KS * KS) * (p.Cin / BK);
     const long long items = (long long)((p.M + BM - 1) / BM) * nbn * S;
     const int tile = blockIdx.x;
     const long long t0 = (long long)tile * S, t1 = t0 + S;
@@ -664,7 +673,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     Y3_CHECK_ARG((x_up != nullptr) == (d->c_up > 0), "y3_conv2d_fwd: x_up and c_up must agree");
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
-    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0;
+    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -722,7 +731,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     ConvArgs a;
     a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
     a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.workers = 0;
-    a.wrev = 1; a.tmode = fwd->stride == 2 ? 1 : 0;
+    a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
     a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;
     a.Ho = fwd->h; a.Wo = fwd->w;
@@ -733,6 +742,26 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     if (fwd->k == 1) return dispatch_bn<1, false>(stream, a);
     const bool has_ws = workspace != nullptr && workspace_bytes >= (size_t)SK_WORKERS * 2 * 128 * 128 * sizeof(float) &&
                         ((uintptr_t)workspace & 15) == 0;
+    if (fwd->stride == 2) {
+        // four output parity classes, each a dense conv over N*Ho*Wo rows with 1/2/2/4 taps
+        a.tmode = 1;
+        a.M = (int)((long long)fwd->n * Ho * Wo);
+        for (int cls = 0; cls < 4; ++cls) {
+            a.cy = cls >> 1; a.cx = cls & 1;
+            a.ntaps = (a.cy ? 2 : 1) * (a.cx ? 2 : 1);
+            a.partial = nullptr; a.workers = 0;
+            int rc;
+            if (use_streamk(a, 3, has_ws)) {
+                a.partial = static_cast<float*>(workspace);
+                a.workers = SK_WORKERS;
+                rc = launch_streamk<3>(stream, a, nullptr);
+            } else {
+                rc = dispatch_bn<3, false>(stream, a);
+            }
+            if (rc != Y3_OK) return rc;
+        }
+        return Y3_OK;
+    }
     if (use_streamk(a, 3, has_ws)) {
         a.partial = static_cast<float*>(workspace);
         a.workers = SK_WORKERS;

@@ -281,6 +281,9 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x
 // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
 __device__ __forceinline__ float bce_(float z, float x) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
 
+// One WAVE per (cell, anchor) record: the 5+C logits and 6+C targets of a record are contiguous, so lanes
+// read/write them coalesced (lane f handles fields f, f+64, ...); the ignore-mask IoU loop runs with one
+// ground-truth box per lane and a wave max-reduction.
 __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
     extern __shared__ float gts[];                         // [V][4] of this image
     __shared__ float red[4][4];
@@ -291,71 +294,75 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
     for (int i = threadIdx.x; i < V * 4; i += 256) gts[i] = a.gt_boxes[(size_t)n * a.cap * 4 + i];
     __syncthreads();
     const float invN = 1.f / (float)a.N;
-    float l_xy = 0.f, l_wh = 0.f, l_conf = 0.f, l_cls = 0.f;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < cells) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float l_xy = 0.f, l_wh = 0.f, l_conf = 0.f, l_cls = 0.f;   // lane-partial sums
+    for (int i = blockIdx.x * 4 + wave; i < cells; i += gridDim.x * 4) {
         const int anc = i % 3;
         const int cell = i / 3;
         const int gy = cell / a.gw, gx = cell - gy * a.gw;
         const float* f = a.fm + ((size_t)n * cells + i) * F;
         const float* yt = a.y_true + ((size_t)n * cells + i) * T;
         float* g = a.grad + ((size_t)n * (cells / 3) + cell) * a.grad_stride + anc * F;
-        // reorg_layer (model.py:96-126)
+        // every lane decodes the box (same addresses: broadcast loads) — reorg_layer (model.py:96-126)
         const float sx = sigmoid_(f[0]), sy = sigmoid_(f[1]);
         const float ex = expf(f[2]), ey = expf(f[3]);
         const float px = (sx + (float)gx) * a.ratio_w, py = (sy + (float)gy) * a.ratio_h;
         const float pw = (ex * a.ra_w[anc]) * a.ratio_w, ph = (ey * a.ra_h[anc]) * a.ratio_h;
         // ignore mask (model.py:220-237): best IoU with this image's GT boxes of THIS scale < 0.5
         float best = -INFINITY;
-        for (int v = 0; v < V; ++v) {
+        for (int v = lane; v < V; v += 64) {
             const float tx = gts[4 * v], ty = gts[4 * v + 1], tw = gts[4 * v + 2], th = gts[4 * v + 3];
             const float iw = fmaxf(fminf(px + pw / 2.f, tx + tw / 2.f) - fmaxf(px - pw / 2.f, tx - tw / 2.f), 0.f);
             const float ih = fmaxf(fminf(py + ph / 2.f, ty + th / 2.f) - fmaxf(py - ph / 2.f, ty - th / 2.f), 0.f);
             const float inter = iw * ih;
             best = fmaxf(best, inter / (pw * ph + tw * th - inter + 1e-10f));
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
         const float ignore = best < 0.5f ? 1.f : 0.f;
         const float m = yt[4];                       // object_mask
         const float mixw = yt[T - 1];
-        const float bls = 2.f - (yt[2] / a.img_w) * (yt[3] / a.img_h);
-        const float wgt = m * bls * mixw;
-        // xy (model.py:248-249,276)
-        const float txy0 = yt[0] / a.ratio_w - (float)gx, txy1 = yt[1] / a.ratio_h - (float)gy;
-        const float pxy0 = px / a.ratio_w - (float)gx, pxy1 = py / a.ratio_h - (float)gy;
-        const float d0 = txy0 - pxy0, d1 = txy1 - pxy1;
-        l_xy = (d0 * d0 + d1 * d1) * wgt;
-        g[0] = -2.f * d0 * wgt * sx * (1.f - sx) * invN;
-        g[1] = -2.f * d1 * wgt * sy * (1.f - sy) * invN;
-        // wh (model.py:254-262,277)
-        float tt0 = yt[2] / a.anc_w[anc], tt1 = yt[3] / a.anc_h[anc];
-        float pt0 = pw / a.anc_w[anc], pt1 = ph / a.anc_h[anc];
-        tt0 = tt0 == 0.f ? 1.f : tt0; tt1 = tt1 == 0.f ? 1.f : tt1;
-        const bool pz0 = pt0 == 0.f, pz1 = pt1 == 0.f;
-        pt0 = pz0 ? 1.f : pt0; pt1 = pz1 ? 1.f : pt1;
-        const bool in0 = !pz0 && pt0 >= 1e-9f && pt0 <= 1e9f, in1 = !pz1 && pt1 >= 1e-9f && pt1 <= 1e9f;
-        const float e0 = logf(fminf(fmaxf(tt0, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt0, 1e-9f), 1e9f));
-        const float e1 = logf(fminf(fmaxf(tt1, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt1, 1e-9f), 1e9f));
-        l_wh = (e0 * e0 + e1 * e1) * wgt;
-        g[2] = in0 ? -2.f * e0 * wgt * invN : 0.f;   // d log(exp(t)*const)/dt = 1 inside the clip range
-        g[3] = in1 ? -2.f * e1 * wgt * invN : 0.f;
-        // conf (model.py:280-292)
-        const float xc = f[4];
-        const float pc = sigmoid_(xc);
-        const float cmask = m + (1.f - m) * ignore;
-        const float b = bce_(m, xc);
-        float lc = cmask * b;
-        float gc = cmask * (pc - m);
-        if (a.focal) {
-            const float dm = m - pc;
-            const float fo = dm * dm;                                   // alpha=1, gamma=2
-            gc = cmask * ((pc - m) * fo + b * (-2.f * dm * pc * (1.f - pc)));
-            lc *= fo;
+        if (lane == 0) {
+            const float bls = 2.f - (yt[2] / a.img_w) * (yt[3] / a.img_h);
+            const float wgt = m * bls * mixw;
+            // xy (model.py:248-249,276)
+            const float txy0 = yt[0] / a.ratio_w - (float)gx, txy1 = yt[1] / a.ratio_h - (float)gy;
+            const float pxy0 = px / a.ratio_w - (float)gx, pxy1 = py / a.ratio_h - (float)gy;
+            const float d0 = txy0 - pxy0, d1 = txy1 - pxy1;
+            l_xy += (d0 * d0 + d1 * d1) * wgt;
+            g[0] = -2.f * d0 * wgt * sx * (1.f - sx) * invN;
+            g[1] = -2.f * d1 * wgt * sy * (1.f - sy) * invN;
+            // wh (model.py:254-262,277)
+            float tt0 = yt[2] / a.anc_w[anc], tt1 = yt[3] / a.anc_h[anc];
+            float pt0 = pw / a.anc_w[anc], pt1 = ph / a.anc_h[anc];
+            tt0 = tt0 == 0.f ? 1.f : tt0; tt1 = tt1 == 0.f ? 1.f : tt1;
+            const bool pz0 = pt0 == 0.f, pz1 = pt1 == 0.f;
+            pt0 = pz0 ? 1.f : pt0; pt1 = pz1 ? 1.f : pt1;
+            const bool in0 = !pz0 && pt0 >= 1e-9f && pt0 <= 1e9f, in1 = !pz1 && pt1 >= 1e-9f && pt1 <= 1e9f;
+            const float e0 = logf(fminf(fmaxf(tt0, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt0, 1e-9f), 1e9f));
+            const float e1 = logf(fminf(fmaxf(tt1, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt1, 1e-9f), 1e9f));
+            l_wh += (e0 * e0 + e1 * e1) * wgt;
+            g[2] = in0 ? -2.f * e0 * wgt * invN : 0.f;   // d log(exp(t)*const)/dt = 1 inside the clip range
+            g[3] = in1 ? -2.f * e1 * wgt * invN : 0.f;
+            // conf (model.py:280-292)
+            const float xc = f[4];
+            const float pc = sigmoid_(xc);
+            const float cmask = m + (1.f - m) * ignore;
+            const float b = bce_(m, xc);
+            float lc = cmask * b;
+            float gc = cmask * (pc - m);
+            if (a.focal) {
+                const float dm = m - pc;
+                const float fo = dm * dm;                                   // alpha=1, gamma=2
+                gc = cmask * ((pc - m) * fo + b * (-2.f * dm * pc * (1.f - pc)));
+                lc *= fo;
+            }
+            l_conf += lc * mixw;
+            g[4] = gc * mixw * invN;
         }
-        l_conf = lc * mixw;
-        g[4] = gc * mixw * invN;
-        // class (model.py:296-302)
+        // class (model.py:296-302): lanes over the classes
         const float delta = 0.01f;
-        for (int c = 0; c < a.C; ++c) {
+        for (int c = lane; c < a.C; c += 64) {
             float tgt = yt[5 + c];
             if (a.label_smooth) tgt = (1.f - delta) * tgt + delta * 1.f / (float)a.C;
             const float x = f[5 + c];
@@ -363,14 +370,14 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
             g[5 + c] = m * mixw * (sigmoid_(x) - tgt) * invN;
         }
     }
-    // workgroup reduction in a fixed order
+    // wave reduction, then the four waves, in a fixed order
     float vals[4] = {l_xy, l_wh, l_conf, l_cls};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float v = vals[q];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+        if (lane == 0) red[wave][q] = v;
     }
     __syncthreads();
     if (threadIdx.x < 4) {
@@ -681,7 +688,7 @@ extern "C" int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float*
     a.N = n; a.gh = gh; a.gw = gw; a.C = class_num;
     const int cells = gh * gw * 3;
     a.cap = cells;
-    const int blocks = (cells + 255) / 256;
+    const int blocks = (cells + 255) / 256;   // also the loss kernel's grid.x: each workgroup walks its records
     char* p = static_cast<char*>(scratch);
     a.gt_boxes = reinterpret_cast<float*>(p); p += (((size_t)n * cells * 4 * sizeof(float)) + 255) & ~(size_t)255;
     a.gt_count = reinterpret_cast<int*>(p);   p += (((size_t)n * sizeof(int)) + 255) & ~(size_t)255;

@@ -146,17 +146,34 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
         }
     };
 
+    // Same MFMA-shadow interleave as the forward conv (y3_conv.hip): global loads behind the first MFMAs, one
+    // fragment read per MFMA, LDS writes behind the last ones.
+    auto pipeline_hint = [&]() {
+        constexpr int NM = MI * NI * (WBK / 2);          // MFMAs per K-step
+        constexpr int NR = (MI + NI) * (WBK / 2);        // ds_read_b32 per K-step
+        constexpr int NV = 4 + BPASS;                    // buffer loads per K-step
+        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (i < NR - (MI + NI)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i >= NM - NV) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+    };
+
     if (T > 0) {
         load_tile(0);
         store_tile(0);
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            const bool more = t + 1 < T;
-            if (more) load_tile(t + 1);
+        for (int t = 0; t + 1 < T; ++t) {
+            load_tile(t + 1);
             compute_tile(t & 1);
-            if (more) store_tile((t + 1) & 1);
+            store_tile((t + 1) & 1);
+            pipeline_hint();
             __syncthreads();
         }
+        compute_tile((T - 1) & 1);
     }
 
     // D layout: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (j)
@@ -186,32 +203,70 @@ __global__ void __launch_bounds__(256) wgrad_sum_splits_kernel(const float* __re
     }
 }
 
-// Stem conv (Cin = 3): D[27][COUT] over all pixels.  Workgroup = a chunk of pixels; thread t owns output
-// row j = t / (COUT/4) and a float4 of output channels.
-template <int COUT>
+// Stem conv (Cin = 3): D[27][32] = sum over pixels of patch[m][27] * dz[m][32].  One 32x32 MFMA tile
+// (patch rows padded 27 -> 32 with zeros); a workgroup walks its chunk of pixels 128 at a time: the dz rows
+// and the gathered 3x3x3 patches are staged in LDS, each wave accumulates a quarter of the tile's pixels,
+// the four wave accumulators are summed through LDS at the end.
 __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                          int N, int H, int W, int M, int chunk,
-                                                         float* __restrict__ partial /*[grid][27][COUT]*/) {
-    constexpr int Q = COUT / 4;
-    const int jrow = threadIdx.x / Q, c4 = (threadIdx.x % Q) * 4;
-    const bool act = jrow < 27;
-    const int tap = jrow / 3, ci = jrow - tap * 3;
+                                                         float* __restrict__ partial /*[grid][27][32]*/) {
+    constexpr int TP = 128;
+    __shared__ __attribute__((aligned(16))) float xs[TP * 32];
+    __shared__ __attribute__((aligned(16))) float zs[TP * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = tid & 31;                   // patch column owned while staging
+    const int tap = j / 3, ci = j - tap * 3;
     const int ky = tap / 3, kx = tap - ky * 3;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const int m0 = blockIdx.x * chunk, m1 = min(m0 + chunk, M);
-    if (act) {
-        for (int m = m0; m < m1; ++m) {
-            const int n = m / (H * W);
-            const int rem = m - n * H * W;
-            const int oy = rem / W, ox = rem - oy * W;
-            const int iy = oy - 1 + ky, ix = ox - 1 + kx;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                const float xv = x[((size_t)(n * H + iy) * W + ix) * 3 + ci];
-                s += xv * *reinterpret_cast<const f32x4*>(dz + (size_t)m * COUT + c4);
+    const int pr0 = tid >> 5;                 // staging rows pr0 + 8*i
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int m_begin = blockIdx.x * chunk, m_end = min(m_begin + chunk, M);
+    for (int m0 = m_begin; m0 < m_end; m0 += TP) {
+        // dz rows: 128 x 32 floats, coalesced float4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;              // float4 index inside the tile
+            const int p = e >> 3, c4 = (e & 7) * 4;
+            const int m = m0 + p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) v = *reinterpret_cast<const f32x4*>(dz + (size_t)m * 32 + c4);
+            *reinterpret_cast<f32x4*>(zs + p * 32 + c4) = v;
+        }
+        // patches: thread owns column j and rows pr0 + 8*i (coordinates advanced incrementally)
+        {
+            int m = m0 + pr0;
+            int n = m / (H * W);
+            int rem = m - n * H * W;
+            int oy = rem / W, ox = rem - oy * W;
+#pragma unroll 4
+            for (int i = 0; i < TP / 8; ++i) {
+                float v = 0.f;
+                const int iy = oy - 1 + ky, ix = ox - 1 + kx;
+                if (j < 27 && m < m_end && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    v = x[((size_t)(n * H + iy) * W + ix) * 3 + ci];
+                xs[(pr0 + 8 * i) * 32 + j] = v;
+                m += 8; ox += 8;
+                if (ox >= W) { ox -= W; if (++oy == H) { oy = 0; ++n; } }
             }
         }
-        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 27 + jrow) * COUT + c4) = s;
+        __syncthreads();
+        // wave w: pixels [32w, 32w+32) -> 16 MFMAs of k = 2 pixels
+        const float* as = xs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
+        const float* bs = zs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s2 * 64], bs[s2 * 64], acc, 0, 0, 0);
+        __syncthreads();
     }
+    // sum the four waves: D layout col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (j)
+    float* red = xs;                              // [4][32][32] needs 16 KB: xs (16 KB) is free now
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 27 * 32; e += 256)
+        partial[(size_t)blockIdx.x * 27 * 32 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
 }
 
 }  // namespace
@@ -258,11 +313,12 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && dz_stride == 32,
                      "y3_conv_wgrad: Cin=3 is supported only as the 3x3 3->32 stem conv");
-        int nblk = (int)((M + 2047) / 2048);
-        if (nblk > 4096) nblk = 4096;
-        const int chunk = (int)((M + nblk - 1) / nblk);
+        int nblk = (int)((M + 4095) / 4096);
+        if (nblk > 2048) nblk = 2048;
+        const int chunk = (int)(((M + nblk - 1) / nblk + 127) / 128 * 128);   // multiple of the 128-pixel tile
+        nblk = (int)((M + chunk - 1) / chunk);
         float* part = static_cast<float*>(scratch);
-        hipLaunchKernelGGL(stem_wgrad_kernel<32>, dim3(nblk), dim3(256), 0, st, x, dz, d->n, d->h, d->w, (int)M,
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dz, d->n, d->h, d->w, (int)M,
                            chunk, part);
         Y3_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3(4), dim3(256), 0, st, part, nblk, (long long)27 * 32, dw_hwio);
