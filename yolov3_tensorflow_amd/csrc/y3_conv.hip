@@ -69,7 +69,7 @@ struct Geo {
 
 // ---- epilogue shared by the conv kernel and the stream-K fix-up kernel ------------------------------
 // D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool TMODE>
 __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                                          f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI],
                                          int m0, int n0) {
@@ -79,7 +79,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     // output pixel of GEMM row `row`: the row itself, or (tmode) pixel (2y'+cy, 2x'+cx) of the 2x finer grid
     auto out_pixel = [&](int row) -> size_t {
-        if (!p.tmode) return (size_t)row;
+        if (!TMODE) return (size_t)row;
         const int hw = p.H * p.W;
         const int n = row / hw;
         const int rem = row - n * hw;
@@ -176,7 +176,9 @@ __device__ __forceinline__ int sk_worker_id(int b, int workers) {
     return (workers & 7) == 0 ? (b & 7) * (workers >> 3) + (b >> 3) : b;
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK>
+// TMODE (compile time, so that the forward instantiations carry none of its state): data gradient of a stride-2
+// conv, one output parity class per launch (see ConvArgs::tmode)
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, bool TMODE>
 __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     constexpr int MI = G::MI, NI = G::NI, WTM = G::WTM, WTN = G::WTN;
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
     const int nbn = (p.Cout + BN - 1) / BN;
     const int nbm = (p.M + BM - 1) / BM;
     const int kchunks = p.Cin / BK;
-    const int taps = p.tmode ? p.ntaps : KS * KS;
+    const int taps = TMODE ? p.ntaps : KS * KS;
     const int S = taps * kchunks;  // K-steps per output tile
 
     // ---- this workgroup's range of work items (item = tile * S + kstep) ----------------------------
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
     int ld_wtap = 0;   // index of the weight tap plane of the prepared K-step
     auto set_tap = [&]() {
         int ky, kx, dy, dx;
-        if (p.tmode) {
+        if (TMODE) {
             const int nkx = p.cx ? 2 : 1;
             const int ty = ld_tap / nkx, tx = ld_tap - ty * nkx;
             ky = p.cy ? 2 * ty : 1;
@@ -277,8 +279,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         const int bn = tile / nbm, bm = tile - bn * nbm;
         ld_tap = ks / kchunks;
         ld_cc = ks - ld_tap * kchunks;
-        const int HoWo = p.tmode ? p.H * p.W : p.Ho * p.Wo;
-        const int Wrow = p.tmode ? p.W : p.Wo;
+        const int HoWo = TMODE ? p.H * p.W : p.Ho * p.Wo;
+        const int Wrow = TMODE ? p.W : p.Wo;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int m = bm * BM + r0 + 32 * j;
@@ -289,8 +291,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
                 const int oy = rem / Wrow;
                 const int ox = rem - oy * Wrow;
                 // first source pixel of the row (tmode: (y', x'); else (oy*stride - pad, ox*stride - pad))
-                const int iy0 = p.tmode ? oy : oy * p.stride - p.pad;
-                const int ix0 = p.tmode ? ox : ox * p.stride - p.pad;
+                const int iy0 = TMODE ? oy : oy * p.stride - p.pad;
+                const int ix0 = TMODE ? ox : ox * p.stride - p.pad;
 #pragma unroll
                 for (int t = 0; t < KS; ++t) {
                     if ((unsigned)(iy0 + t) < (unsigned)p.H) mk |= 1 << t;
@@ -450,7 +452,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         __syncthreads();
 
         if (!STREAMK || (ks == 0 && seg_end == tile_end)) {
-            epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0);
+            epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, m0, n0);
         } else {
             // partial tile: raw accumulators to this worker's slot (0 = its first tile, 1 = its last)
             float* slot = p.partial + ((size_t)worker * 2 + (tile == (int)first_tile ? 0 : 1)) * (BM * BN);
@@ -472,12 +474,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
 
 // Stream-K fix-up: one workgroup per output tile; tiles computed whole by one worker exit at once, split
 // tiles sum their partials in worker (= K) order and run the common epilogue.
-template <int BM, int BN, int WGM, int WGN, int KS>
+template <int BM, int BN, int WGM, int WGN, int KS, bool TMODE>
 __global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nbn = (p.Cout + BN - 1) / BN;
-    const int S = (p.tmode ? p.ntaps : KS * KS) * (p.Cin / BK);
+    const int S = (TMODE ? p.ntaps : KS * KS) * (p.Cin / BK);
     const long long items = (long long)((p.M + BM - 1) / BM) * nbn * S;
     const int tile = blockIdx.x;
     const long long t0 = (long long)tile * S, t1 = t0 + S;
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvAr
     }
     const int nbm = (p.M + BM - 1) / BM;
     const int bn = tile / nbm, bm = tile - bn * nbm;
-    epilogue<BM, BN, WGM, WGN>(p, smem, acc, bm * BM, bn * BN);
+    epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, bm * BM, bn * BN);
 }
 
 // ---- stem conv: 3x3, Cin = 3 -> COUT (=32), stride 1 ------------------------------------------------
@@ -580,10 +582,10 @@ int set_lds_attr(K kern, size_t lds) {
     return Y3_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = false>
 int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     using G = Geo<BM, BN, WGM, WGN>;
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, TMODE>;
     static bool attr_set = false;  // per instantiation; benign race (idempotent)
     if (!attr_set) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
@@ -596,12 +598,12 @@ int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     return Y3_OK;
 }
 
-template <int KS>
+template <int KS, bool TMODE = false>
 int launch_streamk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true>;
-    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true, TMODE>;
+    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS, TMODE>;
     static bool attr_set = false;
     if (!attr_set) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
@@ -617,11 +619,11 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) 
     return Y3_OK;
 }
 
-template <int KS, bool UPCAT>
+template <int KS, bool UPCAT, bool TMODE = false>
 int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
-    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT>(stream, a);
-    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT>(stream, a);
-    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT>(stream, a);
+    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT, TMODE>(stream, a);
+    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT, TMODE>(stream, a);
+    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT, TMODE>(stream, a);
 }
 
 constexpr int SK_WORKERS = 512;  // 256 CUs x 2 co-resident 128x128 workgroups (73.7 KB LDS, 176 VGPRs)
@@ -754,9 +756,9 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
             if (use_streamk(a, 3, has_ws)) {
                 a.partial = static_cast<float*>(workspace);
                 a.workers = SK_WORKERS;
-                rc = launch_streamk<3>(stream, a, nullptr);
+                rc = launch_streamk<3, true>(stream, a, nullptr);
             } else {
-                rc = dispatch_bn<3, false>(stream, a);
+                rc = dispatch_bn<3, false, true>(stream, a);
             }
             if (rc != Y3_OK) return rc;
         }
