@@ -145,7 +145,13 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
+                    help="c2 (default, the BASELINE metric): fp32 416x416 bs=32; c5: bf16-storage 608x608 bs=16")
     args = ap.parse_args()
+    global BATCH, SIZE
+    bf16 = args.workload == 'c5'
+    if bf16:
+        BATCH, SIZE = 16, 608
 
     import torch
     import torch.distributed as dist
@@ -174,6 +180,8 @@ def main():
         torch.cuda.synchronize()
 
     model = y3.yolov3(CLASS_NUM, ANCHORS)
+    if bf16:
+        model.compute_dtype = 'bf16'
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda',
                    generator=torch.Generator(device='cuda').manual_seed(100 + rank))
     with y3.variable_scope('yolov3'):
@@ -210,13 +218,17 @@ def main():
         value = world * BATCH * args.steps / elapsed
         flops = conv_flops(table, BATCH, SIZE, SIZE)
         is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
+        if bf16:   # dominant family: the 3x3 convs on 128x128 tiles (conv_mfma_bf16_kernel<128,128,2,2,3,false>)
+            is_sk = np.array([k == 3 and cin != 3 and cout > 64 for (k, s, cin, cout, bn) in table])
         dom_ms = float(main_ms[is_sk].sum())          # the stream-K kernel alone (fix-up excluded)
         dom_flops = float(flops[is_sk].sum())
         n_dom = int(is_sk.sum())
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS
         whole = float(flops.sum()) / (float(layer_ms.sum()) * 1e-3) / 1e12
         out = {
-            "metric": "images/sec at 416x416 bs=32 (Darknet-53 + 3-scale head forward)",
+            "metric": ("images/sec at 608x608 bs=16 bf16 (Darknet-53 + 3-scale head forward)" if bf16 else
+                       "images/sec at 416x416 bs=32 (Darknet-53 + 3-scale head forward)"),
             "value": round(value, 2),
             "unit": "images/s",
             "n_gpus": world,
@@ -227,17 +239,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16" if bf16 else "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: Darknet-53 + 3-scale head forward, random weights, "
-                                   "416x416 bs=32 fp32 per GPU, input resident in HBM",
+            "config": {"workload": ("configs[4]: Darknet-53 + 3-scale head forward, random weights, 608x608 bs=16 "
+                                    "per GPU, bf16 storage / fp32 accumulate, input resident in HBM" if bf16 else
+                                    "configs[1]: Darknet-53 + 3-scale head forward, random weights, "
+                                    "416x416 bs=32 fp32 per GPU, input resident in HBM"),
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE,
                        "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": traffic_from_profile(),
-                         "kernel": "conv_mfma_f32_kernel<128,128,2,2,3,false,true> (3x3 implicit-GEMM conv, "
-                                   "stream-K schedule)",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": None if bf16 else traffic_from_profile(),
+                         "kernel": ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; "
+                                    "staging-bound, see DESIGN.md)" if bf16 else
+                                    "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, "
+                                    "stream-K schedule)"),
                          "launches_per_step": n_dom,
                          "avg_launch_ms": round(dom_ms / n_dom, 4),
                          "algorithmic_gflop_per_launch": round(dom_flops / n_dom / 1e9, 3),
@@ -246,7 +262,10 @@ def main():
                          "whole_forward_tflops": round(whole, 2),
                          "sum_layer_ms": round(float(layer_ms.sum()), 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if bf16:
+            # algorithmic HBM traffic of the whole bf16 forward: 6.565 GB per bs=16 batch at 608
+            out["roofline"]["whole_forward_hbm_tbps"] = round(6.565e9 / (ms_per_step * 1e-3) / 1e12, 3)
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(y3.global_variables(scope='yolov3'))
         print(json.dumps(out), flush=True)
     if distributed:

@@ -89,6 +89,15 @@ int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const floa
                   const float* w, const float* scale, const float* shift, const float* residual,
                   float* y, void* workspace, size_t workspace_bytes);
 
+/* ---- bf16 storage / fp32 accumulate variant (BASELINE configs[4]: 608x608 bf16 inference) -----------------
+ * Same contract as y3_conv2d_fwd with bf16 (round-to-nearest-even) activations, residual and packed weights
+ * ([k*k][cout][cin] bf16 from y3_pack_conv_weights_bf16); scale/shift stay fp32; the accumulator is fp32.
+ * out_f32 != 0 writes fp32 (used for the detection convs so that decode/NMS are unchanged).  The Cin==3 stem
+ * takes the fp32 image and the fp32 HWIO kernel and writes bf16. */
+int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, void* w_packed);
+int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
+                       const float* scale, const float* shift, const void* residual, void* y, int out_f32);
+
 /* ---- unfused graph ops, for callers composing the network op by op (utils/layer_utils.py) ---------
  * y3_net_forward never launches these (it fuses them into the neighbouring convs).
  * y3_upsample_nearest : tf.image.resize_nearest_neighbor, align_corners=False (utils/layer_utils.py:82-87)
@@ -138,6 +147,9 @@ int y3_nms(y3_ctx* ctx, int mode, const float* boxes, const float* scores, int n
  * Per layer the caller registers device pointers: packed weights (HWIO for layer 0), scale, shift. */
 int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out);
 int y3_net_destroy(y3_net* net);
+/* 0 = fp32 (default), 1 = bf16 storage: layer parameters must then be bf16-packed (fp32 HWIO for layer 0),
+ * intermediate activations are bf16, the three feature maps stay fp32. */
+int y3_net_set_dtype(y3_net* net, int dtype);
 int y3_net_num_layers(const y3_net* net);
 /* geometry of layer i for input-independent fields: k, stride, cin, cout, has_bn */
 int y3_net_layer_info(const y3_net* net, int i, int* k, int* stride, int* cin, int* cout, int* has_bn);

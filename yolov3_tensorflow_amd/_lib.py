@@ -28,6 +28,10 @@ PROTOTYPES = {
     "y3_conv_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv2d_fwd": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_size_t]),
+    "y3_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "y3_conv2d_fwd_bf16": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_int]),
+    "y3_net_set_dtype": (c_int, [c_void_p, c_int]),
     "y3_upsample_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong, c_void_p]),
     "y3_add": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),

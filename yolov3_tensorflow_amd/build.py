@@ -17,6 +17,7 @@ LIB = os.path.join(CSRC, "libyolo355.so")
 SOURCES = [
     ("y3_abi.hip", []),
     ("y3_conv.hip", []),
+    ("y3_conv_bf16.hip", []),
     ("y3_decode.hip", ["-ffp-contract=off"]),
     ("y3_nms.hip", ["-ffp-contract=off"]),
     ("y3_ops.hip", ["-ffp-contract=off"]),

@@ -79,6 +79,7 @@ struct Layer {
 struct y3_net {
     y3_ctx* ctx;
     int class_num;
+    int dtype = 0;            // 0: fp32 activations/weights, 1: bf16 storage with fp32 accumulation
     std::vector<Tensor> tensors;
     std::vector<Layer> layers;
     // cached plan
@@ -162,7 +163,8 @@ struct y3_net {
 
     size_t tensor_bytes(int id, int n, int h, int w) const {
         const Tensor& t = tensors[id];
-        return (size_t)n * (h / t.sdiv) * (w / t.sdiv) * t.c * sizeof(float);
+        const size_t esize = (dtype == 1 && t.ext < 0 && id != 0) ? 2 : sizeof(float);
+        return (size_t)n * (h / t.sdiv) * (w / t.sdiv) * t.c * esize;
     }
 
     // Liveness-based arena: a tensor's bytes are recycled after its last reader has been launched
@@ -223,6 +225,7 @@ struct y3_net {
         arena_bytes = (peak + 255) & ~(size_t)255;
         scratch_bytes = 0;
         for (const Layer& l : layers) {
+            if (dtype == 1) break;   // the bf16 kernels use no stream-K scratch
             y3_conv_desc d;
             d.n = n; d.h = h / tensors[l.src].sdiv; d.w = w / tensors[l.src].sdiv;
             d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
@@ -242,6 +245,14 @@ extern "C" int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out) {
     net->class_num = class_num;
     net->build();
     *out = net;
+    return Y3_OK;
+}
+
+extern "C" int y3_net_set_dtype(y3_net* net, int dtype) {
+    Y3_CHECK_ARG(net, "y3_net_set_dtype: null net");
+    Y3_CHECK_ARG(dtype == 0 || dtype == 1, "y3_net_set_dtype: dtype must be 0 (fp32) or 1 (bf16)");
+    net->dtype = dtype;
+    net->pn = net->ph = net->pw = 0;   // re-plan
     return Y3_OK;
 }
 
@@ -358,9 +369,12 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         // the mid event is recorded only by two-kernel (stream-K) layers; pre-record it so that it is
         // always valid, a later record by the launcher supersedes it
         if (ev) Y3_CHECK_HIP(hipEventRecord(ev[nl + 1 + i], st));
-        const int rc = y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
-                                      ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
-                                      ev ? ev[nl + 1 + i] : nullptr);
+        const int rc = net->dtype == 1
+            ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
+                                  net->tensors[l.dst].ext >= 0 ? 1 : 0)
+            : y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
+                             ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
+                             ev ? ev[nl + 1 + i] : nullptr);
         if (rc != Y3_OK) return rc;
         if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
     }
@@ -368,7 +382,7 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
 }
 
 extern "C" int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w) {
-    if (!net || i < 0 || i >= (int)net->layers.size() || n <= 0 || h <= 0 || w <= 0) return 0;
+    if (!net || i < 0 || i >= (int)net->layers.size() || n <= 0 || h <= 0 || w <= 0 || net->dtype == 1) return 0;
     const Layer& l = net->layers[i];
     const Tensor& in = net->tensors[l.src];
     y3_conv_desc d;

@@ -42,3 +42,5 @@ int y3_conv_schedule_impl(const y3_conv_desc* d);
 int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                          const float* w_d, const float* ones, const float* zeros, int accumulate, float* dx,
                          void* workspace, size_t workspace_bytes);
+int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
+                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);

@@ -12,6 +12,22 @@ BN_EPS = 1e-5  # model.py:37
 _param_cache = {}  # weights op_name -> (version key, w_dev, scale, shift)
 
 
+def prepare_conv_params_bf16(w_var, bn_vars=None, bias_var=None):
+    """As prepare_conv_params, with the kernel packed to bf16 (the 3->32 stem keeps its fp32 HWIO kernel)."""
+    w32, scale, shift = prepare_conv_params(w_var, bn_vars=bn_vars, bias_var=bias_var)
+    k, _, cin, cout = w_var.shape
+    if cin == 3:
+        return w32, scale, shift
+    key = w_var.op_name + '#bf16'
+    hit = _param_cache.get(key)
+    if hit is not None and hit[0] == w_var.version:
+        return hit[1], scale, shift
+    wb = torch.empty(k * k * cout * cin, dtype=torch.bfloat16, device=w_var.tensor.device)
+    _lib.check(_lib.lib().y3_pack_conv_weights_bf16(fw.context(), fw.ptr(w_var.tensor), k, cin, cout, fw.ptr(wb)))
+    _param_cache[key] = (w_var.version, wb)
+    return wb, scale, shift
+
+
 def prepare_conv_params(w_var, bn_vars=None, bias_var=None):
     """Return (w_packed, scale, shift) device tensors for one conv layer.
 

@@ -31,8 +31,11 @@ class yolov3(object):
         self.use_focal_loss = use_focal_loss
         self.weight_decay = weight_decay
         self.use_static_shape = use_static_shape
-        self._nets = {}   # (ctx key, scope) -> dict(handle, version, keepalive, workspace)
+        self._nets = {}   # (ctx key, scope, dtype) -> dict(handle, version, keepalive, workspace)
         self.img_size = None
+        # 'f32' (the reference's precision) or 'bf16' (bf16 storage, fp32 accumulation; BASELINE configs[4]);
+        # an attribute rather than a constructor argument so that the reference's signature is unchanged
+        self.compute_dtype = 'f32'
 
     # ------------------------------------------------------------------------------------------
     # variables
@@ -68,14 +71,19 @@ class yolov3(object):
         return layers
 
     def _get_net(self, device):
+        if self.compute_dtype not in ('f32', 'bf16'):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        bf16 = self.compute_dtype == 'bf16'
         ctx = fw.context(device)
         scope = fw.current_scope_name()
-        key = (ctx.value, scope)
+        key = (ctx.value, scope, self.compute_dtype)
         ent = self._nets.get(key)
         L = _lib.lib()
         if ent is None:
             h = ctypes.c_void_p()
             _lib.check(L.y3_net_create(ctx, int(self.class_num), ctypes.byref(h)))
+            if bf16:
+                _lib.check(L.y3_net_set_dtype(h, 1))
             table = self._layer_table(h)
             ent = dict(handle=h, table=table, version=-1, keep=None, ws=None, ws_bytes=0,
                        layers=self._ensure_variables(scope, table))
@@ -83,7 +91,8 @@ class yolov3(object):
         if ent['version'] != fw.global_version():
             keep = []
             for i, (w, bnv, bias) in enumerate(ent['layers']):
-                wp, sc, sh = engine.prepare_conv_params(w, bn_vars=bnv, bias_var=bias)
+                prep = engine.prepare_conv_params_bf16 if bf16 else engine.prepare_conv_params
+                wp, sc, sh = prep(w, bn_vars=bnv, bias_var=bias)
                 _lib.check(L.y3_net_set_layer(ent['handle'], i, fw.ptr(wp), fw.ptr(sc), fw.ptr(sh)))
                 keep.append((wp, sc, sh))
             ent['keep'] = keep   # the library holds raw pointers: keep the tensors alive
