@@ -168,7 +168,7 @@ def main():
             sys.exit(2)
     torch.cuda.set_device(local_rank)
     y3.set_default_device('cuda:%d' % local_rank)
-    distributed = world > 1
+    distributed = world > 1 or 'RANK' in os.environ      # under torch.distributed.run even at N=1
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', rank=rank, world_size=world,
