@@ -21,7 +21,6 @@ inline int grid_for(long long work, int cap = 256 * 16) {
 // ---- column reductions over an [M][C] matrix -----------------------------------------------------
 // MODE 0: (sum z, sum z^2)                                       -> BN forward statistics
 // MODE 1: (sum g', sum g'*zhat), g' = dy * leaky'(z*scale+shift) -> BN backward (d beta, d gamma)
-// MODE 2: (sum dy, 0)                                            -> bias gradient
 // Workgroup b handles rows b, b+gridDim, ...; thread t owns float4 column (t % C4) and row lane t / C4.
 template <int MODE>
 __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict__ z, const float* __restrict__ dy,
@@ -53,7 +52,7 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict
                     const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * C + 4 * c4);
                     s0 += v;
                     s1 += v * v;
-                } else if (MODE == 1) {
+                } else {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * C + 4 * c4);
                     f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + 4 * c4);
 #pragma unroll
@@ -63,8 +62,6 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict
                     }
                     s0 += g;
                     s1 += g * ((v - mu) * is);
-                } else {
-                    s0 += *reinterpret_cast<const f32x4*>(dy + r * C + 4 * c4);
                 }
             }
         }
@@ -573,11 +570,8 @@ static int reduce_launch(y3_ctx* ctx, int mode, const float* z, const float* dy,
     if (mode == 0)
         hipLaunchKernelGGL(col_reduce_kernel<0>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
                            mean, inv_std, rows, c, scratch);
-    else if (mode == 1)
-        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
-                           mean, inv_std, rows, c, scratch);
     else
-        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
+        hipLaunchKernelGGL(col_reduce_kernel<1>, dim3((int)nb), dim3(256), lds, ctx->stream, z, dy, scale, shift,
                            mean, inv_std, rows, c, scratch);
     Y3_CHECK_HIP(hipGetLastError());
     *nblocks_out = (int)nb;

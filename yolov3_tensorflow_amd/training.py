@@ -138,7 +138,6 @@ def forward_train(model, x):
     n, h, w, _ = x.shape
     tens = {0: x}
     saved = []
-    det_pad = ((3 * (5 + model.class_num) + 31) // 32) * 32
     for i, l in enumerate(topo.layers):
         wvar, bnv, bias = layer_vars[i]
         xin = tens[l['src']]
@@ -170,7 +169,7 @@ def forward_train(model, x):
         saved.append(rec)
     fms = [tens[t] for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0]
     fms.sort(key=lambda f: f.shape[1])                          # ext slots 0,1,2 = 13-, 26-, 52-grid
-    st.update(saved=saved, tens=tens, layer_vars=layer_vars, fm_grads=None, det_pad=det_pad, batch=n)
+    st.update(saved=saved, tens=tens, layer_vars=layer_vars, fm_grads=None, batch=n)
     return fms[0], fms[1], fms[2]
 
 
