@@ -147,6 +147,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
                     help="c2 (default, the BASELINE metric): fp32 416x416 bs=32; c5: bf16-storage 608x608 bs=16")
+    ap.add_argument('--precision', choices=['f32', 'f32_bf16x6', 'f32_bf16x3'], default='f32',
+                    help="c2 only. f32: exact fp32 MFMA (default); f32_bf16x6 / f32_bf16x3: fp32 tensors, every "
+                         "product rebuilt from 6 / 3 bf16 plane products with fp32 accumulation")
     args = ap.parse_args()
     global BATCH, SIZE
     bf16 = args.workload == 'c5'
@@ -182,6 +185,9 @@ def main():
     model = y3.yolov3(CLASS_NUM, ANCHORS)
     if bf16:
         model.compute_dtype = 'bf16'
+    split = (not bf16) and args.precision != 'f32'
+    if split:
+        model.compute_dtype = args.precision
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda',
                    generator=torch.Generator(device='cuda').manual_seed(100 + rank))
     with y3.variable_scope('yolov3'):
@@ -224,7 +230,9 @@ def main():
         dom_flops = float(flops[is_sk].sum())
         n_dom = int(is_sk.sum())
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        peak = 2500.0 if bf16 else PEAK_FP32_MFMA_TFLOPS
+        # split precisions: fp32-equivalent peak = dense bf16 MFMA peak / products per fp32 multiply-add
+        peak = 2500.0 if bf16 else {'f32': PEAK_FP32_MFMA_TFLOPS, 'f32_bf16x6': 2500.0 / 6,
+                                    'f32_bf16x3': 2500.0 / 3}[args.precision]
         whole = float(flops.sum()) / (float(layer_ms.sum()) * 1e-3) / 1e12
         out = {
             "metric": ("images/sec at 608x608 bs=16 bf16 (Darknet-53 + 3-scale head forward)" if bf16 else
@@ -240,6 +248,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
+            "precision": ("bf16 storage, fp32 accumulate" if bf16 else
+                          {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                           "f32_bf16x6": "fp32 tensors; each product = 6 bf16 plane products, fp32 accumulate "
+                                         "(dropped terms <= 2^-23 relative)",
+                           "f32_bf16x3": "fp32 tensors; each product = 3 bf16 plane products, fp32 accumulate "
+                                         "(dropped terms <= 2^-15 relative)"}[args.precision]),
             "data": "synthetic",
             "config": {"workload": ("configs[4]: Darknet-53 + 3-scale head forward, random weights, 608x608 bs=16 "
                                     "per GPU, bf16 storage / fp32 accumulate, input resident in HBM" if bf16 else
@@ -249,9 +263,12 @@ def main():
                        "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None if bf16 else traffic_from_profile(),
+                         "traffic": None if (bf16 or split) else traffic_from_profile(),
                          "kernel": ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; "
                                     "staging-bound, see DESIGN.md)" if bf16 else
+                                    "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM "
+                                    "conv on the bf16 matrix pipe, stream-K schedule; peak = 2500/%d fp32-equivalent)"
+                                    % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3)) if split else
                                     "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, "
                                     "stream-K schedule)"),
                          "launches_per_step": n_dom,

@@ -98,6 +98,32 @@ int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, 
 int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 
+/* ---- fp32 on the bf16 matrix pipe ----------------------------------------------------------------------------
+ * Same contract and tensors as y3_conv2d_fwd (fp32 NHWC in, fp32 out, same epilogue, same workspace rule); every
+ * fp32 product a*b is rebuilt from bf16 plane products with fp32 accumulation: planes = 3 splits each operand
+ * exactly into three bf16 values and keeps the 6 products a_i*b_j, i+j <= 2 (dropped terms <= 2^-23 |ab|, i.e.
+ * fp32-level accuracy at 6/16 of the fp32-MFMA cost); planes = 2 keeps 3 products (<= 2^-15 |ab|).
+ * w_split = [k*k][cin/16][planes][cout][16] bf16 (cin % 16 == 0) from y3_pack_conv_weights_split (the Cin==3 stem takes the fp32 HWIO
+ * kernel and runs the exact kernel).  Replaces the same reference code as y3_conv2d_fwd
+ * (utils/layer_utils.py:9-22). */
+int y3_pack_conv_weights_split(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, int planes,
+                               void* w_split);
+int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int planes, const float* x, const float* x_up,
+                        const void* w_split, const float* scale, const float* shift, const float* residual,
+                        float* y, void* workspace, size_t workspace_bytes);
+
+/* Plane-tensor form of the same conv: an fp32 tensor of `count`
+ * elements is stored as `planes` bf16 planes, plane p starting p * count elements after the base pointer, whose
+ * fp32 sum is the value (exactly the original fp32 value for planes = 3).  The producer's epilogue splits every
+ * element once; the consumer's K loop then carries no split arithmetic.  x / x_up / residual are plane tensors, y is
+ * one too unless out_f32 != 0 (detection feature maps).  The Cin == 3 stem takes the fp32 image and the fp32 HWIO
+ * kernel and writes planes.  y3_split_planes / y3_merge_planes convert fp32 <-> planes (count % 4 == 0). */
+int y3_conv2d_fwd_planes(y3_ctx* ctx, const y3_conv_desc* d, int planes, const void* x, const void* x_up,
+                         const void* w_split, const float* scale, const float* shift, const void* residual,
+                         void* y, int out_f32, void* workspace, size_t workspace_bytes);
+int y3_split_planes(y3_ctx* ctx, const float* x, size_t count, int planes, void* out);
+int y3_merge_planes(y3_ctx* ctx, const void* in, size_t count, int planes, float* y);
+
 /* ---- unfused graph ops, for callers composing the network op by op (utils/layer_utils.py) ---------
  * y3_net_forward never launches these (it fuses them into the neighbouring convs).
  * y3_upsample_nearest : tf.image.resize_nearest_neighbor, align_corners=False (utils/layer_utils.py:82-87)
@@ -148,7 +174,8 @@ int y3_nms(y3_ctx* ctx, int mode, const float* boxes, const float* scores, int n
 int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out);
 int y3_net_destroy(y3_net* net);
 /* 0 = fp32 (default), 1 = bf16 storage: layer parameters must then be bf16-packed (fp32 HWIO for layer 0),
- * intermediate activations are bf16, the three feature maps stay fp32. */
+ * intermediate activations are bf16, the three feature maps stay fp32.  2 / 3 = fp32 tensors with the products on
+ * the bf16 matrix pipe (y3_conv2d_fwd_split with planes = 3 / 2): layer weights from y3_pack_conv_weights_split. */
 int y3_net_set_dtype(y3_net* net, int dtype);
 int y3_net_num_layers(const y3_net* net);
 /* geometry of layer i for input-independent fields: k, stride, cin, cout, has_bn */

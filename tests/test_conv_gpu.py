@@ -1,6 +1,8 @@
 """GPU parity: y3_conv2d_fwd (through the C ABI) against an fp64 torch-CPU convolution of the same op, on
 every distinct conv shape of the network at reduced spatial size, plus true-size cases.
-Tolerance (stated here, fp32 accumulate over K <= 4608): |d| <= 1e-4 + 1e-4*|ref|."""
+Tolerance (stated here, fp32 accumulate over K <= 4608): |d| <= 1e-4 + 1e-4*|ref|.
+The same cases run through y3_conv2d_fwd_split with planes = 3 (fp32 products rebuilt from 6 bf16 plane products)
+at the SAME tolerance, and with planes = 2 (3 products, dropped terms 2^-15) at 2e-3."""
 import numpy as np
 import pytest
 import torch
@@ -40,7 +42,13 @@ def ref_conv(x, w_hwio, scale, shift, k, stride, act, resid=None):
     return y.numpy()
 
 
-def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None):
+# 0: exact fp32 kernel; 3 / 2: y3_conv2d_fwd_split (fp32 tensors, split on the fly); -3 / -2: y3_conv2d_fwd_planes
+# (inputs, residual and output are 3 / 2 bf16 plane tensors; converted with y3_split_planes / y3_merge_planes)
+PLANES = [0, 3, 2, -3, -2]
+TOL = {0: 1e-4, 3: 1e-4, 2: 2e-3, -3: 1e-4, -2: 2e-3}
+
+
+def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None, planes=0):
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
     import ctypes
     dev = fw.default_device()
@@ -50,11 +58,30 @@ def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None):
     w = torch.from_numpy(w_hwio).to(dev)
     if cin_total == 3:
         wp = w
-    else:
+    elif planes > 0:
+        wp = torch.empty(planes * k * k * cout * cin_total, device=dev, dtype=torch.bfloat16)
+        _lib.check(L.y3_pack_conv_weights_split(fw.context(), fw.ptr(w), k, cin_total, cout, planes, fw.ptr(wp)))
+    elif planes == 0:
         wp = torch.empty(k * k * cout * cin_total, device=dev)
         _lib.check(L.y3_pack_conv_weights(fw.context(), fw.ptr(w), k, cin_total, cout, fw.ptr(wp)))
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
-    y = engine.conv2d_fwd(t(x), wp, t(scale), t(shift), k, stride, cout, act, residual=t(resid), x_up=t(x_up))
+    if planes < 0:
+        sp = lambda a: None if a is None else engine.split_planes(t(a), -planes)
+        if cin_total == 3:
+            xin, wp = t(x), w
+        else:
+            xin = sp(x)
+            wp = torch.empty(-planes * k * k * cout * cin_total, device=dev, dtype=torch.bfloat16)
+            _lib.check(L.y3_pack_conv_weights_split(fw.context(), fw.ptr(w), k, cin_total, cout, -planes, fw.ptr(wp)))
+        out_f32 = cout % 4 != 0
+        y = engine.conv2d_fwd_planes(xin, wp, t(scale), t(shift), k, stride, cout, act, residual=sp(resid),
+                                     x_up=sp(x_up), out_f32=out_f32, planes=-planes)
+        if not out_f32:
+            y = engine.merge_planes(y)
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+    y = engine.conv2d_fwd(t(x), wp, t(scale), t(shift), k, stride, cout, act, residual=t(resid), x_up=t(x_up),
+                          planes=planes)
     torch.cuda.synchronize()
     return y.cpu().numpy()
 
@@ -67,34 +94,36 @@ def make_case(rng, n, h, w, k, cin, cout):
     return x, wt, scale, shift
 
 
-def check(got, want, what):
+def check(got, want, what, planes=0):
     err = np.abs(got - want)
-    tol = 1e-4 + 1e-4 * np.abs(want)
+    tol = TOL[planes] * (1 + np.abs(want))
     assert got.shape == want.shape, what
     assert np.isfinite(got).all(), what
     assert (err <= tol).all(), '%s: max err %.3e (max |ref| %.2f)' % (what, err.max(), np.abs(want).max())
 
 
+@pytest.mark.parametrize('planes', PLANES)
 @pytest.mark.parametrize('k,stride,cin,cout,act,resid', DISTINCT)
-def test_distinct_shapes_reduced_spatial(k, stride, cin, cout, act, resid):
+def test_distinct_shapes_reduced_spatial(k, stride, cin, cout, act, resid, planes):
     rng = np.random.RandomState(hash((k, stride, cin, cout, resid)) % (2 ** 31))
     n, h, w = 3, 20, 28                       # M = 1680 or 420: ragged last tile, non-square map
     x, wt, scale, shift = make_case(rng, n, h, w, k, cin, cout)
     r = rng.standard_normal((n, h // stride, w // stride, cout)).astype(np.float32) if resid else None
-    got = run_gpu(x, wt, scale, shift, k, stride, act, r)
-    check(got, ref_conv(x, wt, scale, shift, k, stride, act, r), 'k%d s%d %d->%d' % (k, stride, cin, cout))
+    got = run_gpu(x, wt, scale, shift, k, stride, act, r, planes=planes)
+    check(got, ref_conv(x, wt, scale, shift, k, stride, act, r), 'k%d s%d %d->%d' % (k, stride, cin, cout), planes)
 
 
+@pytest.mark.parametrize('planes', PLANES)
 @pytest.mark.parametrize('c_up,c_route,cout', [(256, 512, 256), (128, 256, 128), (32, 32, 64)])
-def test_fused_upsample_concat_input(c_up, c_route, cout):
+def test_fused_upsample_concat_input(c_up, c_route, cout, planes):
     rng = np.random.RandomState(c_up)
     n, h, w = 2, 26, 26
     xu = rng.standard_normal((n, h // 2, w // 2, c_up)).astype(np.float32)
     xr = rng.standard_normal((n, h, w, c_route)).astype(np.float32)
     _, wt, scale, shift = make_case(rng, 1, 1, 1, 1, c_up + c_route, cout)
-    got = run_gpu(xr, wt, scale, shift, 1, 1, True, None, x_up=xu)
+    got = run_gpu(xr, wt, scale, shift, 1, 1, True, None, x_up=xu, planes=planes)
     cat = np.concatenate([np.repeat(np.repeat(xu, 2, 1), 2, 2), xr], axis=3)   # upsampled channels first
-    check(got, ref_conv(cat, wt, scale, shift, 1, 1, True), 'upcat %d+%d' % (c_up, c_route))
+    check(got, ref_conv(cat, wt, scale, shift, 1, 1, True), 'upcat %d+%d' % (c_up, c_route), planes)
 
 
 @pytest.mark.parametrize('n,h,w,k,stride,cin,cout', [
@@ -105,11 +134,13 @@ def test_fused_upsample_concat_input(c_up, c_route, cout):
     (1, 19, 19, 1, 1, 1024, 255),    # 608-input head, odd map
     (5, 2, 2, 3, 1, 64, 64),         # map smaller than the kernel footprint
 ])
-def test_true_size_and_edge_cases(n, h, w, k, stride, cin, cout):
+@pytest.mark.parametrize('planes', PLANES)
+def test_true_size_and_edge_cases(n, h, w, k, stride, cin, cout, planes):
     rng = np.random.RandomState(n * 1000 + h)
     x, wt, scale, shift = make_case(rng, n, h, w, k, cin, cout)
-    got = run_gpu(x, wt, scale, shift, k, stride, True)
-    check(got, ref_conv(x, wt, scale, shift, k, stride, True), '%dx%dx%d k%d s%d %d->%d' % (n, h, w, k, stride, cin, cout))
+    got = run_gpu(x, wt, scale, shift, k, stride, True, planes=planes)
+    check(got, ref_conv(x, wt, scale, shift, k, stride, True),
+          '%dx%dx%d k%d s%d %d->%d' % (n, h, w, k, stride, cin, cout), planes)
 
 
 def test_linearity_and_zero_input_at_full_batch():
@@ -139,6 +170,68 @@ def test_linearity_and_zero_input_at_full_batch():
     assert torch.allclose(y1, y1d, rtol=1e-5, atol=1e-5)
     # run-to-run determinism of the stream-K schedule
     assert torch.equal(engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False), y1)
+
+
+@pytest.mark.parametrize('planes', [3, 2])
+def test_split_full_batch_properties(planes):
+    """planes=3/2 at BASELINE size (bs=32, 52x52x128->256, stream-K schedule): conv(0) == shift, exact
+    power-of-two linearity (the bf16 planes scale exactly), run-to-run determinism, stream-K vs data-parallel
+    agreement, and closeness to the exact-fp32 kernel (same tolerance as against the fp64 reference)."""
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    dev = fw.default_device()
+    rng = np.random.RandomState(1)
+    n, h, w, cin, cout, k = 32, 52, 52, 128, 256, 3
+    wt = torch.from_numpy((rng.standard_normal((k, k, cin, cout)) * 0.03).astype(np.float32)).to(dev)
+    wp = torch.empty(k * k * cout * cin, device=dev)
+    _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(), fw.ptr(wt), k, cin, cout, fw.ptr(wp)))
+    ws = torch.empty(planes * k * k * cout * cin, device=dev, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().y3_pack_conv_weights_split(fw.context(), fw.ptr(wt), k, cin, cout, planes, fw.ptr(ws)))
+    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev)
+    x0 = torch.zeros((n, h, w, cin), device=dev)
+    y0 = engine.conv2d_fwd(x0, ws, ones, shift, k, 1, cout, False, planes=planes)
+    assert torch.equal(y0, shift.view(1, 1, 1, -1).expand_as(y0))
+    x = torch.randn((n, h, w, cin), device=dev)
+    y1 = engine.conv2d_fwd(x, ws, ones, zeros, k, 1, cout, False, planes=planes)
+    y4 = engine.conv2d_fwd(x * 4.0, ws, ones, zeros, k, 1, cout, False, planes=planes)
+    assert torch.equal(y4, y1 * 4.0)
+    assert torch.equal(engine.conv2d_fwd(x, ws, ones, zeros, k, 1, cout, False, planes=planes), y1)
+    y1d = engine.conv2d_fwd(x, ws, ones, zeros, k, 1, cout, False, use_workspace=False, planes=planes)
+    assert torch.allclose(y1, y1d, rtol=1e-5, atol=1e-5)
+    exact = engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False)
+    err = (y1 - exact).abs()
+    assert bool((err <= TOL[planes] * (1 + exact.abs())).all()), float(err.max())
+
+
+@pytest.mark.parametrize('planes', [3, 2])
+def test_plane_tensor_roundtrip_and_fp32_output(planes):
+    """split -> merge is the identity for 3 planes (x1 + x2 + x3 == x exactly, including denormal-range and large
+    values) and 2^-16-accurate for 2 planes; out_f32 of the plane conv equals the merged plane output."""
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    dev = fw.default_device()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(3 * 1024 * 64, generator=g) * torch.exp(4 * torch.randn(3 * 1024 * 64, generator=g))
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 65504.0])
+    x = x.to(dev)
+    back = engine.merge_planes(engine.split_planes(x, planes))
+    if planes == 3:
+        assert torch.equal(back, x)
+    else:
+        assert bool(((back - x).abs() <= 2.0 ** -16 * x.abs()).all())
+    n, h, w, cin, cout, k = 2, 26, 26, 64, 128, 3
+    xin = torch.randn((n, h, w, cin), device=dev)
+    wt = torch.randn((k, k, cin, cout), device=dev) * 0.05
+    ws = torch.empty(planes * k * k * cout * cin, device=dev, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().y3_pack_conv_weights_split(fw.context(), fw.ptr(wt), k, cin, cout, planes, fw.ptr(ws)))
+    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    xp = engine.split_planes(xin, planes)
+    yp = engine.conv2d_fwd_planes(xp, ws, ones, zeros, k, 1, cout, True, planes=planes)
+    yf = engine.conv2d_fwd_planes(xp, ws, ones, zeros, k, 1, cout, True, out_f32=True, planes=planes)
+    merged = engine.merge_planes(yp)
+    if planes == 3:
+        assert torch.equal(merged, yf)
+    else:
+        assert torch.allclose(merged, yf, rtol=2.0 ** -15, atol=1e-6)
 
 
 def test_bad_arguments_raise_value_error():

@@ -1,7 +1,9 @@
 """GPU parity of yolov3.forward (y3_net_forward through the C ABI) against the CPU oracle, with the
 synthetic weights loaded through the darknet-format loader (BASELINE config 3 wiring).
 Tolerances (stated): feature maps |d| <= 2e-4 + 1e-4*|ref| against the fp64 oracle (the fp32 oracle itself
-sits ~5e-6 from fp64); fused plan vs op-by-op composition: bit-exact."""
+sits ~5e-6 from fp64); fused plan vs op-by-op composition: bit-exact.
+The oracle comparisons run for compute_dtype 'f32' (exact fp32 MFMA) and 'f32_bf16x6' (fp32 products rebuilt from
+six bf16 plane products) at the SAME tolerances."""
 import numpy as np
 import pytest
 import torch
@@ -18,10 +20,25 @@ def _cmp(got, want, what, atol=2e-4, rtol=1e-4):
     return float(err.max())
 
 
-def test_forward_matches_oracle_416(gpu_model):
+DTYPES = ['f32', 'f32_bf16x6']
+
+
+@pytest.fixture
+def with_dtype(gpu_model):
+    model, _ = gpu_model
+
+    def setter(dtype):
+        model.compute_dtype = dtype
+    yield setter
+    model.compute_dtype = 'f32'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_forward_matches_oracle_416(gpu_model, with_dtype, dtype):
     import yolov3_tensorflow_amd as y3
     from oracle import yolo_ref
     model, params = gpu_model
+    with_dtype(dtype)
     x = blob_images(0, 2, 416)
     with y3.variable_scope('yolov3'):
         fms = model.forward(x, False)
@@ -36,10 +53,12 @@ def test_forward_matches_oracle_416(gpu_model):
         assert e <= max(20 * e32, 5e-5), 'GPU drift is far above the fp32 CPU drift'
 
 
-def test_forward_other_sizes_and_batches(gpu_model):
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_forward_other_sizes_and_batches(gpu_model, with_dtype, dtype):
     import yolov3_tensorflow_amd as y3
     from oracle import yolo_ref
     model, params = gpu_model
+    with_dtype(dtype)
     for n, h, w in ((1, 320, 608), (3, 96, 64)):
         rng = np.random.RandomState(h)
         x = rng.rand(n, h, w, 3).astype(np.float32)

@@ -16,14 +16,19 @@ from conftest import blob_images
 pytestmark = pytest.mark.gpu
 
 
-def test_forward_predict_nms_against_oracle(gpu_model, anchors):
+@pytest.mark.parametrize('dtype', ['f32', 'f32_bf16x6'])
+def test_forward_predict_nms_against_oracle(gpu_model, anchors, dtype):
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd.utils import nms_utils
     from oracle import yolo_ref, nms_ref
     model, params = gpu_model
     x = blob_images(11, 1, 416)
-    with y3.variable_scope('yolov3'):
-        fms = model.forward(x, False)
+    model.compute_dtype = dtype
+    try:
+        with y3.variable_scope('yolov3'):
+            fms = model.forward(x, False)
+    finally:
+        model.compute_dtype = 'f32'
     boxes, confs, probs, scores = model.predict(fms, with_scores=True)
     rf = yolo_ref.forward(params, x)
     rb, rc, rp = yolo_ref.predict(rf, anchors, [416, 416], 80)

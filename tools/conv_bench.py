@@ -35,30 +35,46 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--planes', type=int, default=0, help='0: exact fp32 MFMA; 2/3: split-bf16 kernel')
+    ap.add_argument('--ptensor', action='store_true', help='plane-tensor form (y3_conv2d_fwd_planes)')
+    ap.add_argument('--only', type=int, default=-1, help='run only this row of the shape table')
     a = ap.parse_args()
     import torch
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
     dev = fw.default_device()
     L = _lib.lib()
-    var = os.environ.get('Y3_CONV_VARIANT', 'default')
+    var = os.environ.get('Y3_CONV_VARIANT', 'default') + ('/p%d%s' % (a.planes, 't' if a.ptensor else ''))
     tot = 0.0
-    for (h, k, s, cin, cout, resid, c_up) in MAIN:
+    for (h, k, s, cin, cout, resid, c_up) in (MAIN if a.only < 0 else MAIN[a.only:a.only + 1]):
         n = a.batch
         cx = cin - c_up
         x = torch.randn((n, h, h, cx), device=dev)
         xu = torch.randn((n, h // 2, h // 2, c_up), device=dev) if c_up else None
         w = torch.randn((k, k, cin, cout), device=dev) * float(np.sqrt(2.0 / (k * k * cin)))
-        wp = torch.empty(k * k * cout * cin, device=dev)
-        _lib.check(L.y3_pack_conv_weights(fw.context(), fw.ptr(w), k, cin, cout, fw.ptr(wp)))
+        if a.planes:
+            wp = torch.empty(a.planes * k * k * cout * cin, device=dev, dtype=torch.bfloat16)
+            _lib.check(L.y3_pack_conv_weights_split(fw.context(), fw.ptr(w), k, cin, cout, a.planes, fw.ptr(wp)))
+        else:
+            wp = torch.empty(k * k * cout * cin, device=dev)
+            _lib.check(L.y3_pack_conv_weights(fw.context(), fw.ptr(w), k, cin, cout, fw.ptr(wp)))
         sc = torch.ones(cout, device=dev)
         sh = torch.zeros(cout, device=dev)
         r = torch.randn((n, h // s, h // s, cout), device=dev) if resid else None
+        if a.ptensor:
+            x = engine.split_planes(x, a.planes)
+            xu = engine.split_planes(xu, a.planes) if xu is not None else None
+            r = engine.split_planes(r, a.planes) if r is not None else None
+            of = cout % 4 != 0
+            run = lambda: engine.conv2d_fwd_planes(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, out_f32=of,
+                                                   planes=a.planes)
+        else:
+            run = lambda: engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, planes=a.planes)
         for _ in range(3):
-            y = engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu)
+            y = run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            y = engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu)
+            y = run()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters

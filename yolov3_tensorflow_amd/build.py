@@ -18,6 +18,7 @@ SOURCES = [
     ("y3_abi.hip", []),
     ("y3_conv.hip", []),
     ("y3_conv_bf16.hip", []),
+    ("y3_conv_split.hip", []),
     ("y3_decode.hip", ["-ffp-contract=off"]),
     ("y3_nms.hip", ["-ffp-contract=off"]),
     ("y3_ops.hip", ["-ffp-contract=off"]),
@@ -25,6 +26,7 @@ SOURCES = [
     ("y3_wgrad.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("Y3_EXTRA_HIPCC_FLAGS", "").split()   # experiment hook (e.g. -DY3_EXP=1)
 
 
 def _hipcc():
@@ -40,6 +42,7 @@ def needs_build():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [
         os.path.join(CSRC, "y3_internal.h"),
+        os.path.join(CSRC, "y3_conv_common.h"),
         os.path.join(HERE, "..", "include", "yolo355.h"),
         os.path.abspath(__file__),
     ]

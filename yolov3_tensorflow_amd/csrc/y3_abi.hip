@@ -47,6 +47,42 @@ extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y, workspace, workspace_bytes);
 }
 
+extern "C" int y3_pack_conv_weights_split(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, int planes,
+                                          void* w_split) {
+    Y3_CHECK_ARG(ctx && w_hwio && w_split, "y3_pack_conv_weights_split: null argument");
+    Y3_CHECK_ARG((k == 1 || k == 3) && cin > 0 && cout > 0 && cin % 16 == 0,
+                 "y3_pack_conv_weights_split: k must be 1 or 3 and cin a positive multiple of 16");
+    Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_pack_conv_weights_split: planes must be 2 or 3 (got %d)", planes);
+    return y3_launch_pack_split(ctx->stream, w_hwio, k, cin, cout, planes, w_split);
+}
+
+extern "C" int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int planes, const float* x,
+                                   const float* x_up, const void* w_split, const float* scale, const float* shift,
+                                   const float* residual, float* y, void* workspace, size_t workspace_bytes) {
+    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_split: null context");
+    return y3_launch_conv_split(ctx->stream, d, planes, x, x_up, w_split, scale, shift, residual, y, workspace,
+                                workspace_bytes);
+}
+
+extern "C" int y3_conv2d_fwd_planes(y3_ctx* ctx, const y3_conv_desc* d, int planes, const void* x, const void* x_up,
+                                    const void* w_split, const float* scale, const float* shift,
+                                    const void* residual, void* y, int out_f32, void* workspace,
+                                    size_t workspace_bytes) {
+    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_planes: null context");
+    return y3_launch_conv_planes(ctx->stream, d, planes, x, x_up, w_split, scale, shift, residual, y, out_f32,
+                                 workspace, workspace_bytes);
+}
+
+extern "C" int y3_split_planes(y3_ctx* ctx, const float* x, size_t count, int planes, void* out) {
+    Y3_CHECK_ARG(ctx, "y3_split_planes: null context");
+    return y3_launch_planes_convert(ctx->stream, 1, planes, x, count, out);
+}
+
+extern "C" int y3_merge_planes(y3_ctx* ctx, const void* in, size_t count, int planes, float* y) {
+    Y3_CHECK_ARG(ctx, "y3_merge_planes: null context");
+    return y3_launch_planes_convert(ctx->stream, 0, planes, in, count, y);
+}
+
 extern "C" int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                                const float* w_d, const float* ones, const float* zeros, int accumulate,
                                float* dx, void* workspace, size_t workspace_bytes) {
@@ -79,7 +115,8 @@ struct Layer {
 struct y3_net {
     y3_ctx* ctx;
     int class_num;
-    int dtype = 0;            // 0: fp32 activations/weights, 1: bf16 storage with fp32 accumulation
+    int dtype = 0;            // 0: fp32 (exact fp32 MFMA), 1: bf16 storage with fp32 accumulation,
+                              // 2 / 3: fp32 tensors, products rebuilt from 3 / 2 bf16 planes (y3_conv_split.hip)
     std::vector<Tensor> tensors;
     std::vector<Layer> layers;
     // cached plan
@@ -250,7 +287,8 @@ extern "C" int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out) {
 
 extern "C" int y3_net_set_dtype(y3_net* net, int dtype) {
     Y3_CHECK_ARG(net, "y3_net_set_dtype: null net");
-    Y3_CHECK_ARG(dtype == 0 || dtype == 1, "y3_net_set_dtype: dtype must be 0 (fp32) or 1 (bf16)");
+    Y3_CHECK_ARG(dtype >= 0 && dtype <= 3,
+                 "y3_net_set_dtype: dtype must be 0 (fp32), 1 (bf16), 2 (fp32 via bf16x6) or 3 (fp32 via bf16x3)");
     net->dtype = dtype;
     net->pn = net->ph = net->pw = 0;   // re-plan
     return Y3_OK;
@@ -372,6 +410,10 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         const int rc = net->dtype == 1
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
+            : net->dtype >= 2
+            ? y3_launch_conv_split(st, &d, net->dtype == 2 ? 3 : 2, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift,
+                                   ptr(l.resid), ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
+                                   ev ? ev[nl + 1 + i] : nullptr)
             : y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
                              ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
                              ev ? ev[nl + 1 + i] : nullptr);

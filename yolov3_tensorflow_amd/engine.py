@@ -28,6 +28,27 @@ def prepare_conv_params_bf16(w_var, bn_vars=None, bias_var=None):
     return wb, scale, shift
 
 
+SPLIT_PLANES = {'f32_bf16x6': 3, 'f32_bf16x3': 2}
+
+
+def prepare_conv_params_split(w_var, bn_vars=None, bias_var=None, planes=3):
+    """As prepare_conv_params, with the kernel pre-split into `planes` bf16 planes for the fp32-on-bf16-MFMA
+    kernels (y3_conv_split.hip); the 3->32 stem keeps its fp32 HWIO kernel."""
+    w32, scale, shift = prepare_conv_params(w_var, bn_vars=bn_vars, bias_var=bias_var)
+    k, _, cin, cout = w_var.shape
+    if cin == 3:
+        return w32, scale, shift
+    key = w_var.op_name + '#split%d' % planes
+    hit = _param_cache.get(key)
+    if hit is not None and hit[0] == w_var.version:
+        return hit[1], scale, shift
+    ws = torch.empty(planes * k * k * cout * cin, dtype=torch.bfloat16, device=w_var.tensor.device)
+    _lib.check(_lib.lib().y3_pack_conv_weights_split(fw.context(), fw.ptr(w_var.tensor), k, cin, cout, planes,
+                                                     fw.ptr(ws)))
+    _param_cache[key] = (w_var.version, ws)
+    return ws, scale, shift
+
+
 def prepare_conv_params(w_var, bn_vars=None, bias_var=None):
     """Return (w_packed, scale, shift) device tensors for one conv layer.
 
@@ -77,9 +98,11 @@ def _conv_scratch(device, nbytes):
     return t
 
 
-def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up=None, use_workspace=True):
+def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up=None, use_workspace=True,
+               planes=0):
     """y = act(conv(x) * scale + shift) + residual on NHWC fp32 device tensors (y3_conv2d_fwd).
-    use_workspace=False forces the data-parallel schedule (no scratch)."""
+    use_workspace=False forces the data-parallel schedule (no scratch).  planes=2/3: w_dev is the split-plane
+    packing and the products are rebuilt on the bf16 matrix pipe (y3_conv2d_fwd_split)."""
     n, h, w, cx = x.shape
     c_up = 0
     if x_up is not None:
@@ -93,9 +116,53 @@ def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up
     if use_workspace:
         ws_bytes = L.y3_conv_workspace_bytes(ctypes.byref(d))
         ws = _conv_scratch(x.device, ws_bytes) if ws_bytes else None
+    if planes:
+        _lib.check(L.y3_conv2d_fwd_split(fw.context(x.device), ctypes.byref(d), int(planes), fw.ptr(x), fw.ptr(x_up),
+                                         fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
+                                         fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
+        return y
     _lib.check(L.y3_conv2d_fwd(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(x_up),
                                fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
                                fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
+    return y
+
+
+def split_planes(x, planes):
+    """fp32 tensor -> [planes, *x.shape] bf16 plane tensor (y3_split_planes)."""
+    out = torch.empty((planes,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().y3_split_planes(fw.context(x.device), fw.ptr(x), ctypes.c_size_t(x.numel()), int(planes),
+                                          fw.ptr(out)))
+    return out
+
+
+def merge_planes(xp):
+    """[planes, ...] bf16 plane tensor -> fp32 tensor (y3_merge_planes)."""
+    y = torch.empty(tuple(xp.shape[1:]), dtype=torch.float32, device=xp.device)
+    _lib.check(_lib.lib().y3_merge_planes(fw.context(xp.device), fw.ptr(xp), ctypes.c_size_t(y.numel()),
+                                          int(xp.shape[0]), fw.ptr(y)))
+    return y
+
+
+def conv2d_fwd_planes(xp, w_split, scale, shift, k, stride, cout, act, residual=None, x_up=None, out_f32=False,
+                      use_workspace=True, planes=3):
+    """Plane-tensor conv (y3_conv2d_fwd_planes).  xp: [planes,N,H,W,C] bf16 planes (or the fp32 [N,H,W,3] image for
+    the stem); residual / x_up likewise planes.  Returns planes [planes,N,Ho,Wo,cout] or fp32 if out_f32."""
+    stem = xp.dtype == torch.float32
+    n, h, w, cx = (xp.shape if stem else xp.shape[1:])
+    c_up = 0 if x_up is None else x_up.shape[4]
+    d = _lib.ConvDesc(n, h, w, cx + c_up, c_up, cout, k, stride, 1 if act else 0)
+    if out_f32:
+        y = torch.empty((n, h // stride, w // stride, cout), dtype=torch.float32, device=xp.device)
+    else:
+        y = torch.empty((planes, n, h // stride, w // stride, cout), dtype=torch.bfloat16, device=xp.device)
+    L = _lib.lib()
+    ws, ws_bytes = None, 0
+    if use_workspace:
+        ws_bytes = L.y3_conv_workspace_bytes(ctypes.byref(d))
+        ws = _conv_scratch(xp.device, ws_bytes) if ws_bytes else None
+    _lib.check(L.y3_conv2d_fwd_planes(fw.context(xp.device), ctypes.byref(d), int(planes), fw.ptr(xp), fw.ptr(x_up),
+                                      fw.ptr(w_split), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual), fw.ptr(y),
+                                      1 if out_f32 else 0, fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y
 
 

@@ -17,6 +17,9 @@ from . import framework as fw
 from .utils.layer_utils import conv2d, darknet53_body, yolo_block, upsample_layer, _conv_layer
 
 N_BODY_CONVS = 52  # utils/layer_utils.py:24-68
+# compute_dtype -> y3_net_set_dtype code.  'f32': exact fp32 MFMA; 'f32_bf16x6' / 'f32_bf16x3': fp32 tensors,
+# every product rebuilt from 6 / 3 bf16 plane products with fp32 accumulation; 'bf16': bf16 storage.
+NET_DTYPES = {'f32': 0, 'bf16': 1, 'f32_bf16x6': 2, 'f32_bf16x3': 3}
 
 
 class yolov3(object):
@@ -33,7 +36,8 @@ class yolov3(object):
         self.use_static_shape = use_static_shape
         self._nets = {}   # (ctx key, scope, dtype) -> dict(handle, version, keepalive, workspace)
         self.img_size = None
-        # 'f32' (the reference's precision) or 'bf16' (bf16 storage, fp32 accumulation; BASELINE configs[4]);
+        # 'f32' (the reference's precision), 'f32_bf16x6' / 'f32_bf16x3' (fp32 tensors, products on the bf16
+        # matrix pipe, see NET_DTYPES) or 'bf16' (bf16 storage, fp32 accumulation; BASELINE configs[4]);
         # an attribute rather than a constructor argument so that the reference's signature is unchanged
         self.compute_dtype = 'f32'
 
@@ -71,9 +75,10 @@ class yolov3(object):
         return layers
 
     def _get_net(self, device):
-        if self.compute_dtype not in ('f32', 'bf16'):
-            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        if self.compute_dtype not in NET_DTYPES:
+            raise ValueError("compute_dtype must be one of %s" % (sorted(NET_DTYPES),))
         bf16 = self.compute_dtype == 'bf16'
+        planes = engine.SPLIT_PLANES.get(self.compute_dtype, 0)
         ctx = fw.context(device)
         scope = fw.current_scope_name()
         key = (ctx.value, scope, self.compute_dtype)
@@ -82,8 +87,8 @@ class yolov3(object):
         if ent is None:
             h = ctypes.c_void_p()
             _lib.check(L.y3_net_create(ctx, int(self.class_num), ctypes.byref(h)))
-            if bf16:
-                _lib.check(L.y3_net_set_dtype(h, 1))
+            if NET_DTYPES[self.compute_dtype]:
+                _lib.check(L.y3_net_set_dtype(h, NET_DTYPES[self.compute_dtype]))
             table = self._layer_table(h)
             ent = dict(handle=h, table=table, version=-1, keep=None, ws=None, ws_bytes=0,
                        layers=self._ensure_variables(scope, table))
@@ -91,8 +96,11 @@ class yolov3(object):
         if ent['version'] != fw.global_version():
             keep = []
             for i, (w, bnv, bias) in enumerate(ent['layers']):
-                prep = engine.prepare_conv_params_bf16 if bf16 else engine.prepare_conv_params
-                wp, sc, sh = prep(w, bn_vars=bnv, bias_var=bias)
+                if planes:
+                    wp, sc, sh = engine.prepare_conv_params_split(w, bn_vars=bnv, bias_var=bias, planes=planes)
+                else:
+                    prep = engine.prepare_conv_params_bf16 if bf16 else engine.prepare_conv_params
+                    wp, sc, sh = prep(w, bn_vars=bnv, bias_var=bias)
                 _lib.check(L.y3_net_set_layer(ent['handle'], i, fw.ptr(wp), fw.ptr(sc), fw.ptr(sh)))
                 keep.append((wp, sc, sh))
             ent['keep'] = keep   # the library holds raw pointers: keep the tensors alive
