@@ -112,18 +112,6 @@ int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int planes, const fl
                         const void* w_split, const float* scale, const float* shift, const float* residual,
                         float* y, void* workspace, size_t workspace_bytes);
 
-/* Plane-tensor form of the same conv: an fp32 tensor of `count`
- * elements is stored as `planes` bf16 planes, plane p starting p * count elements after the base pointer, whose
- * fp32 sum is the value (exactly the original fp32 value for planes = 3).  The producer's epilogue splits every
- * element once; the consumer's K loop then carries no split arithmetic.  x / x_up / residual are plane tensors, y is
- * one too unless out_f32 != 0 (detection feature maps).  The Cin == 3 stem takes the fp32 image and the fp32 HWIO
- * kernel and writes planes.  y3_split_planes / y3_merge_planes convert fp32 <-> planes (count % 4 == 0). */
-int y3_conv2d_fwd_planes(y3_ctx* ctx, const y3_conv_desc* d, int planes, const void* x, const void* x_up,
-                         const void* w_split, const float* scale, const float* shift, const void* residual,
-                         void* y, int out_f32, void* workspace, size_t workspace_bytes);
-int y3_split_planes(y3_ctx* ctx, const float* x, size_t count, int planes, void* out);
-int y3_merge_planes(y3_ctx* ctx, const void* in, size_t count, int planes, float* y);
-
 /* ---- unfused graph ops, for callers composing the network op by op (utils/layer_utils.py) ---------
  * y3_net_forward never launches these (it fuses them into the neighbouring convs).
  * y3_upsample_nearest : tf.image.resize_nearest_neighbor, align_corners=False (utils/layer_utils.py:82-87)

@@ -42,10 +42,9 @@ def ref_conv(x, w_hwio, scale, shift, k, stride, act, resid=None):
     return y.numpy()
 
 
-# 0: exact fp32 kernel; 3 / 2: y3_conv2d_fwd_split (fp32 tensors, split on the fly); -3 / -2: y3_conv2d_fwd_planes
-# (inputs, residual and output are 3 / 2 bf16 plane tensors; converted with y3_split_planes / y3_merge_planes)
-PLANES = [0, 3, 2, -3, -2]
-TOL = {0: 1e-4, 3: 1e-4, 2: 2e-3, -3: 1e-4, -2: 2e-3}
+# 0: exact fp32 kernel; 3 / 2: y3_conv2d_fwd_split (fp32 tensors, operands split into 3 / 2 bf16 planes)
+PLANES = [0, 3, 2]
+TOL = {0: 1e-4, 3: 1e-4, 2: 2e-3}
 
 
 def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None, planes=0):
@@ -65,21 +64,6 @@ def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None, plan
         wp = torch.empty(k * k * cout * cin_total, device=dev)
         _lib.check(L.y3_pack_conv_weights(fw.context(), fw.ptr(w), k, cin_total, cout, fw.ptr(wp)))
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
-    if planes < 0:
-        sp = lambda a: None if a is None else engine.split_planes(t(a), -planes)
-        if cin_total == 3:
-            xin, wp = t(x), w
-        else:
-            xin = sp(x)
-            wp = torch.empty(-planes * k * k * cout * cin_total, device=dev, dtype=torch.bfloat16)
-            _lib.check(L.y3_pack_conv_weights_split(fw.context(), fw.ptr(w), k, cin_total, cout, -planes, fw.ptr(wp)))
-        out_f32 = cout % 4 != 0
-        y = engine.conv2d_fwd_planes(xin, wp, t(scale), t(shift), k, stride, cout, act, residual=sp(resid),
-                                     x_up=sp(x_up), out_f32=out_f32, planes=-planes)
-        if not out_f32:
-            y = engine.merge_planes(y)
-        torch.cuda.synchronize()
-        return y.cpu().numpy()
     y = engine.conv2d_fwd(t(x), wp, t(scale), t(shift), k, stride, cout, act, residual=t(resid), x_up=t(x_up),
                           planes=planes)
     torch.cuda.synchronize()
@@ -201,37 +185,6 @@ def test_split_full_batch_properties(planes):
     exact = engine.conv2d_fwd(x, wp, ones, zeros, k, 1, cout, False)
     err = (y1 - exact).abs()
     assert bool((err <= TOL[planes] * (1 + exact.abs())).all()), float(err.max())
-
-
-@pytest.mark.parametrize('planes', [3, 2])
-def test_plane_tensor_roundtrip_and_fp32_output(planes):
-    """split -> merge is the identity for 3 planes (x1 + x2 + x3 == x exactly, including denormal-range and large
-    values) and 2^-16-accurate for 2 planes; out_f32 of the plane conv equals the merged plane output."""
-    from yolov3_tensorflow_amd import engine, framework as fw, _lib
-    dev = fw.default_device()
-    g = torch.Generator(device='cpu').manual_seed(3)
-    x = torch.randn(3 * 1024 * 64, generator=g) * torch.exp(4 * torch.randn(3 * 1024 * 64, generator=g))
-    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 65504.0])
-    x = x.to(dev)
-    back = engine.merge_planes(engine.split_planes(x, planes))
-    if planes == 3:
-        assert torch.equal(back, x)
-    else:
-        assert bool(((back - x).abs() <= 2.0 ** -16 * x.abs()).all())
-    n, h, w, cin, cout, k = 2, 26, 26, 64, 128, 3
-    xin = torch.randn((n, h, w, cin), device=dev)
-    wt = torch.randn((k, k, cin, cout), device=dev) * 0.05
-    ws = torch.empty(planes * k * k * cout * cin, device=dev, dtype=torch.bfloat16)
-    _lib.check(_lib.lib().y3_pack_conv_weights_split(fw.context(), fw.ptr(wt), k, cin, cout, planes, fw.ptr(ws)))
-    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-    xp = engine.split_planes(xin, planes)
-    yp = engine.conv2d_fwd_planes(xp, ws, ones, zeros, k, 1, cout, True, planes=planes)
-    yf = engine.conv2d_fwd_planes(xp, ws, ones, zeros, k, 1, cout, True, out_f32=True, planes=planes)
-    merged = engine.merge_planes(yp)
-    if planes == 3:
-        assert torch.equal(merged, yf)
-    else:
-        assert torch.allclose(merged, yf, rtol=2.0 ** -15, atol=1e-6)
 
 
 def test_bad_arguments_raise_value_error():

@@ -16,6 +16,7 @@ from conftest import blob_images
 pytestmark = pytest.mark.gpu
 
 
+# ('f32_bf16x3' is deliberately absent: measured 1.2e-3 relative box drift, just outside the 1e-3 north-star bound)
 @pytest.mark.parametrize('dtype', ['f32', 'f32_bf16x6'])
 def test_forward_predict_nms_against_oracle(gpu_model, anchors, dtype):
     import yolov3_tensorflow_amd as y3

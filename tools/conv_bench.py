@@ -36,14 +36,13 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--planes', type=int, default=0, help='0: exact fp32 MFMA; 2/3: split-bf16 kernel')
-    ap.add_argument('--ptensor', action='store_true', help='plane-tensor form (y3_conv2d_fwd_planes)')
     ap.add_argument('--only', type=int, default=-1, help='run only this row of the shape table')
     a = ap.parse_args()
     import torch
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
     dev = fw.default_device()
     L = _lib.lib()
-    var = os.environ.get('Y3_CONV_VARIANT', 'default') + ('/p%d%s' % (a.planes, 't' if a.ptensor else ''))
+    var = os.environ.get('Y3_CONV_VARIANT', 'default') + ('/p%d' % a.planes)
     tot = 0.0
     for (h, k, s, cin, cout, resid, c_up) in (MAIN if a.only < 0 else MAIN[a.only:a.only + 1]):
         n = a.batch
@@ -60,15 +59,7 @@ def main():
         sc = torch.ones(cout, device=dev)
         sh = torch.zeros(cout, device=dev)
         r = torch.randn((n, h // s, h // s, cout), device=dev) if resid else None
-        if a.ptensor:
-            x = engine.split_planes(x, a.planes)
-            xu = engine.split_planes(xu, a.planes) if xu is not None else None
-            r = engine.split_planes(r, a.planes) if r is not None else None
-            of = cout % 4 != 0
-            run = lambda: engine.conv2d_fwd_planes(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, out_f32=of,
-                                                   planes=a.planes)
-        else:
-            run = lambda: engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, planes=a.planes)
+        run = lambda: engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, planes=a.planes)
         for _ in range(3):
             y = run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

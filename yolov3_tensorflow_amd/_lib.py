@@ -31,10 +31,6 @@ PROTOTYPES = {
     "y3_pack_conv_weights_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_conv2d_fwd_split": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
-    "y3_conv2d_fwd_planes": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t]),
-    "y3_split_planes": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    "y3_merge_planes": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "y3_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_conv2d_fwd_bf16": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int]),

@@ -64,25 +64,6 @@ extern "C" int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int plane
                                 workspace_bytes);
 }
 
-extern "C" int y3_conv2d_fwd_planes(y3_ctx* ctx, const y3_conv_desc* d, int planes, const void* x, const void* x_up,
-                                    const void* w_split, const float* scale, const float* shift,
-                                    const void* residual, void* y, int out_f32, void* workspace,
-                                    size_t workspace_bytes) {
-    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_planes: null context");
-    return y3_launch_conv_planes(ctx->stream, d, planes, x, x_up, w_split, scale, shift, residual, y, out_f32,
-                                 workspace, workspace_bytes);
-}
-
-extern "C" int y3_split_planes(y3_ctx* ctx, const float* x, size_t count, int planes, void* out) {
-    Y3_CHECK_ARG(ctx, "y3_split_planes: null context");
-    return y3_launch_planes_convert(ctx->stream, 1, planes, x, count, out);
-}
-
-extern "C" int y3_merge_planes(y3_ctx* ctx, const void* in, size_t count, int planes, float* y) {
-    Y3_CHECK_ARG(ctx, "y3_merge_planes: null context");
-    return y3_launch_planes_convert(ctx->stream, 0, planes, in, count, y);
-}
-
 extern "C" int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                                const float* w_d, const float* ones, const float* zeros, int accumulate,
                                float* dx, void* workspace, size_t workspace_bytes) {

@@ -402,7 +402,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     Y3_CHECK_ARG((x_up != nullptr) == (d->c_up > 0), "y3_conv2d_fwd: x_up and c_up must agree");
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
-    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0; a.bkk = BK; a.x_plane = a.xu_plane = a.y_plane = 0; a.out_f32 = 1;
+    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0; a.bkk = BK;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -414,7 +414,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && !x_up && !residual,
                      "y3_conv2d_fwd: Cin=3 is supported only as the 3x3 3->32 stem conv");
-        auto stem = conv_stem_kernel<32, 0>;
+        auto stem = conv_stem_kernel<32>;
         hipLaunchKernelGGL(stem, dim3((a.M + 255) / 256), dim3(256), 0, stream, a);
         Y3_CHECK_HIP(hipGetLastError());
         return Y3_OK;
@@ -461,7 +461,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     ConvArgs a;
     a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
     a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.workers = 0;
-    a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0; a.bkk = BK; a.x_plane = a.xu_plane = a.y_plane = 0; a.out_f32 = 1;
+    a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0; a.bkk = BK;
     a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
     a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;
     a.Ho = fwd->h; a.Wo = fwd->w;

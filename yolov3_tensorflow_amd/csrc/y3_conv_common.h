@@ -28,10 +28,6 @@ struct ConvArgs {
                          //    (1, 2, 2 or 4 of the 9), reading x[y'+dy, x'+dx] with dy,dx in {0,1}
     int cy, cx, ntaps;   // tmode only
     int bkk;             // K elements per K-step of the kernel that produced the stream-K partials (fix-up)
-    // bf16-plane tensors (y3_conv_split.hip, NPIO > 0 instantiations only): plane pl of a tensor starts pl * plane
-    // ELEMENTS after its base pointer (x / xu / y / resid are then const unsigned short* in disguise)
-    size_t x_plane, xu_plane, y_plane;
-    int out_f32;         // NPIO only: 1 = write plain fp32 (detection feature maps) instead of planes
 };
 
 constexpr int BK = 32;
@@ -75,24 +71,9 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[NP]) {
         o[pl][1] = (h[pl][2] >> 16) | h[pl][3];
     }
 }
-// inverse: the fp32 sum of the planes (exact for NP = 3: it is the original fp32 value)
-template <int NP>
-__device__ __forceinline__ f32x4 merge4(const u32x2 (&o)[NP]) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pl = NP - 1; pl >= 0; --pl) {
-        v[0] += __uint_as_float(o[pl][0] << 16);
-        v[1] += __uint_as_float(o[pl][0] & 0xffff0000u);
-        v[2] += __uint_as_float(o[pl][1] << 16);
-        v[3] += __uint_as_float(o[pl][1] & 0xffff0000u);
-    }
-    return v;
-}
-
 // ---- epilogue shared by the conv kernel and the stream-K fix-up kernel ------------------------------
 // D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-// NPIO > 0: the residual and (unless p.out_f32) the output are NPIO-plane bf16 tensors.
-template <int BM, int BN, int WGM, int WGN, bool TMODE, int NPIO = 0>
+template <int BM, int BN, int WGM, int WGN, bool TMODE>
 __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                                          f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI],
                                          int m0, int n0) {
@@ -122,21 +103,9 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const int row = m0 + tr + i * RPP;
-                if (NPIO > 0) {
-                    u32x2 rp[NPIO > 0 ? NPIO : 1];
-#pragma unroll
-                    for (int pl = 0; pl < NPIO; ++pl)
-                        rp[pl] = (cok && row < p.M)
-                                     ? *reinterpret_cast<const u32x2*>(
-                                           reinterpret_cast<const unsigned short*>(p.resid) + pl * p.y_plane +
-                                           out_pixel(row) * p.Cout + col)
-                                     : u32x2{0u, 0u};
-                    res[i] = merge4<(NPIO > 0 ? NPIO : 1)>(rp);
-                } else {
-                    res[i] = (cok && row < p.M)
-                                 ? *reinterpret_cast<const f32x4*>(p.resid + out_pixel(row) * p.Cout + col)
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                res[i] = (cok && row < p.M)
+                             ? *reinterpret_cast<const f32x4*>(p.resid + out_pixel(row) * p.Cout + col)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         float* cs = smem;
@@ -164,16 +133,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                     }
                     if (p.resid) v += res[i];
-                    if (NPIO > 0 && !p.out_f32) {
-                        u32x2 o[NPIO > 0 ? NPIO : 1];
-                        split4<(NPIO > 0 ? NPIO : 1)>(v, o);
-#pragma unroll
-                        for (int pl = 0; pl < NPIO; ++pl)
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.y) + pl * p.y_plane +
-                                                      out_pixel(row) * p.Cout + col) = o[pl];
-                    } else {
-                        *reinterpret_cast<f32x4*>(p.y + out_pixel(row) * p.Cout + col) = v;
-                    }
+                    *reinterpret_cast<f32x4*>(p.y + out_pixel(row) * p.Cout + col) = v;
                 }
             }
         }
@@ -222,7 +182,7 @@ __device__ __forceinline__ int sk_worker_id(int b, int workers) {
 
 // Stream-K fix-up: one workgroup per output tile; tiles computed whole by one worker exit at once, split
 // tiles sum their partials in worker (= K) order and run the common epilogue.
-template <int BM, int BN, int WGM, int WGN, int KS, bool TMODE, int NPIO = 0>
+template <int BM, int BN, int WGM, int WGN, int KS, bool TMODE>
 __global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -259,14 +219,13 @@ __global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvAr
     }
     const int nbm = (p.M + BM - 1) / BM;
     const int bn = tile / nbm, bm = tile - bn * nbm;
-    epilogue<BM, BN, WGM, WGN, TMODE, NPIO>(p, smem, acc, bm * BM, bn * BN);
+    epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, bm * BM, bn * BN);
 }
 
 // ---- stem conv: 3x3, Cin = 3 -> COUT (=32), stride 1 ------------------------------------------------
 // K = 27 is too short for the implicit-GEMM tile and the layer is HBM-write bound (709 MB out per
 // bs=32 batch vs 9.6 GFLOP): one thread per output pixel, weights HWIO [27][COUT] broadcast from LDS.
-// NPOUT > 0: the output is written as NPOUT bf16 planes (p.y_plane elements apart).
-template <int COUT, int NPOUT>
+template <int COUT>
 __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
     __shared__ float ssc[COUT], ssh[COUT];
@@ -320,16 +279,7 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
             if (p.act) t = t > 0.f ? t : 0.1f * t;
             v[q] = t;
         }
-        if (NPOUT > 0) {
-            u32x2 o[NPOUT > 0 ? NPOUT : 1];
-            split4<(NPOUT > 0 ? NPOUT : 1)>(v, o);
-#pragma unroll
-            for (int pl = 0; pl < NPOUT; ++pl)
-                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.y) + pl * p.y_plane +
-                                          (size_t)m * COUT + c) = o[pl];
-        } else {
-            *reinterpret_cast<f32x4*>(out + c) = v;
-        }
+        *reinterpret_cast<f32x4*>(out + c) = v;
     }
 }
 

@@ -35,16 +35,11 @@ constexpr size_t split_lds_bytes() {
     return t > e ? t : e;
 }
 
-// APL = false: x / x_up / residual / y are fp32 tensors; the activations are split between the global load and
-//              the LDS write (drop-in for y3_conv2d_fwd).
-// APL = true : x / x_up / residual / y are NP-plane bf16 tensors (the producer's epilogue split them once, instead
-//              of every consumer workgroup re-splitting every element 9 * Cout/128 times); loads go to the LDS
-//              unchanged, the K loop carries no split arithmetic.  p.out_f32 selects an fp32 output.
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, int NP, bool APL>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, int NP>
 __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     constexpr int MI = G::MI, NI = G::NI, WTM = G::WTM, WTN = G::WTN;
-    constexpr int AROWS = APL ? 1 : BM / 64;            // fp32: float4 chunks of A each thread stages per K-step
+    constexpr int AROWS = BM / 64;                      // float4 chunks of A each thread stages per K-step
     constexpr int PLANE_A = BM * SROW, PLANE_B = BN * SROW;
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -82,20 +77,16 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
     if (item >= item_end) return;
     const int first_tile = (int)(item / S);
 
-    // staging coordinates.  fp32 A: float4 column c4 of rows r0 + 64*j.  B (and plane A): 16-byte half `tid&1`
-    // (8 bf16) of row tid>>1.
+    // staging coordinates.  A: float4 column c4 of rows r0 + 64*j.  B: 16-byte half `tid&1` (8 bf16) of row tid>>1.
     const int brow = tid >> 1, bhalf = tid & 1;
-    const int c4 = APL ? bhalf * 8 : (tid & 3) * 4;
-    const int r0 = APL ? brow : tid >> 2;
+    const int c4 = (tid & 3) * 4;
+    const int r0 = tid >> 2;
 
-    // element size of the activation tensors: fp32, or NP bf16 planes p.x_plane / p.xu_plane elements apart
-    constexpr unsigned AES = APL ? 2u : 4u;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cx * (APL ? 2 * NP : 4)), 0x00020000);
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cx * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(UPCAT ? p.xu : p.x), 0,
-        (unsigned)(UPCAT ? (size_t)p.N * (p.H >> 1) * (p.W >> 1) * p.Cu * (APL ? 2 * NP : 4) : 16), 0x00020000);
-    const unsigned xplane_b = (unsigned)(p.x_plane * 2), uplane_b = (unsigned)(p.xu_plane * 2);
+        (unsigned)(UPCAT ? (size_t)p.N * (p.H >> 1) * (p.W >> 1) * p.Cu * 4 : 16), 0x00020000);
     const unsigned wplane = (unsigned)(p.Cout * SBK * 2);   // bytes of one [Cout][16] bf16 plane slice
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w), 0, (unsigned)((size_t)taps * p.Cout * p.Cin * 2 * NP), 0x00020000);
@@ -115,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         const int HoWo = p.Ho * p.Wo;
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
-            const int m = bm * BM + r0 + 64 * j;   // (APL: one row per thread, j == 0)
+            const int m = bm * BM + r0 + 64 * j;
             int mk = 0, base = 0, base_u = 0;
             if (m < p.M) {
                 const int n = m / HoWo;
@@ -140,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         b_voff = (brow < BN && co < p.Cout) ? (unsigned)(co * SBK + bhalf * 8) * 2u : OOB;
     };
 
-    f32x4 ra[2][APL ? NP : AROWS];   // fp32 chunks, or (APL) one 16-byte piece per plane
+    f32x4 ra[2][AROWS];
     u32x4 rb[2][NP];
 
     // fetch the prepared K-step into register set s and step the loader.  Past the end of a tile the state runs
@@ -156,18 +147,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         for (int j = 0; j < AROWS; ++j) {
             const int mk = a_msk[j];
             const bool ok = ((mk >> ky) & (mk >> (4 + kx)) & 1) != 0;
-            voff[j] = ok ? (unsigned)(a_base[j] + tap_off) * AES : OOB;
-            if (UPCAT) voff_u[j] = ok ? (unsigned)a_base_u[j] * AES : OOB;
+            voff[j] = ok ? (unsigned)(a_base[j] + tap_off) * 4u : OOB;
+            if (UPCAT) voff_u[j] = ok ? (unsigned)a_base_u[j] * 4u : OOB;
         }
-        if (APL) {
-            const bool from_up = UPCAT && c0 < p.Cu;
-            const unsigned soff = (unsigned)(from_up ? c0 : c0 - (UPCAT ? p.Cu : 0)) * 2u;
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-                ra[s][pl] = __builtin_bit_cast(
-                    f32x4, from_up ? __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[0], soff + pl * uplane_b, 0)
-                                   : __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[0], soff + pl * xplane_b, 0));
-        } else if (UPCAT) {
+        if (UPCAT) {
             const bool from_up = c0 < p.Cu;
             const unsigned soff = (unsigned)(from_up ? c0 : c0 - p.Cu) * 4u;
 #pragma unroll
@@ -195,19 +178,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         constexpr int s = decltype(sc)::value;      // register set s -> LDS buffer s
         unsigned char* as = As + s * NP * PLANE_A;
         unsigned char* bs = Bs + s * NP * PLANE_B;
-        if (APL) {
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            u32x2 o[NP];
+            split4<NP>(ra[s][j], o);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                *reinterpret_cast<f32x4*>(as + pl * PLANE_A + lds_off(brow, bhalf)) = ra[s][pl];
-        } else {
-#pragma unroll
-            for (int j = 0; j < AROWS; ++j) {
-                u32x2 o[NP];
-                split4<NP>(ra[s][j], o);
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    *reinterpret_cast<u32x2*>(as + pl * PLANE_A + lds_off(r0 + 64 * j, c4 >> 3) + (c4 & 4) * 2) = o[pl];
-            }
+                *reinterpret_cast<u32x2*>(as + pl * PLANE_A + lds_off(r0 + 64 * j, c4 >> 3) + (c4 & 4) * 2) = o[pl];
         }
         if (BN >= 128 || brow < BN) {
 #pragma unroll
@@ -250,19 +227,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
                                                                               acc[mi][ni], 0, 0, 0);
     };
 
-    // One K-step = MF MFMAs of 32 cycles.  In their shadow: the fragment reads up front, then the split
-    // arithmetic of the NEXT K-step's A chunks (VALU) and, behind the last MFMAs, its LDS writes.
-    auto pipeline_hint = [&]() {
-        constexpr int MF = MI * NI * (NP * (NP + 1) / 2);
-        constexpr int NW = (APL ? NP : AROWS * NP) + NP;
-        __builtin_amdgcn_sched_group_barrier(0x100, (MI + NI) * NP, 0);
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < MF - NW) __builtin_amdgcn_sched_group_barrier(0x002, APL ? 1 : 4, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-    };
+    // Scheduling hint: issue the K-step's fragment reads together, ahead of its MFMAs; the rest is left to the
+    // compiler (measured: interleaving the split arithmetic and the LDS writes between the MFMAs by hand was 5 %
+    // slower than hipcc's own order — MFMAs back to back, staging behind them).
+    auto pipeline_hint = [&]() { __builtin_amdgcn_sched_group_barrier(0x100, (MI + NI) * NP, 0); };
 
     // ---- segments: maximal runs of items of one tile inside this workgroup's range ---------------------
     // Invariant at the top of a segment: register sets 0 and 1 hold (or are receiving) its first two K-steps and
@@ -289,22 +257,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
 
         store(i0);
         __syncthreads();
-#ifndef Y3_EXP
-#define Y3_EXP 0
-#endif
         for (int t = 0; t + 1 < npairs; ++t) {
-            // Y3_EXP knock-out experiments (timing only, results wrong): 1 no barriers, 2 no global loads,
-            // 3 no split/LDS writes, 4 no MFMA+fragment reads, 5 no scheduling hints
-            if (Y3_EXP != 2) issue(i0);
-            if (Y3_EXP != 4) compute(0);
-            if (Y3_EXP != 3) store(i1);
-            if (Y3_EXP != 5) pipeline_hint();
-            if (Y3_EXP != 1) __syncthreads();
-            if (Y3_EXP != 2) issue(i1);
-            if (Y3_EXP != 4) compute(1);
-            if (Y3_EXP != 3) store(i0);
-            if (Y3_EXP != 5) pipeline_hint();
-            if (Y3_EXP != 1) __syncthreads();
+            issue(i0);
+            compute(0);
+            store(i1);
+            pipeline_hint();
+            __syncthreads();
+            issue(i1);
+            compute(1);
+            store(i0);
+            pipeline_hint();
+            __syncthreads();
         }
         // last pair of the segment: its prefetches belong to the next tile (if this workgroup has one)
         if (STREAMK && seg_end < item_end) set_loader(seg_end);
@@ -317,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         __syncthreads();
 
         if (!STREAMK || (pair0 == 0 && seg_end == tile_end)) {
-            epilogue<BM, BN, WGM, WGN, false, (APL ? NP : 0)>(p, reinterpret_cast<float*>(smem_raw), acc, bm * BM, bn * BN);
+            epilogue<BM, BN, WGM, WGN, false>(p, reinterpret_cast<float*>(smem_raw), acc, bm * BM, bn * BN);
         } else {
             // partial tile: raw accumulators to this worker's slot (0 = its first tile, 1 = its last)
             float* slot = p.partial + ((size_t)worker * 2 + (tile == first_tile ? 0 : 1)) * (BM * BN);
@@ -337,9 +300,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int NP, bool APL>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int NP>
 int launch_dp(hipStream_t stream, const ConvArgs& a) {
-    auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, NP, APL>;
+    auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, NP>;
     constexpr size_t lds = split_lds_bytes<BM, BN, NP>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -353,12 +316,12 @@ int launch_dp(hipStream_t stream, const ConvArgs& a) {
     return Y3_OK;
 }
 
-template <int KS, int NP, bool APL>
+template <int KS, int NP>
 int launch_sk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
-    auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, false, true, NP, APL>;
-    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS, false, (APL ? NP : 0)>;
+    auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, false, true, NP>;
+    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS, false>;
     constexpr size_t lds = split_lds_bytes<BM, BN, NP>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -375,26 +338,26 @@ int launch_sk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
     return Y3_OK;
 }
 
-template <int KS, bool UPCAT, int NP, bool APL>
+template <int KS, bool UPCAT, int NP>
 int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
-    if (a.Cout <= 32) return launch_dp<128, 32, 4, 1, KS, UPCAT, NP, APL>(stream, a);
-    if (a.Cout <= 64) return launch_dp<128, 64, 4, 1, KS, UPCAT, NP, APL>(stream, a);
-    return launch_dp<128, 128, 2, 2, KS, UPCAT, NP, APL>(stream, a);
+    if (a.Cout <= 32) return launch_dp<128, 32, 4, 1, KS, UPCAT, NP>(stream, a);
+    if (a.Cout <= 64) return launch_dp<128, 64, 4, 1, KS, UPCAT, NP>(stream, a);
+    return launch_dp<128, 128, 2, 2, KS, UPCAT, NP>(stream, a);
 }
 
-template <int NP, bool APL>
+template <int NP>
 int launch_np(hipStream_t stream, const y3_conv_desc* d, ConvArgs& a, void* workspace, size_t workspace_bytes,
               hipEvent_t mid_event) {
-    if (a.xu) return dispatch_bn<1, true, NP, APL>(stream, a);
-    if (d->k == 1) return dispatch_bn<1, false, NP, APL>(stream, a);
+    if (a.xu) return dispatch_bn<1, true, NP>(stream, a);
+    if (d->k == 1) return dispatch_bn<1, false, NP>(stream, a);
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     if (use_streamk(a, d->k, has_ws)) {
         a.partial = static_cast<float*>(workspace);
         a.workers = SK_WORKERS;
-        return launch_sk<3, NP, APL>(stream, a, mid_event);
+        return launch_sk<3, NP>(stream, a, mid_event);
     }
-    return dispatch_bn<3, false, NP, APL>(stream, a);
+    return dispatch_bn<3, false, NP>(stream, a);
 }
 
 __global__ void pack_weights_split_kernel(const float* __restrict__ w_hwio, unsigned short* __restrict__ out,
@@ -417,28 +380,6 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w_hwio, unsi
                 (unsigned short)(u >> 16);
             rem -= __uint_as_float(u);
         }
-    }
-}
-
-// fp32 tensor <-> NP bf16 planes (count % 4 == 0), 4 elements per thread
-template <int NP>
-__global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, size_t count4,
-                                    size_t plane) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (size_t)gridDim.x * blockDim.x) {
-        u32x2 o[NP];
-        split4<NP>(reinterpret_cast<const f32x4*>(x)[i], o);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(out + pl * plane + 4 * i) = o[pl];
-    }
-}
-template <int NP>
-__global__ void merge_planes_kernel(const unsigned short* __restrict__ in, float* __restrict__ y, size_t count4,
-                                    size_t plane) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (size_t)gridDim.x * blockDim.x) {
-        u32x2 o[NP];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) o[pl] = *reinterpret_cast<const u32x2*>(in + pl * plane + 4 * i);
-        reinterpret_cast<f32x4*>(y)[i] = merge4<NP>(o);
     }
 }
 
@@ -469,10 +410,6 @@ void fill_args(ConvArgs& a, const y3_conv_desc* d) {
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
     a.M = d->n * a.Ho * a.Wo;
-    a.x_plane = (size_t)d->n * d->h * d->w * a.Cx;
-    a.xu_plane = (size_t)d->n * (d->h / 2) * (d->w / 2) * d->c_up;
-    a.y_plane = (size_t)a.M * d->cout;
-    a.out_f32 = 1;
 }
 
 }  // namespace
@@ -482,25 +419,6 @@ int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weights_split_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio,
                        static_cast<unsigned short*>(out), k * k, cin, cout, planes);
-    Y3_CHECK_HIP(hipGetLastError());
-    return Y3_OK;
-}
-
-int y3_launch_planes_convert(hipStream_t stream, int to_planes, int planes, const void* in, size_t count, void* out) {
-    Y3_CHECK_ARG(in && out, "y3_split_planes/y3_merge_planes: null pointer argument");
-    Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_split_planes/y3_merge_planes: planes must be 2 or 3 (got %d)", planes);
-    Y3_CHECK_ARG(count > 0 && count % 4 == 0, "y3_split_planes/y3_merge_planes: count must be a positive multiple of 4");
-    const size_t c4 = count / 4;
-    const int blocks = (int)((c4 + 255) / 256 < 8192 ? (c4 + 255) / 256 : 8192);
-    if (to_planes) {
-        auto k = planes == 3 ? split_planes_kernel<3> : split_planes_kernel<2>;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, stream, static_cast<const float*>(in),
-                           static_cast<unsigned short*>(out), c4, count);
-    } else {
-        auto k = planes == 3 ? merge_planes_kernel<3> : merge_planes_kernel<2>;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, stream, static_cast<const unsigned short*>(in),
-                           static_cast<float*>(out), c4, count);
-    }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
@@ -520,45 +438,6 @@ int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, 
     a.x = x; a.xu = x_up; a.w = static_cast<const float*>(w); a.scale = scale; a.shift = shift;
     a.resid = residual; a.y = y;
     fill_args(a, d);
-    return planes == 3 ? launch_np<3, false>(stream, d, a, workspace, workspace_bytes, mid_event)
-                       : launch_np<2, false>(stream, d, a, workspace, workspace_bytes, mid_event);
-}
-
-// Plane-tensor form: x / x_up / residual (and y unless out_f32) are `planes` bf16 planes, plane pl starting
-// pl * (tensor element count) elements after the base pointer.  The Cin == 3 stem takes the fp32 image and the
-// fp32 HWIO kernel.
-int y3_launch_conv_planes(hipStream_t stream, const y3_conv_desc* d, int planes, const void* x, const void* x_up,
-                          const void* w, const float* scale, const float* shift, const void* residual, void* y,
-                          int out_f32, void* workspace, size_t workspace_bytes, hipEvent_t mid_event) {
-    Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_conv2d_fwd_planes: planes must be 2 or 3 (got %d)", planes);
-    Y3_CHECK_ARG(d && x && w && scale && shift && y, "y3_conv2d_fwd_planes: null pointer argument");
-    ConvArgs a;
-    a.x = static_cast<const float*>(x); a.xu = static_cast<const float*>(x_up); a.w = static_cast<const float*>(w);
-    a.scale = scale; a.shift = shift; a.resid = static_cast<const float*>(residual); a.y = static_cast<float*>(y);
-    if (d->cin == 3) {
-        Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && !x_up && !residual && !out_f32 && d->n > 0 &&
-                     d->h > 0 && d->w > 0,
-                     "y3_conv2d_fwd_planes: Cin=3 is supported only as the 3x3 s1 3->32 stem conv with plane output");
-        Y3_CHECK_ARG((long long)d->n * d->h * d->w * 32 < (1LL << 29),
-                     "y3_conv2d_fwd_planes: tensor exceeds 2^29 elements");
-        fill_args(a, d);
-        a.out_f32 = 0;
-        if (planes == 3) {
-            auto stem = conv_stem_kernel<32, 3>;
-            hipLaunchKernelGGL(stem, dim3((a.M + 255) / 256), dim3(256), 0, stream, a);
-        } else {
-            auto stem = conv_stem_kernel<32, 2>;
-            hipLaunchKernelGGL(stem, dim3((a.M + 255) / 256), dim3(256), 0, stream, a);
-        }
-        Y3_CHECK_HIP(hipGetLastError());
-        return Y3_OK;
-    }
-    if (int rc = check_desc(d, x_up, "y3_conv2d_fwd_planes")) return rc;
-    Y3_CHECK_ARG(out_f32 || d->cout % 4 == 0, "y3_conv2d_fwd_planes: plane output needs Cout %% 4 == 0 (got %d)",
-                 d->cout);
-    Y3_CHECK_ARG(!residual || d->cout % 4 == 0, "y3_conv2d_fwd_planes: residual needs Cout %% 4 == 0");
-    fill_args(a, d);
-    a.out_f32 = out_f32 ? 1 : 0;
-    return planes == 3 ? launch_np<3, true>(stream, d, a, workspace, workspace_bytes, mid_event)
-                       : launch_np<2, true>(stream, d, a, workspace, workspace_bytes, mid_event);
+    return planes == 3 ? launch_np<3>(stream, d, a, workspace, workspace_bytes, mid_event)
+                       : launch_np<2>(stream, d, a, workspace, workspace_bytes, mid_event);
 }

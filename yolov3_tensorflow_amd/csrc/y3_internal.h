@@ -48,7 +48,3 @@ int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin
 int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, const float* x, const float* x_up,
                          const void* w, const float* scale, const float* shift, const float* residual, float* y,
                          void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
-int y3_launch_conv_planes(hipStream_t stream, const y3_conv_desc* d, int planes, const void* x, const void* x_up,
-                          const void* w, const float* scale, const float* shift, const void* residual, void* y,
-                          int out_f32, void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
-int y3_launch_planes_convert(hipStream_t stream, int to_planes, int planes, const void* in, size_t count, void* out);

@@ -127,45 +127,6 @@ def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up
     return y
 
 
-def split_planes(x, planes):
-    """fp32 tensor -> [planes, *x.shape] bf16 plane tensor (y3_split_planes)."""
-    out = torch.empty((planes,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().y3_split_planes(fw.context(x.device), fw.ptr(x), ctypes.c_size_t(x.numel()), int(planes),
-                                          fw.ptr(out)))
-    return out
-
-
-def merge_planes(xp):
-    """[planes, ...] bf16 plane tensor -> fp32 tensor (y3_merge_planes)."""
-    y = torch.empty(tuple(xp.shape[1:]), dtype=torch.float32, device=xp.device)
-    _lib.check(_lib.lib().y3_merge_planes(fw.context(xp.device), fw.ptr(xp), ctypes.c_size_t(y.numel()),
-                                          int(xp.shape[0]), fw.ptr(y)))
-    return y
-
-
-def conv2d_fwd_planes(xp, w_split, scale, shift, k, stride, cout, act, residual=None, x_up=None, out_f32=False,
-                      use_workspace=True, planes=3):
-    """Plane-tensor conv (y3_conv2d_fwd_planes).  xp: [planes,N,H,W,C] bf16 planes (or the fp32 [N,H,W,3] image for
-    the stem); residual / x_up likewise planes.  Returns planes [planes,N,Ho,Wo,cout] or fp32 if out_f32."""
-    stem = xp.dtype == torch.float32
-    n, h, w, cx = (xp.shape if stem else xp.shape[1:])
-    c_up = 0 if x_up is None else x_up.shape[4]
-    d = _lib.ConvDesc(n, h, w, cx + c_up, c_up, cout, k, stride, 1 if act else 0)
-    if out_f32:
-        y = torch.empty((n, h // stride, w // stride, cout), dtype=torch.float32, device=xp.device)
-    else:
-        y = torch.empty((planes, n, h // stride, w // stride, cout), dtype=torch.bfloat16, device=xp.device)
-    L = _lib.lib()
-    ws, ws_bytes = None, 0
-    if use_workspace:
-        ws_bytes = L.y3_conv_workspace_bytes(ctypes.byref(d))
-        ws = _conv_scratch(xp.device, ws_bytes) if ws_bytes else None
-    _lib.check(L.y3_conv2d_fwd_planes(fw.context(xp.device), ctypes.byref(d), int(planes), fw.ptr(xp), fw.ptr(x_up),
-                                      fw.ptr(w_split), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual), fw.ptr(y),
-                                      1 if out_f32 else 0, fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
-    return y
-
-
 def upsample_nearest(x, out_h, out_w):
     n, h, w, c = x.shape
     y = torch.empty((n, out_h, out_w, c), dtype=torch.float32, device=x.device)
