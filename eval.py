@@ -1,0 +1,139 @@
+# coding: utf-8
+"""Twin of the reference's eval.py (same command line, same printed report) on the MI355X-native path.
+
+What changes underneath: the reference evaluates ONE image per `sess.run`, pulls the decoded
+predictions to the host and feeds them back for a second `sess.run` of the NMS op; here a batch of `--batch_size`
+images goes forward -> decode -> per-class NMS on the device in one launch set (`yolov3.detect` building blocks),
+the loss of the batch is computed on the device from `process_box_batch` targets, and only the surviving detections
+cross to the host.  Weights: a darknet `.weights` file (`--restore_path`; the reference restores a TF checkpoint
+converted from the same file).  Images are read with PIL; `--letterbox_resize true` uses the cv2-INTER_NEAREST-exact
+letterbox of utils.data_utils, otherwise PIL bilinear (cv2.INTER_LINEAR in the reference: same geometry, pixel values
+may differ in the last bit).
+"""
+from __future__ import division, print_function
+
+import argparse
+import sys
+
+import numpy as np
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="YOLO-V3 eval procedure.")
+    # some paths
+    parser.add_argument("--eval_file", type=str, default="./data/my_data/val.txt",
+                        help="The path of the validation or test txt file.")
+    parser.add_argument("--restore_path", type=str, default="./data/darknet_weights/yolov3.weights",
+                        help="The path of the darknet weights to restore.")
+    parser.add_argument("--anchor_path", type=str, default="./data/yolo_anchors.txt",
+                        help="The path of the anchor txt file.")
+    parser.add_argument("--class_name_path", type=str, default="./data/coco.names",
+                        help="The path of the class names.")
+    # some numbers
+    parser.add_argument("--img_size", nargs='*', type=int, default=[416, 416],
+                        help="Resize the input image to `img_size`, size format: [width, height]")
+    parser.add_argument("--letterbox_resize", type=lambda x: (str(x).lower() == 'true'), default=False,
+                        help="Whether to use the letterbox resize, i.e., keep the original image aspect ratio.")
+    parser.add_argument("--num_threads", type=int, default=10, help="(accepted for compatibility; unused)")
+    parser.add_argument("--prefetech_buffer", type=int, default=5, help="(accepted for compatibility; unused)")
+    parser.add_argument("--nms_threshold", type=float, default=0.45, help="IOU threshold in nms operation.")
+    parser.add_argument("--score_threshold", type=float, default=0.01,
+                        help="Threshold of the probability of the classes in nms operation.")
+    parser.add_argument("--nms_topk", type=int, default=400, help="Keep at most nms_topk outputs after nms.")
+    parser.add_argument("--use_voc_07_metric", type=lambda x: (str(x).lower() == 'true'), default=False,
+                        help="Whether to use the voc 2007 mAP metrics.")
+    # additions
+    parser.add_argument("--batch_size", type=int, default=32, help="Images per device batch (the reference uses 1).")
+    parser.add_argument("--compute_dtype", type=str, default="f32", help="f32 | f32_bf16x6 (see DESIGN.md 4.3)")
+    return parser
+
+
+def load_image(path, line_boxes, img_size, letterbox):
+    """PIL read + resize to img_size [w, h]; returns (float32 RGB image in [0,1], boxes mapped to the new frame)."""
+    from PIL import Image
+    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize
+    img = np.asarray(Image.open(path).convert('RGB'))
+    h0, w0 = img.shape[:2]
+    boxes = np.array(line_boxes, np.float32).reshape(-1, 4)
+    if letterbox:
+        img, ratio, dw, dh = letterbox_resize(img, img_size[0], img_size[1])
+        boxes = boxes * ratio
+        boxes[:, [0, 2]] += dw
+        boxes[:, [1, 3]] += dh
+    else:
+        img = np.asarray(Image.fromarray(img).resize((img_size[0], img_size[1]), Image.BILINEAR))
+        boxes[:, [0, 2]] *= img_size[0] / float(w0)
+        boxes[:, [1, 3]] *= img_size[1] / float(h0)
+    return np.asarray(img, np.float32) / 255., boxes
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import torch
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd.utils.data_utils import parse_line, process_box_batch
+    from yolov3_tensorflow_amd.utils.eval_utils import get_preds_batch, voc_eval, parse_gt_rec
+    from yolov3_tensorflow_amd.utils import eval_utils
+    from yolov3_tensorflow_amd.utils.misc_utils import (parse_anchors, read_class_names, AverageMeter, load_weights,
+                                                        run_ops)
+    from yolov3_tensorflow_amd.utils.nms_utils import gpu_nms_batched
+
+    args.anchors = parse_anchors(args.anchor_path)
+    args.classes = read_class_names(args.class_name_path)
+    args.class_num = len(args.classes)
+    lines = [l for l in open(args.eval_file, 'r').readlines() if l.strip()]
+    args.img_cnt = len(lines)
+
+    yolo_model = y3.yolov3(args.class_num, args.anchors)
+    yolo_model.compute_dtype = args.compute_dtype
+    with y3.variable_scope('yolov3'):
+        yolo_model.forward(torch.zeros((1, 64, 64, 3)), False)            # create the variables
+        run_ops(load_weights(y3.global_variables(scope='yolov3'), args.restore_path))
+
+    print('\n----------- start to eval -----------\n')
+    meters = [AverageMeter() for _ in range(5)]      # total, xy, wh, conf, class
+    val_preds = []
+    for start in range(0, args.img_cnt, args.batch_size):
+        chunk = [parse_line(l) for l in lines[start:start + args.batch_size]]
+        n = len(chunk)
+        kmax = max(len(c[3]) for c in chunk)
+        images = np.zeros((n, args.img_size[1], args.img_size[0], 3), np.float32)
+        boxes = np.zeros((n, kmax, 5), np.float32)
+        labels = np.zeros((n, kmax), np.int64)
+        counts = np.zeros((n,), np.int64)
+        for i, (_, pic_path, b, l, _, _) in enumerate(chunk):
+            images[i], nb = load_image(pic_path, b, args.img_size, args.letterbox_resize)
+            k = len(l)
+            boxes[i, :k, :4], boxes[i, :k, 4], labels[i, :k], counts[i] = nb, 1.0, l, k     # mix-up weight 1
+        y_true = process_box_batch(boxes, labels, counts, args.img_size, args.class_num, args.anchors)
+        with y3.variable_scope('yolov3'):
+            fms = yolo_model.forward(images, False)
+        loss = yolo_model.compute_loss(fms, y_true)
+        pb, _, _, ps = yolo_model.predict(fms, with_scores=True)
+        dets = gpu_nms_batched(pb, ps, args.class_num, args.nms_topk, args.score_threshold, args.nms_threshold)
+        val_preds.extend(get_preds_batch([c[0] for c in chunk], dets))
+        for m, v in zip(meters, loss):
+            m.update(float(v), n)
+
+    rec_total, prec_total, ap_total = AverageMeter(), AverageMeter(), AverageMeter()
+    eval_utils.gt_dict = {}
+    gt_dict = parse_gt_rec(args.eval_file, args.img_size, args.letterbox_resize)
+    print('mAP eval:')
+    for ii in range(args.class_num):
+        npos, nd, rec, prec, ap = voc_eval(gt_dict, val_preds, ii, iou_thres=0.5,
+                                           use_07_metric=args.use_voc_07_metric)
+        rec_total.update(rec, npos)
+        prec_total.update(prec, nd)
+        ap_total.update(ap, 1)
+        print('Class {}: Recall: {:.4f}, Precision: {:.4f}, AP: {:.4f}'.format(ii, rec, prec, ap))
+
+    mAP = ap_total.average
+    print('final mAP: {:.4f}'.format(mAP))
+    print("recall: {:.3f}, precision: {:.3f}".format(rec_total.average, prec_total.average))
+    print("total_loss: {:.3f}, loss_xy: {:.3f}, loss_wh: {:.3f}, loss_conf: {:.3f}, loss_class: {:.3f}".format(
+        *[m.average for m in meters]))
+    return {'mAP': mAP, 'val_preds': val_preds, 'loss': [m.average for m in meters], 'gt_dict': gt_dict}
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])

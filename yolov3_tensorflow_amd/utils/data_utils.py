@@ -1,7 +1,8 @@
 # coding: utf-8
 """The slice of the reference's utils/data_utils.py / utils/data_aug.py that sits immediately either side of
-the hot path: target assignment (`process_box`, on the device, batched) and the
-OpenCV-free letterbox used by the single-image path.  Augmentation and file parsing stay out of scope."""
+the hot path: annotation-line parsing (`parse_line`), target assignment (`process_box`,
+on the device, batched) and the OpenCV-free letterbox used by the single-image and eval paths.  Augmentation
+stays out of scope."""
 from __future__ import division, print_function
 
 import ctypes
@@ -11,6 +12,34 @@ import torch
 
 from .. import _lib
 from .. import framework as fw
+
+
+def parse_line(line):
+    '''
+    Given a line from the training/test txt file, return parsed info (reference utils/data_utils.py:15-48).
+    line format: line_index, img_path, img_width, img_height, [box_info_1 (5 number)], ...
+    return:
+        line_idx: int
+        pic_path: string.
+        boxes: shape [N, 4] float32, [x_min, y_min, x_max, y_max] per ground-truth object
+        labels: shape [N] int64, class index.
+        img_width: int.
+        img_height: int
+    '''
+    if isinstance(line, bytes):
+        line = line.decode()
+    fields = line.strip().split(' ')
+    assert len(fields) > 8, ('Annotation error! Please check your annotation file. Make sure there is at least one '
+                             'target object in each image.')
+    line_idx, pic_path = int(fields[0]), fields[1]
+    img_width, img_height = int(fields[2]), int(fields[3])
+    obj = fields[4:]
+    assert len(obj) % 5 == 0, ('Annotation error! Please check your annotation file. Maybe partially missing some '
+                               'coordinates?')
+    table = np.array(obj, dtype=object).reshape(-1, 5)
+    labels = np.asarray([int(v) for v in table[:, 0]], np.int64)
+    boxes = np.asarray([[float(v) for v in row] for row in table[:, 1:]], np.float32).reshape(-1, 4)
+    return line_idx, pic_path, boxes, labels, img_width, img_height
 
 
 def process_box(boxes, labels, img_size, class_num, anchors):
