@@ -1,0 +1,292 @@
+# coding: utf-8
+"""Twin of the reference's train.py on the MI355X-native path (BASELINE configs[3]).
+
+Same training recipe and the same names as the reference's args.py (every variable of args.py is a command-line
+option with the reference's default): restore (darknet weights, with `restore_include` / `restore_exclude` scope
+filters), `update_part` fine-tuning, warm-up + the five learning-rate schedules, the four optimizers, per-tensor
+clip_by_norm(100), L2 weight decay, label smoothing / focal loss, periodic recall/precision on the training batch
+(`evaluate_on_gpu`), periodic mAP on the validation file (`voc_eval`), multi-scale training.  One `Trainer.step` =
+forward(is_training=True) -> compute_loss -> backward -> clip -> update, all on the device; under
+`python -m torch.distributed.run --nproc-per-node N train.py ...` every rank trains on its shard of each batch and
+the flat gradient buffer is all-reduced over RCCL.
+
+What it does not have (out of scope): the cv2 augmentation pipeline (random colour distortion, expand,
+crop, flip) and mix-up, TensorBoard summaries, TF checkpoints — weights are saved as darknet `.weights` files.
+Images are read with PIL and resized with the cv2-INTER_NEAREST-exact letterbox (`letterbox_resize`) or PIL bilinear.
+"""
+from __future__ import division, print_function
+
+import argparse
+import logging
+import math
+import os
+import random
+import sys
+
+import numpy as np
+
+
+def _bool(x):
+    return str(x).lower() == 'true'
+
+
+def _scopes(x):
+    return None if x in (None, '', 'None', 'none') else [s for s in x.split(',') if s]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="YOLO-V3 training procedure (options = the variables of args.py).")
+    # paths
+    p.add_argument('--train_file', default='./data/my_data/train.txt')
+    p.add_argument('--val_file', default='./data/my_data/val.txt')
+    p.add_argument('--restore_path', default='./data/darknet_weights/yolov3.weights',
+                   help="darknet weights to start from ('' = random initialisation)")
+    p.add_argument('--save_dir', default='./checkpoint/')
+    p.add_argument('--progress_log_path', default='./data/progress.log')
+    p.add_argument('--anchor_path', default='./data/yolo_anchors.txt')
+    p.add_argument('--class_name_path', default='./data/coco.names')
+    # training numbers
+    p.add_argument('--batch_size', type=int, default=6)
+    p.add_argument('--img_size', nargs=2, type=int, default=[416, 416], help='[width, height]')
+    p.add_argument('--letterbox_resize', type=_bool, default=True)
+    p.add_argument('--total_epoches', type=int, default=100)
+    p.add_argument('--train_evaluation_step', type=int, default=100)
+    p.add_argument('--val_evaluation_epoch', type=int, default=2)
+    p.add_argument('--save_epoch', type=int, default=10)
+    p.add_argument('--batch_norm_decay', type=float, default=0.99)
+    p.add_argument('--weight_decay', type=float, default=5e-4)
+    p.add_argument('--global_step', type=int, default=0)
+    # learning rate and optimizer
+    p.add_argument('--optimizer_name', default='momentum', help='sgd | momentum | adam | rmsprop')
+    p.add_argument('--learning_rate_init', type=float, default=1e-4)
+    p.add_argument('--lr_type', default='piecewise',
+                   help='fixed | exponential | cosine_decay | cosine_decay_restart | piecewise')
+    p.add_argument('--lr_decay_epoch', type=float, default=5)
+    p.add_argument('--lr_decay_factor', type=float, default=0.96)
+    p.add_argument('--lr_lower_bound', type=float, default=1e-6)
+    p.add_argument('--pw_boundaries', nargs='*', type=float, default=[30, 50], help='epoch based boundaries')
+    p.add_argument('--pw_values', nargs='*', type=float, default=None,
+                   help='default [learning_rate_init, 3e-5, 1e-5]')
+    # load and finetune
+    p.add_argument('--restore_include', type=_scopes, default=None, help='comma separated scopes, or None')
+    p.add_argument('--restore_exclude', type=_scopes,
+                   default=['yolov3/yolov3_head/Conv_14', 'yolov3/yolov3_head/Conv_6', 'yolov3/yolov3_head/Conv_22'])
+    p.add_argument('--update_part', type=_scopes, default=['yolov3/yolov3_head'],
+                   help="comma separated scopes to train; 'None' = the whole model")
+    # other strategies
+    p.add_argument('--multi_scale_train', type=_bool, default=True)
+    p.add_argument('--use_label_smooth', type=_bool, default=True)
+    p.add_argument('--use_focal_loss', type=_bool, default=True)
+    p.add_argument('--use_warm_up', type=_bool, default=True)
+    p.add_argument('--warm_up_epoch', type=float, default=3)
+    # validation constants
+    p.add_argument('--nms_threshold', type=float, default=0.45)
+    p.add_argument('--score_threshold', type=float, default=0.01)
+    p.add_argument('--nms_topk', type=int, default=150)
+    p.add_argument('--eval_threshold', type=float, default=0.5)
+    p.add_argument('--use_voc_07_metric', type=_bool, default=False)
+    p.add_argument('--seed', type=int, default=0)
+    return p
+
+
+def in_scopes(name, scopes):
+    return any(name == s or name.startswith(s + '/') for s in scopes)
+
+
+def variables_to_restore(variables, include, exclude):
+    """tf.contrib.framework.get_variables_to_restore(include, exclude) on our variable list (train.py:81)."""
+    keep = variables if include is None else [v for v in variables if in_scopes(v.op_name, include)]
+    return keep if exclude is None else [v for v in keep if not in_scopes(v.op_name, exclude)]
+
+
+def load_batch(lines, img_size, letterbox):
+    """Annotation lines -> (image ids, images [n,h,w,3] float32 in [0,1], boxes [n,kmax,5], labels, counts)."""
+    from eval import load_image
+    from yolov3_tensorflow_amd.utils.data_utils import parse_line
+    recs = [parse_line(l) for l in lines]
+    n, kmax = len(recs), max(len(r[3]) for r in recs)
+    images = np.zeros((n, img_size[1], img_size[0], 3), np.float32)
+    boxes = np.zeros((n, kmax, 5), np.float32)
+    labels = np.zeros((n, kmax), np.int64)
+    counts = np.zeros((n,), np.int64)
+    for i, (_, path, b, l, _, _) in enumerate(recs):
+        images[i], nb = load_image(path, b, img_size, letterbox)
+        k = len(l)
+        boxes[i, :k, :4], boxes[i, :k, 4], labels[i, :k], counts[i] = nb, 1.0, l, k       # mix-up weight 1
+    return [r[0] for r in recs], images, boxes, labels, counts
+
+
+def validate(model, y3, args, lines):
+    """mAP / recall / precision / losses over the validation file (train.py:171-214), batched on the device."""
+    from yolov3_tensorflow_amd.utils import eval_utils
+    from yolov3_tensorflow_amd.utils.data_utils import process_box_batch
+    from yolov3_tensorflow_amd.utils.misc_utils import AverageMeter
+    from yolov3_tensorflow_amd.utils.nms_utils import gpu_nms_batched
+    meters = [AverageMeter() for _ in range(5)]
+    val_preds = []
+    for s in range(0, len(lines), args.batch_size):
+        ids, images, boxes, labels, counts = load_batch(lines[s:s + args.batch_size], args.img_size,
+                                                        args.letterbox_resize)
+        y_true = process_box_batch(boxes, labels, counts, args.img_size, args.class_num, args.anchors)
+        with y3.variable_scope('yolov3'):
+            fms = model.forward(images, False)
+        loss = model.compute_loss(fms, y_true)
+        pb, _, _, ps = model.predict(fms, with_scores=True)
+        dets = gpu_nms_batched(pb, ps, args.class_num, args.nms_topk, args.score_threshold, args.nms_threshold)
+        val_preds.extend(eval_utils.get_preds_batch(ids, dets))
+        for m, v in zip(meters, loss):
+            m.update(float(v), len(ids))
+    eval_utils.gt_dict = {}
+    gt = eval_utils.parse_gt_rec(args.val_file, args.img_size, args.letterbox_resize)
+    rec_total, prec_total, ap_total = AverageMeter(), AverageMeter(), AverageMeter()
+    info = ''
+    for ii in range(args.class_num):
+        npos, nd, rec, prec, ap = eval_utils.voc_eval(gt, val_preds, ii, iou_thres=args.eval_threshold,
+                                                      use_07_metric=args.use_voc_07_metric)
+        info += 'EVAL: Class {}: Recall: {:.4f}, Precision: {:.4f}, AP: {:.4f}\n'.format(ii, rec, prec, ap)
+        rec_total.update(rec, npos)
+        prec_total.update(prec, nd)
+        ap_total.update(ap, 1)
+    info += 'EVAL: Recall: {:.4f}, Precison: {:.4f}, mAP: {:.4f}\n'.format(rec_total.average, prec_total.average,
+                                                                          ap_total.average)
+    info += 'EVAL: loss: total: {:.2f}, xy: {:.2f}, wh: {:.2f}, conf: {:.2f}, class: {:.2f}\n'.format(
+        *[m.average for m in meters])
+    return ap_total.average, rec_total.average, prec_total.average, [m.average for m in meters], info
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import functools
+    import torch
+    import torch.distributed as dist
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils.data_utils import process_box_batch
+    from yolov3_tensorflow_amd.utils.eval_utils import evaluate_on_gpu
+    from yolov3_tensorflow_amd.utils.misc_utils import (parse_anchors, read_class_names, AverageMeter,
+                                                        config_learning_rate, config_optimizer, load_weights,
+                                                        save_weights, run_ops)
+    from yolov3_tensorflow_amd.utils.nms_utils import gpu_nms
+
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        y3.set_default_device('cuda:%d' % local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+
+    # ---- the derived parameters of args.py:79-86 ----
+    args.anchors = parse_anchors(args.anchor_path)
+    args.classes = read_class_names(args.class_name_path)
+    args.class_num = len(args.classes)
+    train_lines = [l for l in open(args.train_file, 'r').readlines() if l.strip()]
+    val_lines = [l for l in open(args.val_file, 'r').readlines() if l.strip()]
+    args.train_img_cnt, args.val_img_cnt = len(train_lines), len(val_lines)
+    args.train_batch_num = int(math.ceil(float(args.train_img_cnt) / args.batch_size))
+    args.lr_decay_freq = int(args.train_batch_num * args.lr_decay_epoch)
+    if args.pw_values is None:
+        args.pw_values = [args.learning_rate_init, 3e-5, 1e-5]
+    args.pw_boundaries = [float(i) * args.train_batch_num + args.global_step for i in args.pw_boundaries]
+
+    log = logging.getLogger('yolo355.train')
+    log.setLevel(logging.DEBUG)
+    if rank == 0 and args.progress_log_path:
+        os.makedirs(os.path.dirname(os.path.abspath(args.progress_log_path)), exist_ok=True)
+        handler = logging.FileHandler(args.progress_log_path, mode='w')
+        handler.setFormatter(logging.Formatter('%(asctime)s %(levelname)s %(message)s', '%a, %d %b %Y %H:%M:%S'))
+        log.handlers = [handler]
+
+    random.seed(args.seed)
+    y3.set_init_seed(args.seed)
+    yolo_model = y3.yolov3(args.class_num, args.anchors, args.use_label_smooth, args.use_focal_loss,
+                           args.batch_norm_decay, args.weight_decay, use_static_shape=False)
+    with y3.variable_scope('yolov3'):
+        yolo_model.forward(torch.zeros((1, 64, 64, 3)), False)                 # create the variables
+    variables = y3.global_variables(scope='yolov3')
+    if args.restore_path:
+        restore = set(v.op_name for v in variables_to_restore(variables, args.restore_include, args.restore_exclude))
+        run_ops([op for op in load_weights(variables, args.restore_path) if op.var.op_name in restore])
+    update_vars = None if args.update_part is None else variables_to_restore(variables, args.update_part, None)
+
+    # learning rate: warm-up ramp, then the configured schedule shifted by the warm-up length (train.py:93-99)
+    warm = args.train_batch_num * args.warm_up_epoch
+
+    def learning_rate(global_step):
+        if args.use_warm_up and global_step < warm:
+            return args.learning_rate_init * global_step / warm
+        return config_learning_rate(args, global_step - warm if args.use_warm_up else global_step)
+
+    optimizer = config_optimizer(args.optimizer_name, learning_rate)
+    trainer = training.Trainer(yolo_model, optimizer, update_vars=update_vars, global_step=float(args.global_step),
+                               process_group=dist.group.WORLD if world > 1 else None)
+    gpu_nms_op = functools.partial(gpu_nms, num_classes=args.class_num, max_boxes=args.nms_topk,
+                                   score_thresh=args.score_threshold, nms_thresh=args.nms_threshold)
+    if rank == 0:
+        print('\n----------- start to train -----------\n')
+    best_mAP = -np.inf
+    history = {'loss': [], 'recall': [], 'mAP': []}
+    size = list(args.img_size)
+    for epoch in range(args.total_epoches):
+        order = list(range(args.train_img_cnt))
+        random.shuffle(order)                                                  # same order on every rank (seeded)
+        meters = [AverageMeter() for _ in range(5)]
+        for i in range(args.train_batch_num):
+            if args.multi_scale_train and i % 10 == 0:
+                side = random.randint(10, 20) * 32                             # 320 .. 640, like get_batch_data
+                size = [side, side]
+            elif not args.multi_scale_train:
+                size = list(args.img_size)
+            idx = order[i * args.batch_size:(i + 1) * args.batch_size][rank::world]
+            if not idx:
+                idx = order[:1]
+            _, images, boxes, labels, counts = load_batch([train_lines[j] for j in idx], size, args.letterbox_resize)
+            y_true = process_box_batch(boxes, labels, counts, size, args.class_num, args.anchors)
+            with y3.variable_scope('yolov3'):
+                loss = trainer.step(images, y_true)
+            n = len(idx)
+            for m, v in zip(meters, loss):
+                m.update(float(v), n)
+            history['loss'].append(float(loss[0]))
+            gs, lr = trainer.global_step, learning_rate(trainer.global_step - 1)
+            if gs % args.train_evaluation_step == 0 and gs > 0:
+                with y3.variable_scope('yolov3'):
+                    y_pred = yolo_model.predict(yolo_model.forward(images, False))
+                recall, precision = evaluate_on_gpu(None, gpu_nms_op, None, None, y_pred, y_true, args.class_num,
+                                                    args.nms_threshold)
+                history['recall'].append(recall)
+                info = "Epoch: {}, global_step: {} | loss: total: {:.2f}, xy: {:.2f}, wh: {:.2f}, conf: {:.2f}, " \
+                       "class: {:.2f} | ".format(epoch, int(gs), *[m.average for m in meters])
+                info += 'Last batch: rec: {:.3f}, prec: {:.3f} | lr: {:.5g}'.format(recall, precision, lr)
+                if rank == 0:
+                    print(info)
+                    log.info(info)
+                if np.isnan(meters[0].average):
+                    print('****' * 10)
+                    raise ArithmeticError(
+                        'Gradient exploded! Please train again and you may need modify some parameters.')
+        if rank == 0 and epoch % args.save_epoch == 0 and epoch > 0 and meters[0].average <= 2.:
+            os.makedirs(args.save_dir, exist_ok=True)
+            save_weights(variables, os.path.join(args.save_dir, 'model-epoch_{}_step_{}_loss_{:.4f}_lr_{:.5g}.weights'
+                                                 .format(epoch, int(trainer.global_step), meters[0].average, lr)))
+        if epoch % args.val_evaluation_epoch == 0 and epoch >= args.warm_up_epoch:
+            mAP, rec, prec, vloss, info = validate(yolo_model, y3, args, val_lines)
+            history['mAP'].append(mAP)
+            info = '======> Epoch: {}, global_step: {}, lr: {:.6g} <======\n'.format(epoch, trainer.global_step, lr) + info
+            if rank == 0:
+                print(info)
+                log.info(info)
+                if mAP > best_mAP:
+                    best_mAP = mAP
+                    os.makedirs(args.save_dir, exist_ok=True)
+                    save_weights(variables, os.path.join(
+                        args.save_dir, 'best_model_Epoch_{}_step_{}_mAP_{:.4f}_loss_{:.4f}_lr_{:.7g}.weights'.format(
+                            epoch, int(trainer.global_step), best_mAP, vloss[0], lr)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return history
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
