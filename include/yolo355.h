@@ -220,6 +220,13 @@ int y3_bias_grad(y3_ctx* ctx, const float* dy, long long rows, int c, float* dbi
 int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride, const float* w_d,
                     const float* ones, const float* zeros, int accumulate, float* dx, void* workspace,
                     size_t workspace_bytes);
+/* The same data gradient on the bf16 matrix pipe (stride-1 convs; see y3_conv2d_fwd_split): w_split_d comes from
+ * y3_pack_conv_weights_split_dgrad(w_d = the [k*k][cin][dz_stride] kernel above). */
+int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int cin, int dz_stride, int planes,
+                                     void* w_split_d);
+int y3_conv2d_dgrad_split(y3_ctx* ctx, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
+                          const void* w_split_d, const float* ones, const float* zeros, int accumulate, float* dx,
+                          void* workspace, size_t workspace_bytes);
 size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* fwd);
 int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,
                   float* dw_hwio, void* scratch, size_t scratch_bytes);

@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--optimizer', default='sgd')
     ap.add_argument('--head-only', action='store_true')
+    ap.add_argument('--precision', default='f32', help='f32 | f32_bf16x6 (forward + stride-1 dgrad on the bf16 pipe)')
     a = ap.parse_args()
     import torch
     import yolov3_tensorflow_amd as y3
@@ -49,6 +50,7 @@ def main():
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
     import bench
     model = y3.yolov3(80, bench.ANCHORS, batch_norm_decay=0.99)
+    model.compute_dtype = a.precision
     x = torch.rand((a.batch, a.size, a.size, 3), device='cuda')
     yt = synthetic_y_true(a.batch, a.size, 80, bench.ANCHORS, 0, 'cuda')
     with y3.variable_scope('yolov3'):
@@ -69,8 +71,8 @@ def main():
     flops = 3 * bench.conv_flops(model._train['topo_table'] if 'topo_table' in model._train else
                                  [(l['k'], l['stride'], l['cin'], l['cout'], l['bn']) for l in model._train['topo'].layers],
                                  a.batch, a.size, a.size).sum()
-    print('train step: batch %d @%d, %s%s: %.1f ms/step, %.1f images/s, %.1f TFLOP/s (3x forward FLOPs), loss %.3f, peak mem %.1f GB'
-          % (a.batch, a.size, a.optimizer, ' head-only' if a.head_only else '', dt * 1e3, a.batch / dt,
+    print('train step [%s]: batch %d @%d, %s%s: %.1f ms/step, %.1f images/s, %.1f TFLOP/s (3x forward FLOPs), loss %.3f, peak mem %.1f GB'
+          % (a.precision, a.batch, a.size, a.optimizer, ' head-only' if a.head_only else '', dt * 1e3, a.batch / dt,
              flops / dt / 1e12, float(loss[0]), torch.cuda.max_memory_allocated() / 1e9))
 
 

@@ -31,6 +31,9 @@ PROTOTYPES = {
     "y3_pack_conv_weights_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_conv2d_fwd_split": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "y3_pack_conv_weights_split_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "y3_conv2d_dgrad_split": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_void_p, c_void_p, c_size_t]),
     "y3_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_conv2d_fwd_bf16": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int]),

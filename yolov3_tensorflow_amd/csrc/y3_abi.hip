@@ -64,6 +64,24 @@ extern "C" int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int plane
                                 workspace_bytes);
 }
 
+extern "C" int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int cin, int dz_stride,
+                                                int planes, void* w_split) {
+    Y3_CHECK_ARG(ctx && w_d && w_split, "y3_pack_conv_weights_split_dgrad: null argument");
+    Y3_CHECK_ARG((k == 1 || k == 3) && cin > 0 && dz_stride > 0 && dz_stride % 16 == 0,
+                 "y3_pack_conv_weights_split_dgrad: k must be 1 or 3 and dz_stride a positive multiple of 16");
+    Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_pack_conv_weights_split_dgrad: planes must be 2 or 3 (got %d)", planes);
+    // the gradient conv's K axis is dz_stride, its output axis the forward cin: read [k*k][cin][dz_stride] transposed
+    return y3_launch_pack_split(ctx->stream, w_d, k, dz_stride, cin, planes, w_split, 1);
+}
+
+extern "C" int y3_conv2d_dgrad_split(y3_ctx* ctx, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
+                                     const void* w_split_d, const float* ones, const float* zeros, int accumulate,
+                                     float* dx, void* workspace, size_t workspace_bytes) {
+    Y3_CHECK_ARG(ctx, "y3_conv2d_dgrad_split: null context");
+    return y3_launch_conv_dgrad_split(ctx->stream, fwd, planes, dz, dz_stride, w_split_d, ones, zeros, accumulate, dx,
+                                      workspace, workspace_bytes);
+}
+
 extern "C" int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                                const float* w_d, const float* ones, const float* zeros, int accumulate,
                                float* dx, void* workspace, size_t workspace_bytes) {

@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
                 ra[s][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[j], soff, 0));
         }
         // weights are packed [tap][Cin/16][plane][Cout][16]: one K-step's B tile is contiguous per plane
-        const unsigned wsoff = (unsigned)((ld_tap * kchunks + ld_cc) * NP) * wplane;
+        const int wtap = p.wrev ? taps - 1 - ld_tap : ld_tap;   // data gradient: the flipped kernel
+        const unsigned wsoff = (unsigned)((wtap * kchunks + ld_cc) * NP) * wplane;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
             rb[s][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff, wsoff + pl * wplane, 0);
@@ -361,9 +362,11 @@ int launch_np(hipStream_t stream, const y3_conv_desc* d, ConvArgs& a, void* work
 }
 
 __global__ void pack_weights_split_kernel(const float* __restrict__ w_hwio, unsigned short* __restrict__ out,
-                                          int taps, int cin, int cout, int planes) {
-    // out[t][ci/16][pl][co][ci%16] = plane pl of in[t][ci][co]: the B tile of one K-step (16 input channels) is
-    // contiguous per plane, so a workgroup's weight loads are whole cache lines
+                                          int taps, int cin, int cout, int planes, int s_ci, int s_co) {
+    // out[t][ci/16][pl][co][ci%16] = plane pl of in[t*cin*cout + ci*s_ci + co*s_co]: the B tile of one K-step (16
+    // input channels) is contiguous per plane, so a workgroup's weight loads are whole cache lines.
+    // (s_ci, s_co) = (cout, 1) reads an HWIO kernel; (1, cin) reads it as the data-gradient conv does:
+    // [tap][Cout' = forward cin][Cin' = forward cout].
     const size_t total = (size_t)taps * cin * cout;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -371,7 +374,7 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w_hwio, unsi
         const size_t r = i / cin;
         const int co = (int)(r % cout);
         const int t = (int)(r / cout);
-        float rem = w_hwio[((size_t)t * cin + ci) * cout + co];
+        float rem = w_hwio[(size_t)t * cin * cout + (size_t)ci * s_ci + (size_t)co * s_co];
         for (int pl = 0; pl < planes; ++pl) {
             unsigned u = __float_as_uint(rem);
             if (planes == 2 && pl == 1) u += 0x7fffu + ((u >> 16) & 1u);
@@ -414,11 +417,15 @@ void fill_args(ConvArgs& a, const y3_conv_desc* d) {
 
 }  // namespace
 
-int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out) {
+// transposed == 0: w is HWIO [k*k][cin][cout].  transposed != 0: w is [k*k][cout][cin] (what the data gradient of a
+// forward conv with kernel [k*k][cout][cin'=cin] reads: its "Cin" is the forward Cout).
+int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out,
+                         int transposed) {
     const size_t total = (size_t)k * k * cin * cout;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weights_split_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio,
-                       static_cast<unsigned short*>(out), k * k, cin, cout, planes);
+                       static_cast<unsigned short*>(out), k * k, cin, cout, planes, transposed ? 1 : cout,
+                       transposed ? cin : 1);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
@@ -440,4 +447,32 @@ int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, 
     fill_args(a, d);
     return planes == 3 ? launch_np<3>(stream, d, a, workspace, workspace_bytes, mid_event)
                        : launch_np<2>(stream, d, a, workspace, workspace_bytes, mid_event);
+}
+
+// Data gradient of a stride-1 conv on the split kernel: dx (+)= conv_same(dz, flipped kernel).  `w` is the
+// transposed split packing of the [k*k][cin][dz_stride] kernel (y3_pack_conv_weights_split with transposed = 1:
+// its K axis is dz_stride, its output axis the forward cin).  Stride-2 layers use the exact kernel's parity classes.
+int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
+                               const void* w, const float* ones, const float* zeros, int accumulate, float* dx,
+                               void* workspace, size_t workspace_bytes) {
+    Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_conv2d_dgrad_split: planes must be 2 or 3 (got %d)", planes);
+    Y3_CHECK_ARG(fwd && dz && w && ones && zeros && dx, "y3_conv2d_dgrad_split: null pointer argument");
+    Y3_CHECK_ARG((fwd->k == 1 || fwd->k == 3) && fwd->stride == 1, "y3_conv2d_dgrad_split: only stride-1 1x1 / 3x3 convs");
+    Y3_CHECK_ARG(fwd->c_up == 0, "y3_conv2d_dgrad_split: fused upsample+concat inputs are not supported");
+    Y3_CHECK_ARG(dz_stride >= fwd->cout && dz_stride % (2 * SBK) == 0,
+                 "y3_conv2d_dgrad_split: dz stride must be a multiple of %d", 2 * SBK);
+    Y3_CHECK_ARG(fwd->cin % 4 == 0 && fwd->n > 0 && fwd->h > 0 && fwd->w > 0,
+                 "y3_conv2d_dgrad_split: Cin must be a multiple of 4");
+    y3_conv_desc d = *fwd;              // the gradient conv: [n,h,w,dz_stride] -> [n,h,w,cin]
+    d.cin = dz_stride; d.c_up = 0; d.cout = fwd->cin; d.act = 0;
+    const long long M = (long long)fwd->n * fwd->h * fwd->w;
+    Y3_CHECK_ARG(M * fwd->cin < (1LL << 29) && M * dz_stride < (1LL << 29),
+                 "y3_conv2d_dgrad_split: tensor exceeds 2^29 elements (32-bit byte offsets)");
+    ConvArgs a;
+    a.x = dz; a.xu = nullptr; a.w = static_cast<const float*>(w); a.scale = ones; a.shift = zeros;
+    a.resid = accumulate ? dx : nullptr; a.y = dx;
+    fill_args(a, &d);
+    a.wrev = 1;
+    return planes == 3 ? launch_np<3>(stream, &d, a, workspace, workspace_bytes, nullptr)
+                       : launch_np<2>(stream, &d, a, workspace, workspace_bytes, nullptr);
 }

@@ -44,7 +44,11 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
                          void* workspace, size_t workspace_bytes);
 int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                         const float* scale, const float* shift, const void* residual, void* y, int out_f32);
-int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out);
+int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out,
+                         int transposed = 0);
+int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
+                               const void* w, const float* ones, const float* zeros, int accumulate, float* dx,
+                               void* workspace, size_t workspace_bytes);
 int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, const float* x, const float* x_up,
                          const void* w, const float* scale, const float* shift, const float* residual, float* y,
                          void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);

@@ -104,20 +104,34 @@ def _consts(st, c, device):
     return v
 
 
-def _packed_weights(st, wvar):
-    """[tap][Cout][Cin] re-pack of the HWIO variable for the forward conv, refreshed when the variable changes."""
-    hit = st['packed'].get(wvar.op_name)
+def _planes(model):
+    """3 / 2 when the model computes its convs on the bf16 matrix pipe (compute_dtype 'f32_bf16x6' / 'f32_bf16x3'):
+    the training forward and the stride-1 data gradients then use the split kernels too (weight gradients and the
+    stride-2 data gradients stay on the exact fp32 kernels)."""
+    return engine.SPLIT_PLANES.get(getattr(model, 'compute_dtype', 'f32'), 0)
+
+
+def _packed_weights(st, wvar, planes=0):
+    """[tap][Cout][Cin] re-pack of the HWIO variable for the forward conv (or its split-plane packing), refreshed
+    when the variable changes."""
+    key = wvar.op_name + ('#%d' % planes if planes else '')
+    hit = st['packed'].get(key)
     if hit is not None and hit[0] == wvar.version:
         return hit[1]
     k, _, cin, cout = wvar.shape
     if cin == 3:
         wp = wvar.tensor
+    elif planes:
+        wp = hit[1] if hit is not None else torch.empty(planes * k * k * cout * cin, dtype=torch.bfloat16,
+                                                        device=wvar.tensor.device)
+        _lib.check(_lib.lib().y3_pack_conv_weights_split(fw.context(wvar.tensor.device), fw.ptr(wvar.tensor), k, cin,
+                                                         cout, planes, fw.ptr(wp)))
     else:
         wp = hit[1] if hit is not None else torch.empty(k * k * cout * cin, dtype=torch.float32,
                                                         device=wvar.tensor.device)
         _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(wvar.tensor.device), fw.ptr(wvar.tensor), k, cin, cout,
                                                    fw.ptr(wp)))
-    st['packed'][wvar.op_name] = (wvar.version, wp)
+    st['packed'][key] = (wvar.version, wp)
     return wp
 
 
@@ -146,10 +160,11 @@ def forward_train(model, x):
             xin = engine.concat_channels(upt, xin)
         cout = l['cout']
         ones, zeros = _consts(st, cout, dev)
-        wp = _packed_weights(st, wvar)
+        planes = _planes(model) if l['cin'] != 3 else 0
+        wp = _packed_weights(st, wvar, planes)
         rec = dict(xin=xin)
         if l['bn']:
-            z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False)
+            z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False, planes=planes)
             rows = z.numel() // cout
             stats = torch.empty((4, cout), dtype=torch.float32, device=dev)   # mean, inv_std, scale, shift
             sc = _scratch(st, 'reduce', L.y3_reduce_scratch_bytes(cout), dev)
@@ -164,7 +179,7 @@ def forward_train(model, x):
                                          cout, 1, fw.ptr(y)))
             rec.update(z=z, stats=stats)
         else:              # detection conv: bias, linear (model.py:55-57)
-            y = engine.conv2d_fwd(xin, wp, ones, bias.tensor, l['k'], l['stride'], cout, False)
+            y = engine.conv2d_fwd(xin, wp, ones, bias.tensor, l['k'], l['stride'], cout, False, planes=planes)
         tens[l['dst']] = y
         saved.append(rec)
     fms = [tens[t] for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0]
@@ -374,11 +389,25 @@ class Trainer(object):
                 continue
             cin = int(xin.shape[3])
             ones, zeros = _consts(st, cin, dev)
+            planes = _planes(model) if (l['stride'] == 1 and cin % 4 == 0 and dz_stride % 32 == 0) else 0
+            if planes:
+                k = l['k']
+                w_ds = _scratch(st, 'wsplit_d', planes * k * k * cin * dz_stride * 2, dev)
+                _lib.check(L.y3_pack_conv_weights_split_dgrad(ctx, fw.ptr(w_d), k, cin, dz_stride, planes,
+                                                              fw.ptr(w_ds)))
+
+            def dgrad(accumulate, dx):
+                if planes:
+                    _lib.check(L.y3_conv2d_dgrad_split(ctx, ctypes.byref(d), planes, fw.ptr(dz), dz_stride,
+                                                       fw.ptr(w_ds), fw.ptr(ones), fw.ptr(zeros), accumulate,
+                                                       fw.ptr(dx), fw.ptr(sk_ws), ctypes.c_size_t(sk_ws.numel())))
+                else:
+                    _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_d),
+                                                 fw.ptr(ones), fw.ptr(zeros), accumulate, fw.ptr(dx), fw.ptr(sk_ws),
+                                                 ctypes.c_size_t(sk_ws.numel())))
             if up >= 0:
                 dcat = torch.empty(tuple(xin.shape), dtype=torch.float32, device=dev)
-                _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_d), fw.ptr(ones),
-                                             fw.ptr(zeros), 0, fw.ptr(dcat), fw.ptr(sk_ws),
-                                             ctypes.c_size_t(sk_ws.numel())))
+                dgrad(0, dcat)
                 cu = topo.tensors[up]['c']
                 if need_up:
                     ut = tens[up]
@@ -392,9 +421,7 @@ class Trainer(object):
             else:
                 if src not in have:
                     grads[src] = torch.empty(tuple(tens[src].shape), dtype=torch.float32, device=dev)
-                _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_d), fw.ptr(ones),
-                                             fw.ptr(zeros), 1 if src in have else 0, fw.ptr(grads[src]),
-                                             fw.ptr(sk_ws), ctypes.c_size_t(sk_ws.numel())))
+                dgrad(1 if src in have else 0, grads[src])
                 have.add(src)
             grads.pop(dst, None)      # free the consumed gradient
         st['saved'] = None
