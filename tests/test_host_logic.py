@@ -154,3 +154,59 @@ def test_letterbox_resize_matches_the_reference_geometry():
     assert letterbox_resize(np.zeros((900, 1352, 3), np.uint8), 416, 416)[2:] == (0, 70)
     with pytest.raises(ValueError):
         letterbox_resize(img, 416, 416, interp=1)
+
+
+class NamedVar(FakeVar):
+    @property
+    def op_name(self):
+        return self.name[:-2]
+
+
+def test_native_checkpoint_round_trip_scopes_and_optimizer_slots(tmp_path):
+    """Saver = one .npz keyed by the TF variable names; restore honours include/exclude scope
+    filters, reports a missing key like TF, and carries the optimizer slots under TF1's slot names."""
+    import torch
+    from yolov3_tensorflow_amd import training
+    params = yolo_ref.synthetic_params(80, seed=7)
+    specs = yolo_ref.variable_specs(80)
+    src = [NamedVar(n, s) for n, s in specs]
+    for v in src:
+        v.assign(params[v.op_name])
+    opt = training.Optimizer('adam', 1e-3)
+    opt.step = 17
+    some = src[0]
+    opt.slots[some.op_name] = (torch.full(tuple(some.shape), 0.5), torch.full(tuple(some.shape), 0.25))
+    path = misc_utils.Saver(src).save(str(tmp_path / 'model-epoch_3'), optimizer=opt, global_step=1234.0)
+    assert path.endswith('.npz')
+    keys = set(np.load(path).files)
+    assert {v.op_name for v in src} <= keys
+    assert {some.op_name + '/Adam', some.op_name + '/Adam_1', 'global_step', 'optimizer/step'} <= keys
+    # full restore
+    dst = [NamedVar(n, s) for n, s in specs]
+    assert misc_utils.Saver(dst).restore(path) == 1234.0
+    for v in dst:
+        np.testing.assert_array_equal(v.value, params[v.op_name])
+    # the reference's fine-tuning recipe: everything except the three detection convs (args.py:52-55)
+    exclude = ['yolov3/yolov3_head/Conv_14', 'yolov3/yolov3_head/Conv_6', 'yolov3/yolov3_head/Conv_22']
+    dst = [NamedVar(n, s) for n, s in specs]
+    part = misc_utils.get_variables_to_restore(dst, None, exclude)
+    assert len(part) == len(dst) - 6           # three convs x (weights, biases)
+    misc_utils.Saver(part).restore(path)
+    assert all((v.value is None) == any(v.op_name.startswith(e + '/') for e in exclude) for v in dst)
+    body = misc_utils.get_variables_to_restore(dst, ['yolov3/darknet53_body'], None)
+    assert len(body) == 52 * 5 and all(v.op_name.startswith('yolov3/darknet53_body/') for v in body)
+    # a variable the checkpoint does not hold
+    with pytest.raises(KeyError):
+        misc_utils.Saver([NamedVar('yolov3/yolov3_head/Conv_99/weights', (1, 1, 4, 4))]).restore(path)
+    # shape mismatch is caught by assign(validate_shape=True)
+    with pytest.raises(ValueError):
+        misc_utils.Saver([NamedVar(specs[0][0], (1, 1, 1, 1))]).restore(path)
+    # optimizer slots come back under the same names
+    opt2 = training.Optimizer('adam', 1e-3)
+
+    class DevVar(NamedVar):
+        tensor = torch.zeros(1)
+    dv = DevVar(specs[0][0], specs[0][1])
+    misc_utils.Saver([dv]).restore(path, optimizer=opt2)
+    assert opt2.step == 17 and float(opt2.slots[dv.op_name][0].flatten()[0]) == 0.5 and \
+        float(opt2.slots[dv.op_name][1].flatten()[0]) == 0.25

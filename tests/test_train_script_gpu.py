@@ -61,7 +61,21 @@ def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys):
     assert len(hist['mAP']) == 2 and all(0.0 <= m <= 1.0 for m in hist['mAP'])
     # measured: recall on the training batch 1.0 and mAP 1.0 on the (memorised) set after 201 Adam steps
     assert hist['recall'][-1] > 0.8 and hist['mAP'][-1] > 0.8
-    assert any(f.startswith('best_model_Epoch_') and f.endswith('.weights') for f in os.listdir(str(tmp_path / 'ckpt')))
+    files = os.listdir(str(tmp_path / 'ckpt'))
+    assert any(f.startswith('best_model_Epoch_') and f.endswith('.weights') for f in files)
+    # resume from the native checkpoint (variables + Adam slots + global_step): the loss starts where it ended
+    ckpt = sorted(f for f in files if f.endswith('.npz'))[-1]
+    y3.reset_default_graph()
+    hist2 = train_script.main([
+        '--train_file', ann, '--val_file', ann, '--restore_path', str(tmp_path / 'ckpt' / ckpt), '--restore_exclude', 'None',
+        '--save_dir', str(tmp_path / 'ckpt2'), '--progress_log_path', '', '--anchor_path',
+        os.path.join(ROOT, 'data', 'yolo_anchors.txt'), '--class_name_path', names, '--batch_size', '8',
+        '--img_size', '160', '160', '--letterbox_resize', 'false', '--total_epoches', '3', '--train_evaluation_step', '1000',
+        '--val_evaluation_epoch', '1000', '--save_epoch', '1000', '--batch_norm_decay', '0.9', '--optimizer_name', 'adam',
+        '--learning_rate_init', '1e-3', '--lr_type', 'fixed', '--update_part', 'None', '--multi_scale_train', 'false',
+        '--use_warm_up', 'false', '--warm_up_epoch', '0', '--use_label_smooth', 'false', '--use_focal_loss', 'false',
+        '--weight_decay', '0'])
+    assert hist2['loss'][0] < 3.0 * loss[-1] and hist2['global_step_start'] == 201
     assert os.path.getsize(str(tmp_path / 'progress.log')) > 0
 
 

@@ -139,6 +139,73 @@ def save_weights(var_list, weights_file, header=(0, 2, 0, 0, 0)):
         np.concatenate(chunks).astype(np.float32).tofile(fp)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# native checkpoints keyed by the TF variable names (stands in for tf.train.Saver in
+# train.py:81-82,101-124,169-171,213-216 and convert_weight.py)
+# ------------------------------------------------------------------------------------------------------------
+def _in_scopes(name, scopes):
+    return any(name == s or name.startswith(s + '/') for s in scopes)
+
+
+def get_variables_to_restore(variables, include=None, exclude=None):
+    """tf.contrib.framework.get_variables_to_restore(include, exclude) over an explicit variable list: scopes match
+    whole name components ('yolov3/yolov3_head/Conv_6' does not match '.../Conv_60')."""
+    keep = list(variables) if include is None else [v for v in variables if _in_scopes(v.op_name, include)]
+    return keep if exclude is None else [v for v in keep if not _in_scopes(v.op_name, exclude)]
+
+
+# slot names TF1 gives the optimizer variables (utils/misc_utils.py:151-161 optimizers)
+_SLOT_NAMES = {'momentum': ('Momentum',), 'adam': ('Adam', 'Adam_1'), 'rmsprop': ('RMSProp', 'RMSProp_1'),
+               'sgd': ()}
+
+
+class Saver(object):
+    """A checkpoint is one `.npz` file whose keys are the variables' TF names ('yolov3/darknet53_body/Conv/weights',
+    ...); with an optimizer, its slot variables are stored as '<variable>/<SlotName>' with TF1's slot names and
+    `global_step` as a scalar.  restore() assigns every variable of `var_list` and raises KeyError, like TF's
+    "Key ... not found in checkpoint", when one is missing; arrays are shape-checked by Variable.assign."""
+
+    def __init__(self, var_list):
+        self.var_list = list(var_list)
+
+    @staticmethod
+    def _path(path):
+        return path if path.endswith('.npz') else path + '.npz'
+
+    def save(self, save_path, optimizer=None, global_step=None):
+        out = {v.op_name: v.numpy() for v in self.var_list}
+        if optimizer is not None:
+            for name, slots in optimizer.slots.items():
+                for slot_name, t in zip(_SLOT_NAMES[optimizer.kind], slots):
+                    if t is not None:
+                        out[name + '/' + slot_name] = t.detach().cpu().numpy()
+            out['optimizer/step'] = np.int64(optimizer.step)
+        if global_step is not None:
+            out['global_step'] = np.float64(global_step)
+        path = self._path(save_path)
+        with open(path, 'wb') as f:
+            np.savez(f, **out)
+        return path
+
+    def restore(self, save_path, optimizer=None):
+        """Returns the stored global_step (or None)."""
+        import torch
+        ckpt = np.load(self._path(save_path))
+        for v in self.var_list:
+            if v.op_name not in ckpt.files:
+                raise KeyError('Key %s not found in checkpoint %s' % (v.op_name, save_path))
+            v.assign(ckpt[v.op_name], validate_shape=True)
+        if optimizer is not None:
+            for v in self.var_list:
+                keys = [v.op_name + '/' + s for s in _SLOT_NAMES[optimizer.kind]]
+                if keys and all(k in ckpt.files for k in keys):
+                    slots = [torch.as_tensor(ckpt[k]).to(v.tensor.device) for k in keys]
+                    optimizer.slots[v.op_name] = tuple(slots + [None] * (2 - len(slots)))
+            if 'optimizer/step' in ckpt.files:
+                optimizer.step = int(ckpt['optimizer/step'])
+        return float(ckpt['global_step']) if 'global_step' in ckpt.files else None
+
+
 def config_learning_rate(args, global_step):
     """reference utils/misc_utils.py:129-148, evaluated eagerly: returns the python float learning rate
     for `global_step` (float).  Raises ValueError for an unknown lr_type like the reference."""
