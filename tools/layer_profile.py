@@ -19,11 +19,13 @@ def main():
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--csv', default=None)
+    ap.add_argument('--precision', default='f32', help='f32 | f32_bf16x6 | f32_bf16x3 | bf16')
     a = ap.parse_args()
     import torch
     import yolov3_tensorflow_amd as y3
     import bench
     model = y3.yolov3(80, bench.ANCHORS)
+    model.compute_dtype = a.precision
     x = torch.rand((a.batch, a.size, a.size, 3), device='cuda')
     with y3.variable_scope('yolov3'):
         model.forward(torch.zeros((1, 64, 64, 3), device='cuda'))
