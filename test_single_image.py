@@ -1,89 +1,106 @@
 # coding: utf-8
-"""Single-image detection on the MI355X path — the counterpart of the reference's test_single_image.py
-(same positional/keyword arguments; `--restore_path` takes a darknet .weights file instead of a TF checkpoint,
-and the cv2 window/drawing is replaced by printing the detections and an optional PIL-drawn output file).
+"""Detect the objects of one image file on the MI355X-native path.
 
-    python test_single_image.py ./some.jpg --restore_path ./data/darknet_weights/yolov3.weights
+Command line of the reference's test_single_image.py (positional image path, --anchor_path, --new_size,
+--letterbox_resize, --class_name_path, --restore_path), with two differences forced by the environment: the weights
+come from a darknet `.weights` file (or a native `.npz` checkpoint) instead of a TF checkpoint, and instead of an
+OpenCV window the detections are printed and, with --output, drawn into an image file with PIL.
+
+    python test_single_image.py ./data/demo_data/messi.jpg --restore_path ./data/darknet_weights/yolov3.weights
 """
 from __future__ import division, print_function
 
 import argparse
+import sys
 
 import numpy as np
 
-import yolov3_tensorflow_amd as y3
-from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize
-from yolov3_tensorflow_amd.utils.misc_utils import load_weights, parse_anchors, read_class_names, run_ops
-from yolov3_tensorflow_amd.utils.nms_utils import gpu_nms
-
-parser = argparse.ArgumentParser(description="YOLO-V3 test single image test procedure.")
-parser.add_argument("input_image", type=str, help="The path of the input image.")
-parser.add_argument("--anchor_path", type=str, default="./data/yolo_anchors.txt", help="The path of the anchor txt file.")
-parser.add_argument("--new_size", nargs='*', type=int, default=[416, 416],
-                    help="Resize the input image with `new_size`, size format: [width, height]")
-parser.add_argument("--letterbox_resize", type=lambda x: (str(x).lower() == 'true'), default=True,
-                    help="Whether to use the letterbox resize.")
-parser.add_argument("--class_name_path", type=str, default="./data/coco.names", help="The path of the class names.")
-parser.add_argument("--restore_path", type=str, default="./data/darknet_weights/yolov3.weights",
-                    help="The path of the darknet weights to restore (random weights if the file is absent).")
-parser.add_argument("--output", type=str, default=None, help="Optional path of an annotated output image.")
+SCORE_THRESH, NMS_THRESH, MAX_BOXES = 0.3, 0.45, 200      # test_single_image.py:57
 
 
-def main():
-    args = parser.parse_args()
-    args.anchors = parse_anchors(args.anchor_path)
-    args.classes = read_class_names(args.class_name_path)
-    args.num_class = len(args.classes)
+def parse_args(argv):
+    as_bool = lambda text: str(text).lower() == 'true'
+    ap = argparse.ArgumentParser(description="YOLO-V3 single image detection.")
+    ap.add_argument("input_image", type=str, help="image file to run on")
+    ap.add_argument("--anchor_path", type=str, default="./data/yolo_anchors.txt", help="anchor txt file")
+    ap.add_argument("--new_size", nargs='*', type=int, default=[416, 416], help="network input size: width height")
+    ap.add_argument("--letterbox_resize", type=as_bool, default=True, help="keep the aspect ratio (pad with 128)")
+    ap.add_argument("--class_name_path", type=str, default="./data/coco.names", help="class names, one per line")
+    ap.add_argument("--restore_path", type=str, default="./data/darknet_weights/yolov3.weights",
+                    help="darknet .weights or native .npz checkpoint; random weights if the file does not exist")
+    ap.add_argument("--output", type=str, default=None, help="write the annotated image here")
+    return ap.parse_args(argv)
 
-    from PIL import Image, ImageDraw
-    img_ori = np.asarray(Image.open(args.input_image).convert('RGB'))          # RGB (cv2 would give BGR)
-    height_ori, width_ori = img_ori.shape[:2]
-    if args.letterbox_resize:
-        img, resize_ratio, dw, dh = letterbox_resize(img_ori, args.new_size[0], args.new_size[1])
+
+def to_network_frame(image, size, letterbox):
+    """uint8 RGB image -> ([1,h,w,3] float32 in [0,1], function mapping network-frame boxes back to the image)."""
+    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize
+    h0, w0 = image.shape[:2]
+    if letterbox:
+        resized, ratio, dw, dh = letterbox_resize(image, size[0], size[1])
+
+        def back(boxes):
+            boxes[:, [0, 2]] = (boxes[:, [0, 2]] - dw) / ratio
+            boxes[:, [1, 3]] = (boxes[:, [1, 3]] - dh) / ratio
+            return boxes
     else:
-        sx = np.minimum(np.floor(np.arange(args.new_size[0]) * (width_ori / args.new_size[0])).astype(int), width_ori - 1)
-        sy = np.minimum(np.floor(np.arange(args.new_size[1]) * (height_ori / args.new_size[1])).astype(int), height_ori - 1)
-        img = img_ori[sy][:, sx]
-    img = np.asarray(img, np.float32)
-    img = img[np.newaxis, :] / 255.
+        # plain resize with cv2's nearest-neighbour sampling rule: src = min(floor(dst * src/dst_size), src - 1)
+        cols = np.minimum(np.floor(np.arange(size[0]) * (w0 / size[0])).astype(int), w0 - 1)
+        rows = np.minimum(np.floor(np.arange(size[1]) * (h0 / size[1])).astype(int), h0 - 1)
+        resized = image[rows][:, cols]
 
-    yolo_model = y3.yolov3(args.num_class, args.anchors)
+        def back(boxes):
+            boxes[:, [0, 2]] *= w0 / float(size[0])
+            boxes[:, [1, 3]] *= h0 / float(size[1])
+            return boxes
+    return (np.asarray(resized, np.float32) / 255.)[np.newaxis], back
+
+
+def restore(variables, path):
+    from yolov3_tensorflow_amd.utils.misc_utils import Saver, load_weights, run_ops
+    try:
+        if path.endswith('.npz'):
+            Saver(variables).restore(path)
+        else:
+            run_ops(load_weights(variables, path))
+        return True
+    except (IOError, OSError):
+        print('WARNING: %s not found - running with randomly initialised weights' % path)
+        return False
+
+
+def main(argv=None):
+    args = parse_args(sys.argv[1:] if argv is None else argv)
+    from PIL import Image
+    import torch
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd.utils.misc_utils import parse_anchors, read_class_names
+    from yolov3_tensorflow_amd.utils.plot_utils import get_color_table, plot_one_box
+
+    classes = read_class_names(args.class_name_path)
+    model = y3.yolov3(len(classes), parse_anchors(args.anchor_path))
+    picture = np.asarray(Image.open(args.input_image).convert('RGB'))       # RGB; cv2.imread would give BGR
+    net_in, back = to_network_frame(picture, args.new_size, args.letterbox_resize)
     with y3.variable_scope('yolov3'):
-        pred_feature_maps = yolo_model.forward(img, False)
-        try:
-            run_ops(load_weights(y3.global_variables(scope='yolov3'), args.restore_path))
-            pred_feature_maps = yolo_model.forward(img, False)
-        except (IOError, OSError):
-            print('WARNING: %s not found - running with randomly initialised weights' % args.restore_path)
-    pred_boxes, pred_confs, pred_probs = yolo_model.predict(pred_feature_maps)
-    pred_scores = pred_confs * pred_probs
-    boxes_, scores_, labels_ = gpu_nms(pred_boxes, pred_scores, args.num_class, max_boxes=200, score_thresh=0.3,
-                                       nms_thresh=0.45)
-    boxes_, scores_, labels_ = boxes_.cpu().numpy(), scores_.cpu().numpy(), labels_.cpu().numpy()
+        model.forward(torch.zeros((1, 64, 64, 3)), False)                   # creates the variables
+        restore(y3.global_variables(scope='yolov3'), args.restore_path)
+        boxes, scores, labels = model.detect(net_in, max_boxes=MAX_BOXES, score_thresh=SCORE_THRESH,
+                                             nms_thresh=NMS_THRESH)[0]
+    boxes = back(boxes.cpu().numpy())
+    scores, labels = scores.cpu().numpy(), labels.cpu().numpy()
 
-    # rescale the coordinates to the original image
-    if args.letterbox_resize:
-        boxes_[:, [0, 2]] = (boxes_[:, [0, 2]] - dw) / resize_ratio
-        boxes_[:, [1, 3]] = (boxes_[:, [1, 3]] - dh) / resize_ratio
-    else:
-        boxes_[:, [0, 2]] *= (width_ori / float(args.new_size[0]))
-        boxes_[:, [1, 3]] *= (height_ori / float(args.new_size[1]))
-
-    print("box coords:")
-    print(boxes_)
-    print('*' * 30)
-    print("scores:")
-    print(scores_)
-    print('*' * 30)
-    print("labels:")
-    print(labels_)
+    for title, values in (("box coords:", boxes), ("scores:", scores), ("labels:", labels)):
+        print(title)
+        print(values)
+        print('*' * 30)
     if args.output:
-        im = Image.fromarray(img_ori)
-        draw = ImageDraw.Draw(im)
-        for (x0, y0, x1, y1), s, l in zip(boxes_, scores_, labels_):
-            draw.rectangle([float(x0), float(y0), float(x1), float(y1)], outline=(255, 0, 0), width=2)
-            draw.text((float(x0) + 2, float(y0) + 2), '%s, %.2f%%' % (args.classes[int(l)], s * 100), fill=(255, 0, 0))
-        im.save(args.output)
+        colours = get_color_table(len(classes))
+        canvas = picture.copy()
+        for box, score, label in zip(boxes, scores, labels):
+            plot_one_box(canvas, box, label=classes[int(label)] + ', {:.2f}%'.format(score * 100),
+                         color=colours[int(label)])
+        Image.fromarray(canvas).save(args.output)
+    return boxes, scores, labels
 
 
 if __name__ == '__main__':

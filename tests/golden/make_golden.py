@@ -145,6 +145,10 @@ def eval_goldens(nms_utils, data_utils, anchors):
                                                iou_thresh=0.5)
     out['ev_recall_precision'] = np.array([rec, prec], np.float64)
     out['ev_dicts'] = np.array([[tpd[c], tld[c], pld[c]] for c in range(C)], np.int64)
+    # ---- plot_utils.get_color_table (utils/plot_utils.py:9-14) ------------------------------------------
+    from utils import plot_utils
+    table = plot_utils.get_color_table(80)
+    out['color_table_80'] = np.array([table[i] for i in range(80)], np.int64)
     np.savez_compressed(os.path.join(OUT, 'reference_eval_goldens.npz'), **out)
     print('wrote', os.path.join(OUT, 'reference_eval_goldens.npz'), len(out), 'arrays')
 

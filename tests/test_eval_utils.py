@@ -185,3 +185,42 @@ def test_eval_script_batched_equals_per_image(tmp_path, capsys):
     sa, sb = set(map(key, a['val_preds'])), set(map(key, b['val_preds']))
     assert len(sa) > 50 and len(sa ^ sb) <= 0.02 * len(sa), (len(sa), len(sa ^ sb))
     assert abs(a['mAP'] - b['mAP']) < 0.02
+
+
+def test_color_table_matches_the_reference(g):
+    from yolov3_tensorflow_amd.utils.plot_utils import get_color_table, plot_one_box
+    table = get_color_table(80)
+    np.testing.assert_array_equal(np.array([table[i] for i in range(80)]), g['color_table_80'])
+    img = np.zeros((120, 160, 3), np.uint8)
+    plot_one_box(img, [20, 40, 100, 90], label='cat, 97.00%', color=table[3])
+    assert (img[40, 20:101] == table[3]).all() and (img[65, 60] == 0).all()      # outline drawn, interior untouched
+    assert (img[30:40, 20:60] != 0).any()                                         # caption strip above the box
+
+
+@pytest.mark.gpu
+def test_single_image_script(tmp_path, capsys):
+    """test_single_image.py twin on a synthetic picture with random weights: both resize modes run, print the three
+    blocks the reference prints, write the annotated file, and return detections inside the picture frame."""
+    import sys
+    from PIL import Image
+    import yolov3_tensorflow_amd as y3
+    sys.path.insert(0, os.path.dirname(HERE))
+    import test_single_image as script
+    rng = np.random.RandomState(9)
+    pic = (rng.rand(30, 44, 3) * 255).astype(np.uint8).repeat(10, 0).repeat(10, 1)     # 300 x 440
+    src = tmp_path / 'pic.png'
+    Image.fromarray(pic).save(str(src))
+    root = os.path.dirname(HERE)
+    for letterbox in ('true', 'false'):
+        y3.reset_default_graph()
+        y3.set_init_seed(11)
+        out = tmp_path / ('out_%s.png' % letterbox)
+        boxes, scores, labels = script.main([str(src), '--anchor_path', os.path.join(root, 'data', 'yolo_anchors.txt'),
+                                             '--class_name_path', os.path.join(root, 'data', 'coco.names'),
+                                             '--new_size', '320', '224', '--letterbox_resize', letterbox,
+                                             '--restore_path', str(tmp_path / 'missing.weights'), '--output', str(out)])
+        text = capsys.readouterr().out
+        assert 'box coords:' in text and 'scores:' in text and 'labels:' in text and 'not found' in text
+        assert boxes.shape[1] == 4 and len(boxes) == len(scores) == len(labels)
+        assert (scores >= 0.3).all() and labels.dtype == np.int32
+        assert Image.open(str(out)).size == (440, 300)
