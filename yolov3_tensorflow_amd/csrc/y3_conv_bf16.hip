@@ -4,14 +4,17 @@
 //   * activations, packed weights and residuals are bf16 (2 B/element), scale/shift fp32, accumulation fp32
 //     in v_mfma_f32_32x32x16_bf16 (K = 16 per instruction: lane l holds k = 8*(l>>5)..+7 of row l&31, i.e.
 //     one 16-byte LDS read per fragment);
-//   * BK = 32 elements = 64-byte rows (every Cin of the network is a multiple of 32); LDS rows are padded to
-//     80 bytes, which spreads the 16-lane groups of ds_read_b128 over all sixteen 16-byte bank slots;
-//   * a K-step is only 8 MFMAs x 32 cycles per wave, so the kernel is bound by the global->LDS staging
-//     (16 KB per K-step per workgroup), not by the matrix pipe: 40 KB of LDS per workgroup keeps 3 workgroups
-//     per CU in flight to cover the load latency;
+//   * BK = 32 elements = 64-byte rows (every Cin of the network is a multiple of 32); LDS rows are unpadded with the
+//     16-byte slot index XOR-swizzled by (row/4)%4, which makes the ds_read_b128 fragment reads (16 rows of one
+//     slot) and the 64-byte-contiguous staging writes bank-conflict free;
+//   * a K-step is only 8 MFMAs x 32 cycles per wave — shorter than the memory latency — so global loads run TWO
+//     K-steps ahead in two alternating register sets, and the loader is branch-free (a branch around a load makes
+//     hipcc drain vmcnt(0) at its join); weights are packed [tap][Cin/32][Cout][32] so that a K-step's B tile is
+//     whole 128-byte lines;
 //   * epilogue in fp32 (scale/shift, LeakyReLU, residual), ONE rounding to bf16 (round-to-nearest-even) at the
 //     store; the detection convs (linear, 3*(5+C) channels) write fp32 so that decode/NMS are unchanged.
 // Data-parallel schedule with XCD-contiguous tile ids (no stream-K: the kernel is not matrix-pipe bound).
+#include <type_traits>
 #include "y3_internal.h"
 
 namespace {
@@ -36,8 +39,12 @@ struct ConvArgsB {
 };
 
 constexpr int BKB = 32;            // K elements per step
-constexpr int LDB = 80;            // LDS row stride in bytes (64 data + 16 pad)
+constexpr int LDB = 64;            // LDS row stride in bytes (unpadded; 16-byte slots swizzled, see lds_off)
 constexpr unsigned OOB = 0x80000000u;
+
+// LDS byte offset of 16-byte slot `slot` (0..3) of row `row`: four rows share one 256-byte bank row, so the slot is
+// flipped by (row/4)%4 and 16 consecutive rows of one logical slot land on 16 different bank groups.
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * LDB + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even (finite inputs)
@@ -54,8 +61,7 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
     constexpr int ACH = BM * 4 / 256;                 // 16-byte chunks of A each thread stages (2)
     constexpr int BCH = (BN * 4 + 255) / 256;         // of B (2, 1, 1)
     constexpr int LDC = BN + 4;                       // fp32 epilogue staging stride (floats), 64 rows at a time
-    constexpr size_t TILE_BYTES = (size_t)(BM + BN) * LDB;
-    static_assert((size_t)64 * LDC * 4 <= 2 * TILE_BYTES, "epilogue half-tile must fit in the staging LDS");
+    // (the launcher allocates max(2 * TILE_BYTES, 64 * LDC * 4): the epilogue stages 64 fp32 rows at a time)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                        // [2][BM][80 B]
@@ -87,7 +93,7 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
         const_cast<bf16_t*>(p.w), 0, (unsigned)((size_t)KS * KS * p.Cout * p.Cin * 2), 0x00020000);
 
     int a_base[ACH], a_msk[ACH], a_base_u[UPCAT ? ACH : 1];
-    unsigned a_voff[ACH], a_voff_u[UPCAT ? ACH : 1], b_voff[BCH];
+    unsigned b_voff[BCH];
     int ld_tap = 0, ld_cc = 0;
     {
         const int HoWo = p.Ho * p.Wo;
@@ -115,56 +121,52 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
         for (int j = 0; j < BCH; ++j) {
             const int co = n0 + r0 + 64 * j;
             const bool ok = co < p.Cout && (BN >= 64 || r0 < BN) && (r0 + 64 * j) < BN;
-            b_voff[j] = ok ? (unsigned)(co * p.Cin + c8) * 2u : OOB;
+            b_voff[j] = ok ? (unsigned)(co * BKB + c8) * 2u : OOB;
         }
     }
-    auto set_tap = [&]() {
+    u32x4 ra[2][ACH], rb[2][BCH];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // fetch the prepared K-step into register set s and step the loader; branch-free (past the last K-step the
+    // loads read in-bounds-or-zero addresses and are never consumed)
+    auto issue = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
         const int ky = (KS == 1) ? 0 : ld_tap / KS;
         const int kx = (KS == 1) ? 0 : ld_tap - ky * KS;
         const int tap_off = (ky * p.W + kx) * p.Cx + c8;
+        const int c0 = ld_cc * BKB;
+        const bool from_up = UPCAT && c0 < p.Cu;
+        const unsigned soff = (unsigned)(from_up ? c0 : c0 - (UPCAT ? p.Cu : 0)) * 2u;
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const bool ok = ((a_msk[j] >> ky) & (a_msk[j] >> (4 + kx)) & 1) != 0;
-            a_voff[j] = ok ? (unsigned)(a_base[j] + tap_off) * 2u : OOB;
-            if (UPCAT) a_voff_u[j] = ok ? (unsigned)(a_base_u[j] + c8) * 2u : OOB;
+            const unsigned voff = ok ? (unsigned)(a_base[j] + tap_off) * 2u : OOB;
+            if (UPCAT) {
+                const unsigned voff_u = ok ? (unsigned)(a_base_u[j] + c8) * 2u : OOB;
+                ra[s][j] = from_up ? __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, soff, 0)
+                                   : __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, soff, 0);
+            } else {
+                ra[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, soff, 0);
+            }
         }
+        // weights: [tap][Cin/32][Cout][32] — the B tile of a K-step is contiguous
+        const unsigned wsoff = (unsigned)((ld_tap * kchunks + ld_cc) * p.Cout) * (BKB * 2u);
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) rb[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff[j], wsoff, 0);
+        const bool wrap = ++ld_cc == kchunks;
+        ld_cc = wrap ? 0 : ld_cc;
+        ld_tap += wrap ? 1 : 0;
     };
-    set_tap();
-
-    u32x4 ra[ACH], rb[BCH];
-    auto issue_loads = [&]() {
-        const int c0 = ld_cc * BKB;
-        if (UPCAT) {
-            const bool from_up = c0 < p.Cu;
-            const unsigned soff = (unsigned)(from_up ? c0 : c0 - p.Cu) * 2u;
+    auto store = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;      // register set s -> LDS buffer s
+        unsigned char* as = As + s * BM * LDB;
+        unsigned char* bs = Bs + s * BN * LDB;
 #pragma unroll
-            for (int j = 0; j < ACH; ++j)
-                ra[j] = from_up ? __builtin_amdgcn_raw_buffer_load_b128(rs_u, a_voff_u[j], soff, 0)
-                                : __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], soff, 0);
-        } else {
-            const unsigned soff = (unsigned)c0 * 2u;
-#pragma unroll
-            for (int j = 0; j < ACH; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, a_voff[j], soff, 0);
-        }
-        const unsigned wsoff = (unsigned)((ld_tap * p.Cout) * p.Cin + c0) * 2u;
-#pragma unroll
-        for (int j = 0; j < BCH; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_voff[j], wsoff, 0);
-    };
-    auto advance = [&]() {
-        if (++ld_cc == kchunks) {
-            ld_cc = 0;
-            ++ld_tap;
-            if (KS > 1 && ld_tap < KS * KS) set_tap();
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* as = As + buf * BM * LDB;
-        unsigned char* bs = Bs + buf * BN * LDB;
-#pragma unroll
-        for (int j = 0; j < ACH; ++j) *reinterpret_cast<u32x4*>(as + (r0 + 64 * j) * LDB + ch * 16) = ra[j];
+        for (int j = 0; j < ACH; ++j) *reinterpret_cast<u32x4*>(as + lds_off(r0 + 64 * j, ch)) = ra[s][j];
 #pragma unroll
         for (int j = 0; j < BCH; ++j)
-            if ((r0 + 64 * j) < BN) *reinterpret_cast<u32x4*>(bs + (r0 + 64 * j) * LDB + ch * 16) = rb[j];
+            if ((r0 + 64 * j) < BN) *reinterpret_cast<u32x4*>(bs + lds_off(r0 + 64 * j, ch)) = rb[s][j];
     };
 
     f32x16 acc[MI][NI];
@@ -175,19 +177,22 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int frag_row = lane & 31, frag_off = 16 * (lane >> 5);
-    auto compute_tile = [&](int buf) {
-        const unsigned char* as = As + buf * BM * LDB + (wm * WTM + frag_row) * LDB + frag_off;
-        const unsigned char* bs = Bs + buf * BN * LDB + (wn * WTN + frag_row) * LDB + frag_off;
+    // lane l feeds row l&31 of each 32x32 MFMA tile with the 8 k-values of slot 2*kk + (l>>5); tile row bases are
+    // multiples of 32, so the swizzle term depends on the lane only
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    auto compute = [&](int buf) {
+        const unsigned char* as = As + buf * BM * LDB + wm * WTM * LDB;
+        const unsigned char* bs = Bs + buf * BN * LDB + wn * WTN * LDB;
 #pragma unroll
         for (int kk = 0; kk < BKB / 16; ++kk) {
+            const int off = lds_off(frag_row, 2 * kk + frag_half);
             bf16x8 a[MI], b[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                a[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(as + mi * 32 * LDB + kk * 32));
+                a[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(as + mi * 32 * LDB + off));
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                b[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bs + ni * 32 * LDB + kk * 32));
+                b[ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bs + ni * 32 * LDB + off));
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -196,19 +201,23 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
         }
     };
 
-    issue_loads();
-    advance();
-    store_tile(0);
+    // K-step g uses LDS buffer / register set g&1; its loads were issued two K-steps earlier
+    I0 i0;
+    I1 i1;
+    issue(i0);
+    issue(i1);
+    store(i0);
     __syncthreads();
-    for (int t = 0; t + 1 < S; ++t) {
-        issue_loads();
-        compute_tile(t & 1);
-        store_tile((t + 1) & 1);
-        advance();
+    for (int g = 0; g < S; g += 2) {
+        issue(i0);                     // K-step g+2
+        compute(0);
+        store(i1);                     // K-step g+1
+        __syncthreads();
+        issue(i1);                     // K-step g+3
+        if (g + 1 < S) compute(1);
+        store(i0);                     // K-step g+2
         __syncthreads();
     }
-    compute_tile((S - 1) & 1);
-    __syncthreads();
 
     // ---- epilogue --------------------------------------------------------------------------------------
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
@@ -353,14 +362,17 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w_hwio, bf16_
         const size_t r = i / cin;
         const int co = (int)(r % cout);
         const int t = (int)(r / cout);
-        w_packed[i] = f32_to_bf16(w_hwio[((size_t)t * cin + ci) * cout + co]);
+        // [tap][Cin/32][Cout][32]: the B tile of one K-step (32 input channels) is contiguous
+        w_packed[((((size_t)t * (cin / BKB) + ci / BKB) * cout + co) * BKB) + (ci % BKB)] =
+            f32_to_bf16(w_hwio[((size_t)t * cin + ci) * cout + co]);
     }
 }
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT>
 int launch_b(hipStream_t stream, const ConvArgsB& a) {
     auto kern = conv_mfma_bf16_kernel<BM, BN, WGM, WGN, KS, UPCAT>;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDB;
+    constexpr size_t tiles = (size_t)2 * (BM + BN) * LDB, stage = (size_t)64 * (BN + 4) * 4;
+    constexpr size_t lds = tiles > stage ? tiles : stage;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), lds, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
@@ -420,7 +432,8 @@ int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x
 
 extern "C" int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, void* w_packed) {
     Y3_CHECK_ARG(ctx && w_hwio && w_packed, "y3_pack_conv_weights_bf16: null argument");
-    Y3_CHECK_ARG(k > 0 && cin > 0 && cout > 0, "y3_pack_conv_weights_bf16: non-positive dimension");
+    Y3_CHECK_ARG(k > 0 && cin > 0 && cout > 0 && cin % BKB == 0,
+                 "y3_pack_conv_weights_bf16: cin must be a positive multiple of %d", BKB);
     const size_t total = (size_t)k * k * cin * cout;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, w_hwio,
