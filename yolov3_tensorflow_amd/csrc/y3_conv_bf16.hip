@@ -314,32 +314,45 @@ __global__ void __launch_bounds__(256) conv_stem_bf16_kernel(const float* __rest
     constexpr int COUT = 32;
     __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
     __shared__ float ssc[COUT], ssh[COUT];
+    __shared__ __attribute__((aligned(16))) float xs[27 * 256];      // [tap*3+ci][thread]; later the output staging
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
     for (int i = threadIdx.x; i < COUT; i += 256) { ssc[i] = scale[i]; ssh[i] = shift[i]; }
     __syncthreads();
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    const int m_raw = blockIdx.x * 256 + threadIdx.x;
+    const int m = m_raw < M ? m_raw : M - 1;          // threads past the end recompute the last pixel, store nothing
     const int n = m / (H * W);
     const int rem = m - n * H * W;
     const int oy = rem / W, ox = rem - oy * W;
-    float acc[COUT];
+    // inputs first (one round of load latency), parked in a thread-private LDS column; see conv_stem_kernel
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy - 1 + ky;
-#pragma unroll 1
+#pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox - 1 + kx;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const float* src = x + ((size_t)(n * H + iy) * W + ix) * 3;
+            const float* src = x + ((size_t)(n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float xv = ok ? src[ci] : 0.f;
-                const float* wr = ws + ((ky * 3 + kx) * 3 + ci) * COUT;
-#pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] = fmaf(xv, wr[c], acc[c]);
+                const float v = src[ci];
+                xs[((ky * 3 + kx) * 3 + ci) * 256 + threadIdx.x] = ok ? v : 0.f;
             }
+        }
+    }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 3
+    for (int t = 0; t < 27; ++t) {
+        const float xv = xs[t * 256 + threadIdx.x];
+        const float* wr = ws + t * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+            acc[c + 0] = fmaf(xv, wv[0], acc[c + 0]);
+            acc[c + 1] = fmaf(xv, wv[1], acc[c + 1]);
+            acc[c + 2] = fmaf(xv, wv[2], acc[c + 2]);
+            acc[c + 3] = fmaf(xv, wv[3], acc[c + 3]);
         }
     }
     unsigned pk[COUT / 2];
@@ -349,9 +362,23 @@ __global__ void __launch_bounds__(256) conv_stem_bf16_kernel(const float* __rest
         if (act) { t0 = t0 > 0.f ? t0 : 0.1f * t0; t1 = t1 > 0.f ? t1 : 0.1f * t1; }
         pk[c / 2] = (unsigned)f32_to_bf16(t0) | ((unsigned)f32_to_bf16(t1) << 16);
     }
-    u32x4* out = reinterpret_cast<u32x4*>(y + (size_t)m * COUT);
+    // store through the LDS (see conv_stem_kernel): 64 bytes per pixel, staged rows of 80 bytes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                   // every thread is done with its xs column
+    unsigned char* stage = reinterpret_cast<unsigned char*>(xs) + wave * 64 * 80;
 #pragma unroll
-    for (int c = 0; c < COUT / 8; ++c) out[c] = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
+    for (int c = 0; c < COUT / 8; ++c)
+        *reinterpret_cast<u32x4*>(stage + lane * 80 + c * 16) = u32x4{pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]};
+    __syncthreads();
+    const int m_wave = blockIdx.x * 256 + wave * 64;
+#pragma unroll
+    for (int i = 0; i < COUT / 8; ++i) {
+        const int f = i * 64 + lane;                   // 16-byte piece inside the wave's 64 x 64-byte block
+        const int pix = f >> 2, piece = f & 3;
+        if (m_wave + pix < M)
+            *reinterpret_cast<u32x4*>(y + (size_t)(m_wave + pix) * COUT + piece * 8) =
+                *reinterpret_cast<const u32x4*>(stage + pix * 80 + piece * 16);
+    }
 }
 
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w_hwio, bf16_t* __restrict__ w_packed, int taps,

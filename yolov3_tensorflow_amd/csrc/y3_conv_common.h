@@ -229,47 +229,61 @@ template <int COUT>
 __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
     __shared__ float ssc[COUT], ssh[COUT];
+    __shared__ __attribute__((aligned(16))) float xs[4 * 64 * (COUT + 4)];   // inputs [tap*3+ci][thread] (27*256
+                                                                              // floats), later the output staging
     for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = p.w[i];
     for (int i = threadIdx.x; i < COUT; i += 256) {
         ssc[i] = p.scale[i];
         ssh[i] = p.shift[i];
     }
     __syncthreads();
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= p.M) return;
+    const int m_raw = blockIdx.x * 256 + threadIdx.x;
+    const int m = m_raw < p.M ? m_raw : p.M - 1;     // threads past the end recompute the last pixel, store nothing
     const int HoWo = p.Ho * p.Wo;
     const int n = m / HoWo;
     const int rem = m - n * HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    float acc[COUT];
+    // all 27 input values first (one round of global-load latency instead of nine dependent ones), parked in a
+    // thread-private LDS column so that the FMA loop below can stay a real loop (fully unrolled, hipcc hoists all
+    // 27 x COUT/4 weight reads ahead of the FMAs and needs ~390 VGPRs)
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
-#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy * p.stride - p.pad + ky;
-#pragma unroll 1
+#pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox * p.stride - p.pad + kx;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float* src = p.x + ((size_t)(n * p.H + iy) * p.W + ix) * 3;
-            float xv[3];
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) xv[ci] = ok ? src[ci] : 0.f;
+            const float* src = p.x + ((size_t)(n * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * 3;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float* wr = ws + ((ky * 3 + kx) * 3 + ci) * COUT;
-#pragma unroll
-                for (int c = 0; c < COUT; c += 4) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-                    acc[c + 0] = fmaf(xv[ci], wv[0], acc[c + 0]);
-                    acc[c + 1] = fmaf(xv[ci], wv[1], acc[c + 1]);
-                    acc[c + 2] = fmaf(xv[ci], wv[2], acc[c + 2]);
-                    acc[c + 3] = fmaf(xv[ci], wv[3], acc[c + 3]);
-                }
+                const float v = src[ci];
+                xs[((ky * 3 + kx) * 3 + ci) * 256 + threadIdx.x] = ok ? v : 0.f;
             }
         }
     }
-    float* out = p.y + (size_t)m * COUT;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll 3
+    for (int t = 0; t < 27; ++t) {
+        const float x = xs[t * 256 + threadIdx.x];
+        const float* wr = ws + t * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+            acc[c + 0] = fmaf(x, wv[0], acc[c + 0]);
+            acc[c + 1] = fmaf(x, wv[1], acc[c + 1]);
+            acc[c + 2] = fmaf(x, wv[2], acc[c + 2]);
+            acc[c + 3] = fmaf(x, wv[3], acc[c + 3]);
+        }
+    }
+    // Store through the LDS: a thread owns one pixel = COUT contiguous floats, so direct stores would touch 64 cache
+    // lines per wave instruction; staged, each store instruction writes 1 KB contiguous.
+    static_assert(COUT == 32, "staging layout below assumes 32 output channels");
+    constexpr int SROWF = COUT + 4;                      // staged row stride in floats (pad: conflict-free writes)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                     // every thread is done with its xs column
+    float* stage = xs + wave * 64 * SROWF;
 #pragma unroll
     for (int c = 0; c < COUT; c += 4) {
         f32x4 v;
@@ -279,7 +293,17 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
             if (p.act) t = t > 0.f ? t : 0.1f * t;
             v[q] = t;
         }
-        *reinterpret_cast<f32x4*>(out + c) = v;
+        *reinterpret_cast<f32x4*>(stage + lane * SROWF + c) = v;
+    }
+    __syncthreads();
+    const int m_wave = blockIdx.x * 256 + wave * 64;
+#pragma unroll
+    for (int i = 0; i < COUT / 4; ++i) {
+        const int f = i * 64 + lane;                     // float4 index inside the wave's 64 x COUT block
+        const int pix = f / (COUT / 4), c4 = f % (COUT / 4);
+        if (m_wave + pix < p.M)
+            *reinterpret_cast<f32x4*>(p.y + (size_t)(m_wave + pix) * COUT + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(stage + pix * SROWF + c4 * 4);
     }
 }
 
