@@ -65,3 +65,19 @@ def gpu_model():
     ops = misc_utils.load_weights(y3.global_variables(scope='yolov3'), path)
     misc_utils.run_ops(ops)
     return model, params
+
+
+@pytest.fixture
+def isolated_graph():
+    """Run a test on an empty variable store and put the previous one back afterwards, so that tests which build
+    their own networks (y3.reset_default_graph(), the script twins) cannot invalidate the session-scoped `gpu_model`."""
+    from yolov3_tensorflow_amd import framework as fw
+    saved = dict(fw._VARIABLES)
+    fw._VARIABLES.clear()
+    fw._bump_global_version()
+    try:
+        yield
+    finally:
+        fw._VARIABLES.clear()
+        fw._VARIABLES.update(saved)
+        fw._bump_global_version()

@@ -128,7 +128,7 @@ def test_evaluate_on_cpu_and_gpu_through_the_hip_nms(g):
 
 
 @pytest.mark.gpu
-def test_eval_script_batched_equals_per_image(tmp_path, capsys):
+def test_eval_script_batched_equals_per_image(tmp_path, capsys, isolated_graph):
     """eval.py end to end on a synthetic 6-image / 5-class set with random weights: the batched device path
     (--batch_size 4, ragged last batch) reports what the one-image-per-step path (--batch_size 1, the reference's
     shape) reports; the report has the reference's lines."""
@@ -198,7 +198,7 @@ def test_color_table_matches_the_reference(g):
 
 
 @pytest.mark.gpu
-def test_single_image_script(tmp_path, capsys):
+def test_single_image_script(tmp_path, capsys, isolated_graph):
     """test_single_image.py twin on a synthetic picture with random weights: both resize modes run, print the three
     blocks the reference prints, write the annotated file, and return detections inside the picture frame."""
     import sys

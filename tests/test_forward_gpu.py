@@ -114,3 +114,61 @@ def test_bad_input_raises(gpu_model):
             model.forward(np.zeros((1, 100, 100, 3), np.float32))    # not a multiple of 32
         with pytest.raises(ValueError):
             model.forward(np.zeros((1, 64, 64, 4), np.float32))      # not RGB
+
+
+def test_rebuilt_graph_never_sees_the_previous_graphs_packed_weights(isolated_graph):
+    """Regression: the packed-weight caches are keyed by (variable name, version).  Two networks built one after the
+    other under the same names (reset_default_graph in between) with different weights must each produce their own
+    outputs — versions are unique across the process, not per variable."""
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import framework as fw
+    from conftest import COCO_ANCHORS
+    from oracle import yolo_ref
+    x = blob_images(5, 1, 96)
+    outs, seen = [], set()
+    for seed in (3, 4):
+        y3.reset_default_graph()
+        params = yolo_ref.synthetic_params(80, seed=seed)
+        model = y3.yolov3(80, COCO_ANCHORS)
+        with y3.variable_scope('yolov3'):
+            model.forward(torch.zeros(1, 32, 32, 3))
+            for v in y3.global_variables(scope='yolov3'):
+                v.assign(params[v.op_name])
+                assert v.version not in seen
+                seen.add(v.version)
+            fms = model.forward(x, False)
+        ref = yolo_ref.forward(params, x, dtype=torch.float64)
+        for g, r in zip(fms, ref):
+            _cmp(g.cpu().numpy(), r, 'rebuilt graph, seed %d' % seed)
+        outs.append(fms[0].cpu().numpy())
+    assert np.abs(outs[0] - outs[1]).max() > 1e-3
+
+
+def test_inference_after_head_only_training_uses_the_updated_moving_statistics(isolated_graph):
+    """Regression: a training-mode forward updates the moving mean/variance of EVERY BN layer in place, also of layers
+    whose gamma/beta are frozen (update_part = head): the folded inference parameters must follow."""
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    from conftest import COCO_ANCHORS
+    from oracle import yolo_ref, train_ref
+    params = yolo_ref.synthetic_params(80, seed=6)
+    model = y3.yolov3(80, COCO_ANCHORS, batch_norm_decay=0.5)
+    x = blob_images(8, 2, 96)
+    yts = train_ref.synthetic_targets(9, 2, [96, 96], 80, COCO_ANCHORS, max_boxes=3)
+    with y3.variable_scope('yolov3'):
+        model.forward(torch.zeros(1, 32, 32, 3))
+        for v in y3.global_variables(scope='yolov3'):
+            v.assign(params[v.op_name])
+        before = [f.clone() for f in model.forward(x, False)]
+        head = [v for v in y3.global_variables(scope='yolov3') if v.op_name.startswith('yolov3/yolov3_head')]
+        trainer = training.Trainer(model, config_optimizer('sgd', 0.0), update_vars=head)     # lr 0: only BN stats move
+        trainer.step(x, yts)
+        after = model.forward(x, False)
+    new_params = {v.op_name: v.numpy() for v in y3.global_variables(scope='yolov3')}
+    assert np.abs(new_params['yolov3/darknet53_body/Conv/BatchNorm/moving_mean'] -
+                  params['yolov3/darknet53_body/Conv/BatchNorm/moving_mean']).max() > 1e-4
+    ref = yolo_ref.forward(new_params, x, dtype=torch.float64)
+    for g, r, b in zip(after, ref, before):
+        _cmp(g.cpu().numpy(), r, 'inference after head-only training step')
+        assert float((g - b).abs().max()) > 1e-4

@@ -210,3 +210,4 @@ def test_native_checkpoint_round_trip_scopes_and_optimizer_slots(tmp_path):
     misc_utils.Saver([dv]).restore(path, optimizer=opt2)
     assert opt2.step == 17 and float(opt2.slots[dv.op_name][0].flatten()[0]) == 0.5 and \
         float(opt2.slots[dv.op_name][1].flatten()[0]) == 0.25
+

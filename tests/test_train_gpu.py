@@ -175,7 +175,7 @@ def _fresh_model(params, **kw):
     ('momentum', ['yolov3/yolov3_head'], 'f32'),
     # forward + stride-1 data gradients on the bf16 matrix pipe: same oracle, same tolerances
     ('sgd', None, 'f32_bf16x6'), ('adam', None, 'f32_bf16x6')])
-def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype):
+def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated_graph):
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd import training
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
@@ -235,7 +235,7 @@ def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype):
                                       params[body_w])
 
 
-def test_train_step_is_deterministic_and_loss_decreases():
+def test_train_step_is_deterministic_and_loss_decreases(isolated_graph):
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd import training
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer

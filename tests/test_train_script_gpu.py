@@ -37,7 +37,7 @@ def make_dataset(tmp_path, n=8, size=160, seed=0):
     return str(ann), str(names)
 
 
-def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys):
+def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys, isolated_graph):
     import yolov3_tensorflow_amd as y3
     sys.path.insert(0, ROOT)
     import train as train_script

@@ -5,6 +5,7 @@ torch is used only as the owner of device memory and streams: every tensor hande
 contiguous fp32 torch tensor on a HIP device, passed as a raw pointer.
 """
 import contextlib
+import itertools
 import ctypes
 import threading
 
@@ -22,8 +23,15 @@ def _scope_stack():
     return _state.stack
 
 
+_VERSION_COUNTER = itertools.count(1)
+
+
 class Variable(object):
-    """A named, device-resident fp32 parameter (the analogue of a tf.Variable)."""
+    """A named, device-resident fp32 parameter (the analogue of a tf.Variable).
+
+    `version` changes on every assignment and is unique across ALL variables of the process (one global counter), so
+    that (op_name, version) identifies a value even after reset_default_graph() re-creates a variable of the same
+    name — the packed-weight caches are keyed by it."""
 
     def __init__(self, name, shape, trainable=True):
         self.name = name                      # e.g. 'yolov3/darknet53_body/Conv_1/weights:0'
@@ -48,9 +56,13 @@ class Variable(object):
         else:
             t = torch.from_numpy(arr).to(dev)
         self.tensor = t
-        self.version += 1
-        _bump_global_version()
+        self.touch()
         return self
+
+    def touch(self):
+        """Mark the value as changed (after an in-place update of .tensor)."""
+        self.version = next(_VERSION_COUNTER)
+        _bump_global_version()
 
     def numpy(self):
         return self.tensor.detach().cpu().numpy()

@@ -173,6 +173,8 @@ def forward_train(model, x):
                                            ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay),
                                            fw.ptr(stats[0]), fw.ptr(stats[1]), fw.ptr(stats[2]), fw.ptr(stats[3]),
                                            fw.ptr(mmean.tensor), fw.ptr(mvar.tensor), fw.ptr(sc)))
+            mmean.touch()      # updated in place: the folded inference parameters must be rebuilt
+            mvar.touch()
             y = torch.empty_like(z)
             resid = tens[l['resid']] if l['resid'] >= 0 else None
             _lib.check(L.y3_bn_apply_fwd(ctx, fw.ptr(z), fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(resid), rows,
@@ -455,8 +457,7 @@ class Trainer(object):
                                         ctypes.c_float(self.clip_norm), ctypes.c_float(lr),
                                         ctypes.c_float(self.opt.momentum), ctypes.c_float(decay),
                                         ctypes.c_float(self.opt.beta2), ctypes.c_float(self.opt.epsilon), fw.ptr(sc)))
-            v.version += 1
-        fw._bump_global_version()
+            v.touch()
         self.global_step += 1.0
 
     def step(self, images, y_true):
