@@ -49,7 +49,6 @@ TOL = {0: 1e-4, 3: 1e-4, 2: 2e-3}
 
 def run_gpu(x, w_hwio, scale, shift, k, stride, act, resid=None, x_up=None, planes=0):
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
-    import ctypes
     dev = fw.default_device()
     L = _lib.lib()
     cin_total = w_hwio.shape[2]

@@ -4,7 +4,6 @@ the GPU), and inference replicas need no exchange at all — each rank derives i
 import os
 import tempfile
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

@@ -121,7 +121,6 @@ def test_rebuilt_graph_never_sees_the_previous_graphs_packed_weights(isolated_gr
     other under the same names (reset_default_graph in between) with different weights must each produce their own
     outputs — versions are unique across the process, not per variable."""
     import yolov3_tensorflow_amd as y3
-    from yolov3_tensorflow_amd import framework as fw
     from conftest import COCO_ANCHORS
     from oracle import yolo_ref
     x = blob_images(5, 1, 96)

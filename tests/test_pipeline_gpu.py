@@ -9,7 +9,6 @@ GPU, against the same pipeline in the CPU oracle.
     difference must be explained by a near-threshold margin."""
 import numpy as np
 import pytest
-import torch
 
 from conftest import blob_images
 

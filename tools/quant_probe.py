@@ -1,7 +1,6 @@
 """Probe: same conv (3x3 128->256) with M chosen so the block count is / is not a multiple of the 512
 co-resident slots -> separates tile-quantisation loss from steady-state efficiency."""
 import os, sys
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yolov3_tensorflow_amd import engine, framework as fw, _lib

@@ -4,7 +4,7 @@ The product path has NO fallback: if the HIP library is missing or fails to load
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libyolo355.so")
