@@ -16,6 +16,9 @@ conv in its stream-K schedule (32 of the 75 conv layers, ~84 % of the FLOPs, ~70
 matrix-pipe bound in fp32: achieved = algorithmic FLOPs of those 32 launches / the sum of
 their durations, measured with hipEvents recorded on the launch stream inside the timed region (one event
 before the kernel, one between it and its fix-up kernel), peak = 157.3 TFLOP/s (fp32 MFMA).
+fast_path: after the timed region the same steps are repeated with compute_dtype='f32_bf16x6' (fp32 tensors, every
+product rebuilt from six bf16 matrix-pipe products, fp32 accumulation) and reported next to the
+exact-fp32 `value` together with the max deviation between the two sets of feature maps.  It is never `value`.
 cpu_baseline: the CPU oracle's torch-fp32 restatement of the same graph ("port"; the literal TF-CPU
 reference cannot run here: no TensorFlow), same weights, a bounded sample, rank 0 and N=1 only.
 """

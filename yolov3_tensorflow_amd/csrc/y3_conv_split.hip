@@ -9,9 +9,12 @@
 // Why: the exact fp32 MFMA (v_mfma_f32_32x32x2_f32) peaks at 157 TF/s; six bf16 MFMAs per fp32 product run at
 // 2.5 PF / 6 = 417 TF/s fp32-equivalent (SURVEY.md hard part 1 names this route).
 //
-// Tile: 128 x {128,64,32}, 16 K elements per step, 4 waves; LDS rows are 32 data bytes + 16 pad per plane
-// (conflict-free ds_read_b128 fragments).  A K-step is only 24 MFMAs x 32 cycles per wave, shorter than the
-// memory latency, so global loads run TWO K-steps ahead in two alternating register sets.
+// Tile: 128 x {128,64,32}, 16 K elements per step, 4 waves; LDS rows are 32 bytes per plane, unpadded, with the two
+// 16-byte halves XOR-swizzled (conflict-free ds_read_b128 fragments and staging writes).  A K-step is only 24 MFMAs
+// x 32 cycles per wave, shorter than the memory latency, so global loads run TWO K-steps ahead in two alternating
+// register sets; a work item of the stream-K partition is a PAIR of K-steps so that the set index is static.
+// The same kernel computes the stride-1 data gradients of training (wrev: flipped kernel, transposed weight
+// packing).  Design notes, measurements and rejected variants: DESIGN.md 4.3.
 #include <type_traits>
 #include "y3_conv_common.h"
 
