@@ -142,6 +142,34 @@ def cpu_baseline(model_vars, budget_s=20.0):
                       "best of {64,32,16} threads on a %d-core host" % (reps, SIZE, SIZE, ncpu)}
 
 
+def measure_fast_path(model, y3, x, fms, args, barrier, distributed, dist, world):
+    """The bench workload once more with compute_dtype='f32_bf16x6' (outside the timed region of `value`)."""
+    import torch
+    exact = [f.clone() for f in fms]
+    model.compute_dtype = 'f32_bf16x6'
+    try:
+        with y3.variable_scope('yolov3'):
+            for _ in range(args.warmup):
+                fms2 = model.forward(x, False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fms2 = model.forward(x, False)
+            barrier()
+            el2 = time.perf_counter() - t0
+    finally:
+        model.compute_dtype = 'f32'
+    if distributed:
+        t = torch.tensor([el2], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+    return {"precision": "f32_bf16x6: fp32 tensors, each product = 6 bf16 plane products, fp32 accumulate",
+            "value": round(world * BATCH * args.steps / el2, 2), "unit": "images/s",
+            "ms_per_step": round(el2 / args.steps * 1e3, 4),
+            "max_abs_diff_vs_exact_fp32": float(max((a - b).abs().max().item() for a, b in zip(exact, fms2))),
+            "max_abs_feature": float(max(a.abs().max().item() for a in exact))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -221,27 +249,11 @@ def main():
     # workload with the products on the bf16 matrix pipe, and its deviation from the exact-fp32 feature maps.
     fast = None
     if not bf16 and not split:
-        exact = [f.clone() for f in fms]
-        model.compute_dtype = 'f32_bf16x6'
-        with y3.variable_scope('yolov3'):
-            for _ in range(args.warmup):
-                fms2 = model.forward(x, False)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fms2 = model.forward(x, False)
-            barrier()
-            el2 = time.perf_counter() - t0
-        model.compute_dtype = 'f32'
-        if distributed:
-            t = torch.tensor([el2], device='cuda', dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        fast = {"precision": "f32_bf16x6: fp32 tensors, each product = 6 bf16 plane products, fp32 accumulate",
-                "value": round(world * BATCH * args.steps / el2, 2), "unit": "images/s",
-                "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                "max_abs_diff_vs_exact_fp32": float(max((a - b).abs().max().item() for a, b in zip(exact, fms2))),
-                "max_abs_feature": float(max(a.abs().max().item() for a in exact))}
+        try:
+            fast = measure_fast_path(model, y3, x, fms, args, barrier, distributed, dist, world)
+        except Exception as e:      # the secondary measurement must never cost the primary line
+            fast = {"error": "%s: %s" % (type(e).__name__, e)}
+            model.compute_dtype = 'f32'
 
     if distributed:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
