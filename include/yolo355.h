@@ -98,6 +98,16 @@ int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, 
 int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 
+/* ---- Winograd F(2x2,3x3) form of the stride-1 3x3 conv (exact fp32 arithmetic, 2.25x fewer multiplies) ------------
+ * Same tensors and epilogue as y3_conv2d_fwd (utils/layer_utils.py:9-22,25-32) for the convs
+ * y3_conv_wino_eligible accepts (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cin >= 64,
+ * Cout %% 32 == 0).  w_wino = G g G^T per (cin, cout), packed [16][cin/8][cout][8] fp32 (16*cin*cout floats) by
+ * y3_pack_conv_weights_wino.  Results differ from the direct kernel by a few fp32 roundings per term. */
+int y3_conv_wino_eligible(const y3_conv_desc* d);
+int y3_pack_conv_weights_wino(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino);
+int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino, const float* scale,
+                       const float* shift, const float* residual, float* y);
+
 /* ---- fp32 on the bf16 matrix pipe ----------------------------------------------------------------------------
  * Same contract and tensors as y3_conv2d_fwd (fp32 NHWC in, fp32 out, same epilogue, same workspace rule); every
  * fp32 product a*b is rebuilt from bf16 plane products with fp32 accumulation: planes = 3 splits each operand

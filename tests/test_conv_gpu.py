@@ -199,3 +199,49 @@ def test_bad_arguments_raise_value_error():
         engine.conv2d_fwd(x, torch.zeros(9 * 32 * 32, device=dev), s, s, 3, 2, 32, True)
     with pytest.raises(ValueError):
         engine.conv2d_fwd(x, torch.zeros(25 * 32 * 32, device=dev), s, s, 5, 1, 32, True)
+
+
+WINO_CASES = [
+    # n, h, w, cin, cout, act, resid
+    (3, 20, 28, 64, 128, True, True),      # even map, ragged last tile block
+    (2, 13, 13, 512, 1024, True, True),    # odd map (7x7 tiles, last tile half outside), deepest layer shape
+    (1, 26, 26, 256, 512, True, False),
+    (2, 52, 52, 128, 256, True, True),     # true-size 52x52 residual-stage conv
+    (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear
+    (1, 2, 2, 96, 32, True, False),        # one tile per image; Cin not a power of two
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,act,resid', WINO_CASES)
+def test_winograd_conv_matches_fp64(n, h, w, cin, cout, act, resid):
+    """y3_conv2d_fwd_wino (F(2x2,3x3), exact fp32 arithmetic) against the fp64 reference at the direct kernel's
+    tolerance, and against the direct kernel itself."""
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    dev = fw.default_device()
+    rng = np.random.RandomState(n * 100 + h + cin)
+    x, wt, scale, shift = make_case(rng, n, h, w, 3, cin, cout)
+    r = rng.standard_normal((n, h, w, cout)).astype(np.float32) if resid else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 1)
+    assert _lib.lib().y3_conv_wino_eligible(d) == 1
+    wu = engine.pack_wino(t(wt))
+    got = engine.conv2d_fwd_wino(t(x), wu, t(scale), t(shift), cout, act, residual=t(r))
+    torch.cuda.synchronize()
+    want = ref_conv(x, wt, scale, shift, 3, 1, act, r)
+    check(got.cpu().numpy(), want, 'winograd %dx%dx%d %d->%d' % (n, h, w, cin, cout))
+    direct = run_gpu(x, wt, scale, shift, 3, 1, act, r)
+    assert np.abs(got.cpu().numpy() - direct).max() <= 2e-4 * (1 + np.abs(want).max())
+
+
+def test_winograd_eligibility_and_errors():
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    L = _lib.lib()
+    for args, ok in (((1, 8, 8, 64, 0, 64, 3, 1, 1), 1), ((1, 8, 8, 64, 0, 64, 3, 2, 1), 0),
+                     ((1, 8, 8, 64, 0, 64, 1, 1, 1), 0), ((1, 8, 8, 32, 0, 64, 3, 1, 1), 0),
+                     ((1, 8, 8, 64, 0, 255, 3, 1, 1), 0), ((1, 8, 8, 96, 32, 64, 3, 1, 1), 0)):
+        assert L.y3_conv_wino_eligible(_lib.ConvDesc(*args)) == ok, args
+    dev = fw.default_device()
+    x = torch.zeros((1, 8, 8, 32), device=dev)
+    with pytest.raises(ValueError):
+        engine.conv2d_fwd_wino(x, torch.zeros(16 * 32 * 64, device=dev), torch.ones(64, device=dev),
+                               torch.zeros(64, device=dev), 64, True)

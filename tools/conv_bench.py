@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--planes', type=int, default=0, help='0: exact fp32 MFMA; 2/3: split-bf16 kernel')
+    ap.add_argument('--wino', action='store_true', help='Winograd kernel for the eligible 3x3 s1 shapes')
     ap.add_argument('--only', type=int, default=-1, help='run only this row of the shape table')
     a = ap.parse_args()
     import torch
@@ -60,6 +61,9 @@ def main():
         sh = torch.zeros(cout, device=dev)
         r = torch.randn((n, h // s, h // s, cout), device=dev) if resid else None
         run = lambda: engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, planes=a.planes)
+        if a.wino and k == 3 and s == 1 and cin >= 64:
+            wu = engine.pack_wino(w)
+            run = lambda: engine.conv2d_fwd_wino(x, wu, sc, sh, cout, True, residual=r)
         for _ in range(3):
             y = run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -64,6 +64,20 @@ extern "C" int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int plane
                                 workspace_bytes);
 }
 
+extern "C" int y3_conv_wino_eligible(const y3_conv_desc* d) { return y3_conv_wino_eligible_impl(d); }
+
+extern "C" int y3_pack_conv_weights_wino(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino) {
+    Y3_CHECK_ARG(ctx && w_hwio && w_wino, "y3_pack_conv_weights_wino: null argument");
+    Y3_CHECK_ARG(cin > 0 && cout > 0 && cin % 8 == 0, "y3_pack_conv_weights_wino: cin must be a positive multiple of 8");
+    return y3_launch_pack_wino(ctx->stream, w_hwio, cin, cout, w_wino);
+}
+
+extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino,
+                                  const float* scale, const float* shift, const float* residual, float* y) {
+    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_wino: null context");
+    return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y);
+}
+
 extern "C" int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int cin, int dz_stride,
                                                 int planes, void* w_split) {
     Y3_CHECK_ARG(ctx && w_d && w_split, "y3_pack_conv_weights_split_dgrad: null argument");

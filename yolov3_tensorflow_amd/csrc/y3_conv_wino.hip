@@ -1,0 +1,349 @@
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 conv (+ folded BN + LeakyReLU + residual), exact fp32 arithmetic on
+// v_mfma_f32_32x32x2_f32.  Replaces the same reference code as y3_conv.hip (utils/layer_utils.py:9-22,25-32) for the
+// layers where the direct kernel is bound by the fp32 matrix pipe: 16 multiplies per 2x2 output tile and channel pair
+// instead of 36 (2.25x less MFMA work).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, summed over input channels
+//
+//   * weights U = G g G^T are transformed once at load time and packed [16][Cin/8][Cout][8]
+//     (y3_pack_conv_weights_wino): a K-step's B tile is 16 contiguous [Cout][8] slabs;
+//   * a workgroup owns BT = 64 output tiles x 64 output channels for ALL 16 transform positions: each of its four
+//     waves accumulates 16 independent 32(tiles) x 32(channels) products = 256 accumulator registers, so the kernel
+//     runs one wave per SIMD with the accumulators in AGPRs;
+//   * K-step = 8 input channels = 64 MFMAs (4096 cycles) per wave.  Waves 0-1 stage the activations: each thread
+//     gathers the 4x4 input patch of one tile for 4 channels (16 bounds-checked 16-byte loads, padding = OOB = 0),
+//     applies B^T d B on the float4s in registers (32 vector adds) and writes the 16 transformed float4s to the LDS;
+//     waves 2-3 copy the K-step's weight slabs.  Loads for K-step s+1 are issued before the MFMAs of K-step s
+//     (register prefetch, double-buffered LDS);
+//   * LDS rows are 32 bytes (8 channels) per (position, tile|channel), halves XOR-swizzled as in y3_conv_split.hip;
+//   * epilogue: the 16 position sums of one (tile, channel) live in the same lane and register index of the 16
+//     accumulator sets, so A^T M A is 24 adds per output tile in registers; then scale/shift, LeakyReLU, residual,
+//     and 128-byte-per-half-wave stores.
+// Numerics: the transforms use only additions and the constants 1/2, so the result differs from the direct sum by a
+// few fp32 roundings per term (tests/test_conv_gpu.py holds it to the same 1e-4 tolerance against fp64).
+#include "y3_internal.h"
+
+namespace {
+
+struct WinoArgs {
+    const float* x;      // [N,H,W,Cin]
+    const float* u;      // packed [16][Cin/8][Cout][8]
+    const float* scale;  // [Cout]
+    const float* shift;  // [Cout]
+    const float* resid;  // [N,H,W,Cout] or nullptr
+    float* y;            // [N,H,W,Cout]
+    int N, H, W, Cin, Cout, act;
+    int TH, TW, T;       // 2x2 output tiles per image column / row, and in total
+};
+
+constexpr int WKC = 8;                   // input channels per K-step
+constexpr int WROW = 32;                 // LDS bytes per row (8 floats)
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ int lds_off(int row, int half) { return row * WROW + ((half ^ ((row >> 3) & 1)) << 4); }
+
+// B^T d B on float4s (4 channels at once).  d[i][j], i = patch row, j = patch column; result v[i*4+j].
+__device__ __forceinline__ void input_transform(const f32x4 (&d)[16], f32x4 (&v)[16]) {
+    f32x4 t[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // rows: B^T d
+        t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+        t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+        t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+        t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // columns: (B^T d) B
+        v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+        v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+        v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+        v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+    }
+}
+
+template <int WGM, int WGN>
+__global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int BT = WGM * 32, BNW = WGN * 32;
+    constexpr int PLANE_V = BT * WROW, PLANE_U = BNW * WROW;          // bytes per transform position
+    constexpr int STAGE_V = 16 * PLANE_V, STAGE_U = 16 * PLANE_U;
+    static_assert(BT * 2 <= 128 && 16 * BNW * 2 <= 128 * 16, "staging assignment below assumes BT <= 64, BNW <= 64");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Vs = smem;                    // [2][16][BT][32 B]
+    unsigned char* Us = smem + 2 * STAGE_V;      // [2][16][BNW][32 B]
+    // per tile of this workgroup: index of output pixel (n, 2ty, 2tx) (-1: no such tile) and which of the 2x2 outputs
+    // exist (bit dy*2+dx) — written once by the staging threads, read by the epilogue
+    int* tile_pix = reinterpret_cast<int*>(smem + 2 * STAGE_V + 2 * STAGE_U);   // [BT]
+    int* tile_ok = tile_pix + BT;                                                // [BT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int nbt = (p.T + BT - 1) / BT;
+    // XCD-contiguous, column-major block id: the workgroups of one XCD share a weight panel
+    const int nt = gridDim.x;
+    const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+    const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    const int bn = blk / nbt, bt = blk - bn * nbt;
+    const int t0 = bt * BT, n0 = bn * BNW;
+    const int ksteps = p.Cin / WKC;
+
+    // ---- staging roles (wave-uniform) ----------------------------------------------------------------------
+    // waves 0-1 (threads [0, 128)): activation patch of tile (tid>>1), channel quad (tid&1) of the K-step
+    // waves 2-3 (threads [128, 256)): weight pieces: 16 positions x BNW channels x 2 halves = 32*BNW pieces, 16 each
+    static_assert(2 * BT == 128, "waves 0-1 stage one (tile, channel quad) per thread");
+    const bool is_a = __builtin_amdgcn_readfirstlane(wave) < 2;
+    // one buffer descriptor per wave: the activation tensor for waves 0-1, the packed weights for waves 2-3
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(is_a ? p.x : p.u), 0,
+        (unsigned)(is_a ? (size_t)p.N * p.H * p.W * p.Cin * 4 : (size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
+    unsigned voff[16];            // A: byte offsets of the 16 patch pixels (OOB where padded); U: piece offsets
+    const int a_tile = tid >> 1, a_quad = tid & 1;
+    if (is_a) {
+        const int t = t0 + a_tile;
+        int n = 0, ty = 0, tx = 0;
+        const bool tok = t < p.T;
+        if (tok) {
+            n = t / (p.TH * p.TW);
+            const int rem = t - n * p.TH * p.TW;
+            ty = rem / p.TW;
+            tx = rem - ty * p.TW;
+        }
+        if (a_quad == 0) {
+            tile_pix[a_tile] = tok ? (n * p.H + 2 * ty) * p.W + 2 * tx : -1;
+            tile_ok[a_tile] = !tok ? 0 : 1 | ((2 * tx + 1 < p.W) ? 2 : 0) | ((2 * ty + 1 < p.H) ? 4 : 0) |
+                                             ((2 * tx + 1 < p.W && 2 * ty + 1 < p.H) ? 8 : 0);
+        }
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = y0 + i, xx = x0 + j;
+                const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                voff[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_quad * 4) * 4u : OOB;
+            }
+    } else {
+        // piece q = (tid-128) + 128*j, j < 16 (only 32*BNW/128 of them exist): position = q / (2*BNW),
+        // channel = (q / 2) % BNW, half = q & 1.  Packed weights: [pos][Cin/8][Cout][8] floats.
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = (tid - 128) + 128 * j;
+            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+            const bool ok = q < 32 * BNW && (n0 + co) < p.Cout;
+            voff[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
+        }
+    }
+
+    f32x4 reg[16];
+    auto issue = [&](int ks) {
+        // A: channels ks*8 + quad*4 .. +3 of the 16 patch pixels.  U: slab (pos, ks) = [Cout][8] floats.
+        const unsigned soff = is_a ? (unsigned)(ks * WKC) * 4u : (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], soff, 0));
+    };
+    auto store = [&](int buf) {
+        if (is_a) {
+            f32x4 v[16];
+            input_transform(reg, v);
+            unsigned char* vs = Vs + buf * STAGE_V + lds_off(a_tile, a_quad);
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x4*>(vs + pos * PLANE_V) = v[pos];
+        } else {
+            unsigned char* us = Us + buf * STAGE_U;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int q = (tid - 128) + 128 * j;
+                if (q < 32 * BNW) {
+                    const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+                    *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = reg[j];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+
+    const int frag_a = lds_off(wm * 32 + (lane & 31), lane >> 5);
+    const int frag_b = lds_off(wn * 32 + (lane & 31), lane >> 5);
+    auto compute = [&](int buf) {
+        const unsigned char* vs = Vs + buf * STAGE_V + frag_a;
+        const unsigned char* us = Us + buf * STAGE_U + frag_b;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {            // four positions at a time: 8 fragment reads, 16 MFMAs
+            f32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 4 + i) * PLANE_V);
+                b[i] = *reinterpret_cast<const f32x4*>(us + (g * 4 + i) * PLANE_U);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[g * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[i][j], acc[g * 4 + i], 0, 0, 0);
+        }
+    };
+
+    issue(0);
+    store(0);
+    __syncthreads();
+    for (int ks = 0; ks + 1 < ksteps; ++ks) {
+        // Pin the order loads(ks+1) | MFMAs(ks) | transform + LDS writes(ks+1): left alone, hipcc either sinks the
+        // loads below the MFMAs or hoists the writes (and the wait for the loads) above them to shorten the 64 live
+        // load registers — both expose the full load latency every K-step.  (Measured: scheduling the transform into
+        // the MFMA gaps needs the MFMAs and the staging code in one basic block, which spills 300-900 VGPRs.)
+        issue(ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store((ks + 1) & 1);
+        __syncthreads();
+    }
+    compute((ksteps - 1) & 1);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------
+    // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
+    // (2) all threads: float4 rows of the staging tile -> scale/shift, LeakyReLU, + residual -> global, 16 B per lane
+    constexpr int LDC = BNW + 4;
+    static_assert((size_t)BT * 4 * LDC * 4 <= (size_t)2 * (STAGE_V + STAGE_U), "output staging must fit in the tile LDS");
+    float* cs = reinterpret_cast<float*>(smem);
+    __syncthreads();                 // every wave is done reading the last K-step's tiles
+    {
+        const int col = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // D layout of the 32x32 MFMA: row (= tile) = (r&3) + 8*(r>>2) + 4*(lane>>5), column (= channel) = lane&31
+            const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float m[16];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) m[pos] = acc[pos][r];
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+            }
+            float* row = cs + (tl * 4) * LDC + col;
+            row[0 * LDC] = s0[0] + s0[1] + s0[2];       // (dy,dx) = (0,0)
+            row[1 * LDC] = s0[1] - s0[2] - s0[3];       // (0,1)
+            row[2 * LDC] = s1[0] + s1[1] + s1[2];       // (1,0)
+            row[3 * LDC] = s1[1] - s1[2] - s1[3];       // (1,1)
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int C4 = BNW / 4;            // float4 columns per staged row
+        constexpr int RPP = 256 / C4;          // rows per pass
+        constexpr int PASSES = BT * 4 / RPP;
+        const int tc = (tid % C4) * 4, tr = tid / C4;
+        const int co = n0 + tc;
+        const bool cok = co < p.Cout;           // Cout % 4 == 0
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (cok) {
+            sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+            sh = *reinterpret_cast<const f32x4*>(p.shift + co);
+        }
+        size_t off[PASSES];
+        bool ok[PASSES];
+        f32x4 res[PASSES];
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int rr = tr + i * RPP;                       // staged row = tile*4 + dy*2 + dx
+            const int tl = rr >> 2, q = rr & 3;
+            const int pix = tile_pix[tl];
+            ok[i] = cok && ((tile_ok[tl] >> q) & 1) != 0;
+            off[i] = ((size_t)(pix + (q >> 1) * p.W + (q & 1))) * p.Cout + co;
+            res[i] = (ok[i] && p.resid) ? *reinterpret_cast<const f32x4*>(p.resid + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            if (!ok[i]) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + i * RPP) * LDC + tc);
+            v = v * sc + sh;
+            if (p.act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+            }
+            v += res[i];
+            *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
+        }
+    }
+}
+
+// U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
+__global__ void pack_weights_wino_kernel(const float* __restrict__ w_hwio, float* __restrict__ out, int cin, int cout) {
+    const size_t total = (size_t)cin * cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i / cout), co = (int)(i % cout);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                                t[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                out[(((size_t)(a * 4 + b) * (cin / WKC) + ci / WKC) * cout + co) * WKC + (ci % WKC)] = u[b];
+        }
+    }
+}
+
+}  // namespace
+
+int y3_conv_wino_eligible_impl(const y3_conv_desc* d) {
+    return d && d->k == 3 && d->stride == 1 && d->c_up == 0 && d->cin % 32 == 0 && d->cout % 32 == 0 && d->cin >= 64 &&
+           d->n > 0 && d->h > 1 && d->w > 1;
+}
+
+int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {
+    const size_t total = (size_t)cin * cout;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
+                        const float* shift, const float* residual, float* y) {
+    Y3_CHECK_ARG(d && x && u && scale && shift && y, "y3_conv2d_fwd_wino: null pointer argument");
+    Y3_CHECK_ARG(y3_conv_wino_eligible_impl(d),
+                 "y3_conv2d_fwd_wino: needs a 3x3 stride-1 conv with Cin %% 32 == 0, Cin >= 64, Cout %% 32 == 0 and no "
+                 "fused upsample input");
+    const long long M = (long long)d->n * d->h * d->w;
+    Y3_CHECK_ARG(M * d->cin < (1LL << 29) && M * d->cout < (1LL << 29),
+                 "y3_conv2d_fwd_wino: tensor exceeds 2^29 elements (32-bit byte offsets)");
+    WinoArgs a;
+    a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
+    a.TH = (d->h + 1) / 2; a.TW = (d->w + 1) / 2; a.T = d->n * a.TH * a.TW;
+    constexpr int BT = 64, BNW = 64;
+    constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
+    auto kern = conv_wino_f32_kernel<2, 2>;
+    static bool attr_set = false;   // benign race (idempotent)
+    if (!attr_set) {
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int nbt = (a.T + BT - 1) / BT, nbn = (a.Cout + BNW - 1) / BNW;
+    hipLaunchKernelGGL(kern, dim3(nbt * nbn), dim3(256), lds, stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}

@@ -52,3 +52,7 @@ int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int 
 int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, const float* x, const float* x_up,
                          const void* w, const float* scale, const float* shift, const float* residual, float* y,
                          void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
+int y3_conv_wino_eligible_impl(const y3_conv_desc* d);
+int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out);
+int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
+                        const float* shift, const float* residual, float* y);

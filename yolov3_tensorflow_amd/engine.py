@@ -127,6 +127,24 @@ def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up
     return y
 
 
+def conv2d_fwd_wino(x, w_wino, scale, shift, cout, act, residual=None):
+    """3x3 stride-1 conv in its Winograd F(2x2,3x3) form (y3_conv2d_fwd_wino); w_wino from pack_wino."""
+    n, h, w, cin = x.shape
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 1 if act else 0)
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().y3_conv2d_fwd_wino(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino),
+                                             fw.ptr(scale), fw.ptr(shift), fw.ptr(residual), fw.ptr(y)))
+    return y
+
+
+def pack_wino(w_hwio):
+    """HWIO [3,3,cin,cout] fp32 device tensor -> Winograd-transformed packing (y3_pack_conv_weights_wino)."""
+    _, _, cin, cout = w_hwio.shape
+    out = torch.empty(16 * cin * cout, dtype=torch.float32, device=w_hwio.device)
+    _lib.check(_lib.lib().y3_pack_conv_weights_wino(fw.context(w_hwio.device), fw.ptr(w_hwio), cin, cout, fw.ptr(out)))
+    return out
+
+
 def upsample_nearest(x, out_h, out_w):
     n, h, w, c = x.shape
     y = torch.empty((n, out_h, out_w, c), dtype=torch.float32, device=x.device)
