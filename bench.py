@@ -142,11 +142,19 @@ def cpu_baseline(model_vars, budget_s=20.0):
                       "best of {64,32,16} threads on a %d-core host" % (reps, SIZE, SIZE, ncpu)}
 
 
-def measure_fast_path(model, y3, x, fms, args, barrier, distributed, dist, world):
-    """The bench workload once more with compute_dtype='f32_bf16x6' (outside the timed region of `value`)."""
+PRECISION_TEXT = {
+    "f32_wino": "exact fp32 MFMA arithmetic; Winograd F(2x2,3x3) kernel for the stride-1 3x3 convs, direct kernel elsewhere",
+    "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), direct implicit-GEMM kernels only",
+    "f32_bf16x6": "fp32 tensors; each product = 6 bf16 plane products, fp32 accumulate (dropped terms <= 2^-23 relative)",
+    "f32_bf16x3": "fp32 tensors; each product = 3 bf16 plane products, fp32 accumulate (dropped terms <= 2^-15 relative)",
+}
+
+
+def measure_other_precision(model, dtype, primary, y3, x, fms, args, barrier, distributed, dist, world):
+    """The bench workload once more with another compute_dtype (outside the timed region of `value`)."""
     import torch
-    exact = [f.clone() for f in fms]
-    model.compute_dtype = 'f32_bf16x6'
+    ref = [f.clone() for f in fms]
+    model.compute_dtype = dtype
     try:
         with y3.variable_scope('yolov3'):
             for _ in range(args.warmup):
@@ -158,16 +166,16 @@ def measure_fast_path(model, y3, x, fms, args, barrier, distributed, dist, world
             barrier()
             el2 = time.perf_counter() - t0
     finally:
-        model.compute_dtype = 'f32'
+        model.compute_dtype = primary
     if distributed:
         t = torch.tensor([el2], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el2 = float(t.item())
-    return {"precision": "f32_bf16x6: fp32 tensors, each product = 6 bf16 plane products, fp32 accumulate",
+    return {"precision": dtype + ": " + PRECISION_TEXT[dtype],
             "value": round(world * BATCH * args.steps / el2, 2), "unit": "images/s",
             "ms_per_step": round(el2 / args.steps * 1e3, 4),
-            "max_abs_diff_vs_exact_fp32": float(max((a - b).abs().max().item() for a, b in zip(exact, fms2))),
-            "max_abs_feature": float(max(a.abs().max().item() for a in exact))}
+            "max_abs_diff_vs_primary": float(max((a - b).abs().max().item() for a, b in zip(ref, fms2))),
+            "max_abs_feature": float(max(a.abs().max().item() for a in ref))}
 
 
 def main():
@@ -178,9 +186,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
                     help="c2 (default, the BASELINE metric): fp32 416x416 bs=32; c5: bf16-storage 608x608 bs=16")
-    ap.add_argument('--precision', choices=['f32', 'f32_bf16x6', 'f32_bf16x3'], default='f32',
-                    help="c2 only. f32: exact fp32 MFMA (default); f32_bf16x6 / f32_bf16x3: fp32 tensors, every "
-                         "product rebuilt from 6 / 3 bf16 plane products with fp32 accumulation")
+    ap.add_argument('--precision', choices=['f32_wino', 'f32', 'f32_bf16x6', 'f32_bf16x3'], default='f32_wino',
+                    help="c2 only. f32_wino (default): exact fp32 MFMA arithmetic, Winograd F(2x2,3x3) kernel for the "
+                         "stride-1 3x3 convs, direct kernel elsewhere; f32: direct kernels only; f32_bf16x6 / "
+                         "f32_bf16x3: fp32 tensors, every product rebuilt from 6 / 3 bf16 plane products with fp32 "
+                         "accumulation")
     args = ap.parse_args()
     global BATCH, SIZE
     bf16 = args.workload == 'c5'
@@ -216,20 +226,33 @@ def main():
     model = y3.yolov3(CLASS_NUM, ANCHORS)
     if bf16:
         model.compute_dtype = 'bf16'
-    split = (not bf16) and args.precision != 'f32'
-    if split:
+    split = (not bf16) and args.precision in ('f32_bf16x6', 'f32_bf16x3')
+    wino = (not bf16) and args.precision == 'f32_wino'
+    if not bf16:
         model.compute_dtype = args.precision
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda',
                    generator=torch.Generator(device='cuda').manual_seed(100 + rank))
     with y3.variable_scope('yolov3'):
         model.forward(torch.zeros((1, 64, 64, 3), device='cuda'))      # create the variables
         random_init(seed=1)
+        if wino:
+            try:
+                model.forward(x, False)
+                torch.cuda.synchronize()
+            except Exception as e:      # never lose the line to the newer kernel: fall back to the direct kernels
+                print("bench.py: f32_wino failed (%s: %s); falling back to --precision f32" % (type(e).__name__, e),
+                      file=sys.stderr)
+                wino = False
+                args.precision = 'f32'
+                model.compute_dtype = 'f32'
         for _ in range(args.warmup):
             fms = model.forward(x, False)
-        model.set_layer_profiling(True)
+        # per-layer hipEvents (for `roofline`) are recorded inside the timed region on every 4th step only: 150 event
+        # records per step cost ~3 % of the step
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            model.set_layer_profiling(i % 4 == 0)
             fms = model.forward(x, False)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -247,13 +270,21 @@ def main():
 
     # Secondary measurement (c2, default precision only; outside the timed region above and never `value`): the same
     # workload with the products on the bf16 matrix pipe, and its deviation from the exact-fp32 feature maps.
-    fast = None
+    fast, direct = None, None
     if not bf16 and not split:
-        try:
-            fast = measure_fast_path(model, y3, x, fms, args, barrier, distributed, dist, world)
-        except Exception as e:      # the secondary measurement must never cost the primary line
-            fast = {"error": "%s: %s" % (type(e).__name__, e)}
-            model.compute_dtype = 'f32'
+        primary = model.compute_dtype
+        for key, dtype in (('fast', 'f32_bf16x6'), ('direct', 'f32')):
+            if dtype == primary:
+                continue
+            try:
+                res = measure_other_precision(model, dtype, primary, y3, x, fms, args, barrier, distributed, dist, world)
+            except Exception as e:      # a secondary measurement must never cost the primary line
+                res = {"error": "%s: %s" % (type(e).__name__, e)}
+                model.compute_dtype = primary
+            if key == 'fast':
+                fast = res
+            else:
+                direct = res
 
     if distributed:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
@@ -265,6 +296,11 @@ def main():
         value = world * BATCH * args.steps / elapsed
         flops = conv_flops(table, BATCH, SIZE, SIZE)
         is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
+        sk_all = np.array(is_sk, bool)
+        if wino:   # dominant family: the Winograd kernel (every stride-1 3x3 conv with Cin >= 64)
+            is_sk = np.array([k == 3 and s == 1 and cin >= 64 and cin % 32 == 0 and cout % 32 == 0
+                              for (k, s, cin, cout, bn) in table])
+            main_ms = np.where(is_sk, layer_ms, main_ms)
         if bf16:   # dominant family: the 3x3 convs on 128x128 tiles (conv_mfma_bf16_kernel<128,128,2,2,3,false>)
             is_sk = np.array([k == 3 and cin != 3 and cout > 64 for (k, s, cin, cout, bn) in table])
         dom_ms = float(main_ms[is_sk].sum())          # the stream-K kernel alone (fix-up excluded)
@@ -272,7 +308,8 @@ def main():
         n_dom = int(is_sk.sum())
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         # split precisions: fp32-equivalent peak = dense bf16 MFMA peak / products per fp32 multiply-add
-        peak = 2500.0 if bf16 else {'f32': PEAK_FP32_MFMA_TFLOPS, 'f32_bf16x6': 2500.0 / 6,
+        peak = 2500.0 if bf16 else {'f32': PEAK_FP32_MFMA_TFLOPS, 'f32_wino': PEAK_FP32_MFMA_TFLOPS,
+                                    'f32_bf16x6': 2500.0 / 6,
                                     'f32_bf16x3': 2500.0 / 3}[args.precision]
         whole = float(flops.sum()) / (float(layer_ms.sum()) * 1e-3) / 1e12
         out = {
@@ -289,12 +326,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if bf16 else "f32",
-            "precision": ("bf16 storage, fp32 accumulate" if bf16 else
-                          {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                           "f32_bf16x6": "fp32 tensors; each product = 6 bf16 plane products, fp32 accumulate "
-                                         "(dropped terms <= 2^-23 relative)",
-                           "f32_bf16x3": "fp32 tensors; each product = 3 bf16 plane products, fp32 accumulate "
-                                         "(dropped terms <= 2^-15 relative)"}[args.precision]),
+            "precision": ("bf16 storage, fp32 accumulate" if bf16 else PRECISION_TEXT[args.precision]),
             "data": "synthetic",
             "config": {"workload": ("configs[4]: Darknet-53 + 3-scale head forward, random weights, 608x608 bs=16 "
                                     "per GPU, bf16 storage / fp32 accumulate, input resident in HBM" if bf16 else
@@ -304,18 +336,21 @@ def main():
                        "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None if (bf16 or split) else traffic_from_profile(),
+                         "traffic": None if (bf16 or split or wino) else traffic_from_profile(),
                          "kernel": ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; "
                                     "staging-bound, see DESIGN.md)" if bf16 else
                                     "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM "
                                     "conv on the bf16 matrix pipe, stream-K schedule; peak = 2500/%d fp32-equivalent)"
                                     % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3)) if split else
+                                    "conv_wino_f32_kernel<2,2> (Winograd F(2x2,3x3) conv, fp32 MFMA; `achieved` counts the "
+                                    "ALGORITHMIC (direct-convolution) FLOPs, so frac can exceed 1: the kernel issues "
+                                    "1/2.25 of them as MFMA work, see mfma_work_frac)" if wino else
                                     "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, "
                                     "stream-K schedule)"),
                          "launches_per_step": n_dom,
                          "avg_launch_ms": round(dom_ms / n_dom, 4),
                          "algorithmic_gflop_per_launch": round(dom_flops / n_dom / 1e9, 3),
-                         "fixup_ms_per_step": round(float((layer_ms - main_ms)[is_sk].sum()), 4),
+                         "fixup_ms_per_step": round(float((layer_ms - main_ms)[sk_all].sum()), 4),
                          "all_3x3_tflops": round(float(flops[is3].sum()) / (float(layer_ms[is3].sum()) * 1e-3) / 1e12, 2),
                          "whole_forward_tflops": round(whole, 2),
                          "sum_layer_ms": round(float(layer_ms.sum()), 4)},
@@ -323,6 +358,11 @@ def main():
         if bf16:
             # algorithmic HBM traffic of the whole bf16 forward: 6.565 GB per bs=16 batch at 608
             out["roofline"]["whole_forward_hbm_tbps"] = round(6.565e9 / (ms_per_step * 1e-3) / 1e12, 3)
+        if wino:
+            out["roofline"]["mfma_work_tflops"] = round(achieved / 2.25, 2)
+            out["roofline"]["mfma_work_frac"] = round(achieved / 2.25 / peak, 4)
+        if direct is not None:
+            out["direct_path"] = direct
         if fast is not None:
             out["fast_path"] = fast
         if world == 1 and not args.no_cpu_baseline and not bf16:

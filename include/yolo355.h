@@ -173,7 +173,9 @@ int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out);
 int y3_net_destroy(y3_net* net);
 /* 0 = fp32 (default), 1 = bf16 storage: layer parameters must then be bf16-packed (fp32 HWIO for layer 0),
  * intermediate activations are bf16, the three feature maps stay fp32.  2 / 3 = fp32 tensors with the products on
- * the bf16 matrix pipe (y3_conv2d_fwd_split with planes = 3 / 2): layer weights from y3_pack_conv_weights_split. */
+ * the bf16 matrix pipe (y3_conv2d_fwd_split with planes = 3 / 2): layer weights from y3_pack_conv_weights_split.
+ * 4 = fp32 with the Winograd kernel for the layers y3_conv_wino_eligible accepts (their weights from
+ * y3_pack_conv_weights_wino), the direct kernel for the rest. */
 int y3_net_set_dtype(y3_net* net, int dtype);
 int y3_net_num_layers(const y3_net* net);
 /* geometry of layer i for input-independent fields: k, stride, cin, cout, has_bn */

@@ -3,7 +3,7 @@ synthetic weights loaded through the darknet-format loader (BASELINE config 3 wi
 Tolerances (stated): feature maps |d| <= 2e-4 + 1e-4*|ref| against the fp64 oracle (the fp32 oracle itself
 sits ~5e-6 from fp64); fused plan vs op-by-op composition: bit-exact.
 The oracle comparisons run for compute_dtype 'f32' (exact fp32 MFMA) and 'f32_bf16x6' (fp32 products rebuilt from
-six bf16 plane products) at the SAME tolerances."""
+six bf16 plane products) and 'f32_wino' (Winograd F(2x2,3x3) for the stride-1 3x3 convs) at the SAME tolerances."""
 import numpy as np
 import pytest
 import torch
@@ -20,7 +20,7 @@ def _cmp(got, want, what, atol=2e-4, rtol=1e-4):
     return float(err.max())
 
 
-DTYPES = ['f32', 'f32_bf16x6']
+DTYPES = ['f32', 'f32_bf16x6', 'f32_wino']
 
 
 @pytest.fixture

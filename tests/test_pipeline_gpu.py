@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ('f32_bf16x3' is deliberately absent: measured 1.2e-3 relative box drift, just outside the 1e-3 north-star bound)
-@pytest.mark.parametrize('dtype', ['f32', 'f32_bf16x6'])
+@pytest.mark.parametrize('dtype', ['f32', 'f32_bf16x6', 'f32_wino'])
 def test_forward_predict_nms_against_oracle(gpu_model, anchors, dtype):
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd.utils import nms_utils

@@ -130,6 +130,7 @@ struct y3_net {
     int class_num;
     int dtype = 0;            // 0: fp32 (exact fp32 MFMA), 1: bf16 storage with fp32 accumulation,
                               // 2 / 3: fp32 tensors, products rebuilt from 3 / 2 bf16 planes (y3_conv_split.hip)
+                              // 4: fp32, Winograd F(2x2,3x3) kernel for the layers y3_conv_wino_eligible accepts
     std::vector<Tensor> tensors;
     std::vector<Layer> layers;
     // cached plan
@@ -300,8 +301,9 @@ extern "C" int y3_net_create(y3_ctx* ctx, int class_num, y3_net** out) {
 
 extern "C" int y3_net_set_dtype(y3_net* net, int dtype) {
     Y3_CHECK_ARG(net, "y3_net_set_dtype: null net");
-    Y3_CHECK_ARG(dtype >= 0 && dtype <= 3,
-                 "y3_net_set_dtype: dtype must be 0 (fp32), 1 (bf16), 2 (fp32 via bf16x6) or 3 (fp32 via bf16x3)");
+    Y3_CHECK_ARG(dtype >= 0 && dtype <= 4,
+                 "y3_net_set_dtype: dtype must be 0 (fp32), 1 (bf16), 2 (fp32 via bf16x6), 3 (fp32 via bf16x3) or "
+                 "4 (fp32, Winograd for the eligible 3x3 convs)");
     net->dtype = dtype;
     net->pn = net->ph = net->pw = 0;   // re-plan
     return Y3_OK;
@@ -423,7 +425,9 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         const int rc = net->dtype == 1
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
-            : net->dtype >= 2
+            : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
+            ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst))
+            : (net->dtype == 2 || net->dtype == 3)
             ? y3_launch_conv_split(st, &d, net->dtype == 2 ? 3 : 2, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift,
                                    ptr(l.resid), ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
                                    ev ? ev[nl + 1 + i] : nullptr)
@@ -443,13 +447,13 @@ extern "C" int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, i
     y3_conv_desc d;
     d.n = n; d.h = h / in.sdiv; d.w = w / in.sdiv;
     d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
+    if (net->dtype == 4 && y3_conv_wino_eligible_impl(&d)) return 0;   // one Winograd kernel, no fix-up
     return y3_conv_schedule_impl(&d);
 }
 
 extern "C" int y3_net_set_profiling(y3_net* net, int enabled) {
     Y3_CHECK_ARG(net, "y3_net_set_profiling: null net");
-    net->profiling = enabled != 0;
-    net->sets_used = 0;
+    net->profiling = enabled != 0;     // recorded sets are kept until y3_net_get_layer_ms reads (and clears) them
     return Y3_OK;
 }
 

@@ -49,6 +49,28 @@ def prepare_conv_params_split(w_var, bn_vars=None, bias_var=None, planes=3):
     return ws, scale, shift
 
 
+def wino_eligible(k, stride, cin, cout, c_up=0):
+    """True for the convs the Winograd kernel takes (the rule lives in the library: y3_conv_wino_eligible)."""
+    d = _lib.ConvDesc(1, 8, 8, cin, c_up, cout, k, stride, 1)
+    return _lib.lib().y3_conv_wino_eligible(ctypes.byref(d)) == 1
+
+
+def prepare_conv_params_wino(w_var, bn_vars=None, bias_var=None, stride=1):
+    """As prepare_conv_params, with the Winograd-transformed kernel for the eligible layers (the others keep the
+    direct kernel's packing)."""
+    w32, scale, shift = prepare_conv_params(w_var, bn_vars=bn_vars, bias_var=bias_var)
+    k, _, cin, cout = w_var.shape
+    if not wino_eligible(k, stride, cin, cout):
+        return w32, scale, shift
+    key = w_var.op_name + '#wino'
+    hit = _param_cache.get(key)
+    if hit is not None and hit[0] == w_var.version:
+        return hit[1], scale, shift
+    wu = pack_wino(w_var.tensor)
+    _param_cache[key] = (w_var.version, wu)
+    return wu, scale, shift
+
+
 def prepare_conv_params(w_var, bn_vars=None, bias_var=None):
     """Return (w_packed, scale, shift) device tensors for one conv layer.
 

@@ -18,8 +18,9 @@ from .utils.layer_utils import conv2d, darknet53_body, yolo_block, upsample_laye
 
 N_BODY_CONVS = 52  # utils/layer_utils.py:24-68
 # compute_dtype -> y3_net_set_dtype code.  'f32': exact fp32 MFMA; 'f32_bf16x6' / 'f32_bf16x3': fp32 tensors,
-# every product rebuilt from 6 / 3 bf16 plane products with fp32 accumulation; 'bf16': bf16 storage.
-NET_DTYPES = {'f32': 0, 'bf16': 1, 'f32_bf16x6': 2, 'f32_bf16x3': 3}
+# every product rebuilt from 6 / 3 bf16 plane products with fp32 accumulation; 'bf16': bf16 storage; 'f32_wino': exact
+# fp32 arithmetic with the Winograd F(2x2,3x3) kernel for the stride-1 3x3 convs (direct kernel elsewhere).
+NET_DTYPES = {'f32': 0, 'bf16': 1, 'f32_bf16x6': 2, 'f32_bf16x3': 3, 'f32_wino': 4}
 
 
 class yolov3(object):
@@ -96,7 +97,10 @@ class yolov3(object):
         if ent['version'] != fw.global_version():
             keep = []
             for i, (w, bnv, bias) in enumerate(ent['layers']):
-                if planes:
+                if self.compute_dtype == 'f32_wino':
+                    wp, sc, sh = engine.prepare_conv_params_wino(w, bn_vars=bnv, bias_var=bias,
+                                                                 stride=ent['table'][i][1])
+                elif planes:
                     wp, sc, sh = engine.prepare_conv_params_split(w, bn_vars=bnv, bias_var=bias, planes=planes)
                 else:
                     prep = engine.prepare_conv_params_bf16 if bf16 else engine.prepare_conv_params
