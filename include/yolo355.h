@@ -102,11 +102,13 @@ int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const 
  * Same tensors and epilogue as y3_conv2d_fwd (utils/layer_utils.py:9-22,25-32) for the convs
  * y3_conv_wino_eligible accepts (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cin >= 64,
  * Cout %% 32 == 0).  w_wino = G g G^T per (cin, cout), packed [16][cin/8][cout][8] fp32 (16*cin*cout floats) by
- * y3_pack_conv_weights_wino.  Results differ from the direct kernel by a few fp32 roundings per term. */
+ * y3_pack_conv_weights_wino.  Results differ from the direct kernel by a few fp32 roundings per term.  With a
+ * workspace the kernel may pick a stream-K schedule (persistent grid + deterministic fix-up), as y3_conv2d_fwd does. */
 int y3_conv_wino_eligible(const y3_conv_desc* d);
 int y3_pack_conv_weights_wino(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino);
+size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d);   /* stream-K scratch; workspace = NULL is allowed */
 int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino, const float* scale,
-                       const float* shift, const float* residual, float* y);
+                       const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
 
 /* ---- fp32 on the bf16 matrix pipe ----------------------------------------------------------------------------
  * Same contract and tensors as y3_conv2d_fwd (fp32 NHWC in, fp32 out, same epilogue, same workspace rule); every

@@ -207,6 +207,8 @@ WINO_CASES = [
     (2, 13, 13, 512, 1024, True, True),    # odd map (7x7 tiles, last tile half outside), deepest layer shape
     (1, 26, 26, 256, 512, True, False),
     (2, 52, 52, 128, 256, True, True),     # true-size 52x52 residual-stage conv
+    (7, 26, 26, 64, 1024, True, True),     # 19 x 16 = 304 blocks on 256 workers: stream-K schedule, every block split
+    (32, 13, 13, 64, 1024, True, False),   # BASELINE-size 13x13 map: 25 x 16 = 400 blocks, stream-K, ragged last tile block
     (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear
     (1, 2, 2, 96, 32, True, False),        # one tile per image; Cin not a power of two
 ]
@@ -231,6 +233,11 @@ def test_winograd_conv_matches_fp64(n, h, w, cin, cout, act, resid):
     check(got.cpu().numpy(), want, 'winograd %dx%dx%d %d->%d' % (n, h, w, cin, cout))
     direct = run_gpu(x, wt, scale, shift, 3, 1, act, r)
     assert np.abs(got.cpu().numpy() - direct).max() <= 2e-4 * (1 + np.abs(want).max())
+    # the one-workgroup-per-block schedule (no workspace) against the same reference, and run-to-run determinism
+    plain = engine.conv2d_fwd_wino(t(x), wu, t(scale), t(shift), cout, act, residual=t(r), use_workspace=False)
+    check(plain.cpu().numpy(), want, 'winograd (no workspace) %dx%dx%d %d->%d' % (n, h, w, cin, cout))
+    again = engine.conv2d_fwd_wino(t(x), wu, t(scale), t(shift), cout, act, residual=t(r))
+    assert torch.equal(again, got)
 
 
 def test_winograd_eligibility_and_errors():

@@ -30,8 +30,9 @@ PROTOTYPES = {
                               c_void_p, c_void_p, c_void_p, c_size_t]),
     "y3_conv_wino_eligible": (c_int, [POINTER(ConvDesc)]),
     "y3_pack_conv_weights_wino": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "y3_conv_wino_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv2d_fwd_wino": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p]),
+                                   c_void_p, c_void_p, c_size_t]),
     "y3_pack_conv_weights_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_conv2d_fwd_split": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -72,10 +72,13 @@ extern "C" int y3_pack_conv_weights_wino(y3_ctx* ctx, const float* w_hwio, int c
     return y3_launch_pack_wino(ctx->stream, w_hwio, cin, cout, w_wino);
 }
 
+extern "C" size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d) { return y3_conv_wino_workspace_bytes_impl(d); }
+
 extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino,
-                                  const float* scale, const float* shift, const float* residual, float* y) {
+                                  const float* scale, const float* shift, const float* residual, float* y,
+                                  void* workspace, size_t workspace_bytes) {
     Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_wino: null context");
-    return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y);
+    return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y, workspace, workspace_bytes);
 }
 
 extern "C" int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int cin, int dz_stride,
@@ -281,6 +284,7 @@ struct y3_net {
             d.n = n; d.h = h / tensors[l.src].sdiv; d.w = w / tensors[l.src].sdiv;
             d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
             scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
+            if (dtype == 4) scratch_bytes = std::max(scratch_bytes, y3_conv_wino_workspace_bytes_impl(&d));
         }
         plan_bytes = arena_bytes + scratch_bytes;
         pn = n; ph = h; pw = w;
@@ -426,7 +430,8 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
-            ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst))
+            ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
+                                  base + net->arena_bytes, net->scratch_bytes, ev ? ev[nl + 1 + i] : nullptr)
             : (net->dtype == 2 || net->dtype == 3)
             ? y3_launch_conv_split(st, &d, net->dtype == 2 ? 3 : 2, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift,
                                    ptr(l.resid), ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,

@@ -21,6 +21,7 @@
 //     and 128-byte-per-half-wave stores.
 // Numerics: the transforms use only additions and the constants 1/2, so the result differs from the direct sum by a
 // few fp32 roundings per term (tests/test_conv_gpu.py holds it to the same 1e-4 tolerance against fp64).
+#include <cstdlib>
 #include "y3_internal.h"
 
 namespace {
@@ -34,7 +35,20 @@ struct WinoArgs {
     float* y;            // [N,H,W,Cout]
     int N, H, W, Cin, Cout, act;
     int TH, TW, T;       // 2x2 output tiles per image column / row, and in total
+    float* partial;      // stream-K scratch: [workers][2][BT*4][BNW] output-space partial sums (pre scale/shift)
+    int workers;         // stream-K grid size (0 = one workgroup per block)
 };
+
+// Balanced contiguous partition of `items` over `workers` (same as y3_conv_common.h)
+__device__ __host__ __forceinline__ long long wk_begin(long long items, int workers, int w) {
+    const long long q = items / workers, r = items % workers;
+    return (long long)w * q + (w < r ? w : r);
+}
+__device__ __host__ __forceinline__ int wk_owner(long long items, int workers, long long item) {
+    const long long q = items / workers, r = items % workers;
+    if (item < r * (q + 1)) return (int)(item / (q + 1));
+    return (int)(r + (item - r * (q + 1)) / q);
+}
 
 constexpr int WKC = 8;                   // input channels per K-step
 constexpr int WROW = 32;                 // LDS bytes per row (8 floats)
@@ -61,7 +75,71 @@ __device__ __forceinline__ void input_transform(const f32x4 (&d)[16], f32x4 (&v)
     }
 }
 
-template <int WGM, int WGN>
+// Shared tail of the kernel and the fix-up: float4 rows of the LDS staging tile cs[BT*4][LDC] -> scale/shift,
+// LeakyReLU, + residual -> global.  tile_pix / tile_ok describe the workgroup's tiles (see the kernel).
+template <int BT, int BNW>
+__device__ __forceinline__ void wino_store_rows(const WinoArgs& p, const float* cs, const int* tile_pix,
+                                                const int* tile_ok, int n0) {
+    constexpr int LDC = BNW + 4;
+    constexpr int C4 = BNW / 4;            // float4 columns per staged row
+    constexpr int RPP = 256 / C4;          // rows per pass
+    constexpr int PASSES = BT * 4 / RPP;
+    const int tid = threadIdx.x;
+    const int tc = (tid % C4) * 4, tr = tid / C4;
+    const int co = n0 + tc;
+    const bool cok = co < p.Cout;           // Cout % 4 == 0
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + co);
+    }
+    size_t off[PASSES];
+    bool ok[PASSES];
+    f32x4 res[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int rr = tr + i * RPP;                       // staged row = tile*4 + dy*2 + dx
+        const int tl = rr >> 2, q = rr & 3;
+        const int pix = tile_pix[tl];
+        ok[i] = cok && ((tile_ok[tl] >> q) & 1) != 0;
+        off[i] = ((size_t)(pix + (q >> 1) * p.W + (q & 1))) * p.Cout + co;
+        res[i] = (ok[i] && p.resid) ? *reinterpret_cast<const f32x4*>(p.resid + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        if (!ok[i]) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + i * RPP) * LDC + tc);
+        v = v * sc + sh;
+        if (p.act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+        }
+        v += res[i];
+        *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
+    }
+}
+
+// pixel index of output (n, 2ty, 2tx) of tile t (-1: no such tile) and which of its 2x2 outputs exist
+__device__ __forceinline__ void wino_tile_info(const WinoArgs& p, int t, int& pix, int& okbits, int& n, int& ty,
+                                               int& tx) {
+    n = ty = tx = 0;
+    pix = -1;
+    okbits = 0;
+    if (t < p.T) {
+        n = t / (p.TH * p.TW);
+        const int rem = t - n * p.TH * p.TW;
+        ty = rem / p.TW;
+        tx = rem - ty * p.TW;
+        pix = (n * p.H + 2 * ty) * p.W + 2 * tx;
+        okbits = 1 | ((2 * tx + 1 < p.W) ? 2 : 0) | ((2 * ty + 1 < p.H) ? 4 : 0) |
+                 ((2 * tx + 1 < p.W && 2 * ty + 1 < p.H) ? 8 : 0);
+    }
+}
+
+// STREAMK: a persistent grid of p.workers workgroups (one per CU), each owning an equal contiguous range of
+// (block, K-step) work items; a block computed by several workers is summed in output space by
+// conv_wino_fixup_kernel (fixed worker order: deterministic).
+template <int WGM, int WGN, bool STREAMK>
 __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int BT = WGM * 32, BNW = WGN * 32;
@@ -80,13 +158,27 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int nbt = (p.T + BT - 1) / BT;
-    // XCD-contiguous, column-major block id: the workgroups of one XCD share a weight panel
-    const int nt = gridDim.x;
-    const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
-    const int blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
-    const int bn = blk / nbt, bt = blk - bn * nbt;
-    const int t0 = bt * BT, n0 = bn * BNW;
     const int ksteps = p.Cin / WKC;
+    // work range: items = (block, K-step), blocks column-major (bn outer) so that the workgroups of one XCD share a
+    // weight panel; workgroup b runs on XCD b%8 and gets a contiguous eighth of the id space
+    long long item, item_end;
+    int worker = 0;
+    {
+        const int nt = gridDim.x;
+        const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+        if (STREAMK) {
+            const long long items = (long long)nbt * ((p.Cout + BNW - 1) / BNW) * ksteps;
+            worker = id;
+            item = wk_begin(items, p.workers, worker);
+            item_end = wk_begin(items, p.workers, worker + 1);
+        } else {
+            item = (long long)id * ksteps;
+            item_end = item + ksteps;
+        }
+    }
+    if (item >= item_end) return;
+    const int first_blk = (int)(item / ksteps);
 
     // ---- staging roles (wave-uniform) ----------------------------------------------------------------------
     // waves 0-1 (threads [0, 128)): activation patch of tile (tid>>1), channel quad (tid&1) of the K-step
@@ -99,41 +191,48 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         (unsigned)(is_a ? (size_t)p.N * p.H * p.W * p.Cin * 4 : (size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
     unsigned voff[16];            // A: byte offsets of the 16 patch pixels (OOB where padded); U: piece offsets
     const int a_tile = tid >> 1, a_quad = tid & 1;
-    if (is_a) {
-        const int t = t0 + a_tile;
-        int n = 0, ty = 0, tx = 0;
-        const bool tok = t < p.T;
-        if (tok) {
-            n = t / (p.TH * p.TW);
-            const int rem = t - n * p.TH * p.TW;
-            ty = rem / p.TW;
-            tx = rem - ty * p.TW;
+    int t0 = 0, n0 = 0;
+    // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers.  (Fetching the next
+    // block's first K-step ahead of the epilogue was measured: the 64 extra live registers spill there, -13 %.)
+    auto setup_tables = [&](int blk) {
+        const int bn = blk / nbt, bt = blk - bn * nbt;
+        t0 = bt * BT;
+        n0 = bn * BNW;
+        if (is_a && a_quad == 0) {
+            int pix, okbits, n, ty, tx;
+            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
+            tile_pix[a_tile] = pix;
+            tile_ok[a_tile] = okbits;
         }
-        if (a_quad == 0) {
-            tile_pix[a_tile] = tok ? (n * p.H + 2 * ty) * p.W + 2 * tx : -1;
-            tile_ok[a_tile] = !tok ? 0 : 1 | ((2 * tx + 1 < p.W) ? 2 : 0) | ((2 * ty + 1 < p.H) ? 4 : 0) |
-                                             ((2 * tx + 1 < p.W && 2 * ty + 1 < p.H) ? 8 : 0);
-        }
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    };
+    auto setup_voff = [&](int blk) {
+        const int bn = blk / nbt, bt = blk - bn * nbt;
+        const int t0 = bt * BT, n0 = bn * BNW;
+        if (is_a) {
+            int pix, okbits, n, ty, tx;
+            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
+            const bool tok = pix >= 0;
+            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int yy = y0 + i, xx = x0 + j;
-                const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                voff[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_quad * 4) * 4u : OOB;
+                for (int j = 0; j < 4; ++j) {
+                    const int yy = y0 + i, xx = x0 + j;
+                    const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    voff[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_quad * 4) * 4u : OOB;
+                }
+        } else {
+            // piece q = (tid-128) + 128*j, j < 16 (only 32*BNW/128 of them exist): position = q / (2*BNW),
+            // channel = (q / 2) % BNW, half = q & 1.  Packed weights: [pos][Cin/8][Cout][8] floats.
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int q = (tid - 128) + 128 * j;
+                const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+                const bool ok = q < 32 * BNW && (n0 + co) < p.Cout;
+                voff[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
             }
-    } else {
-        // piece q = (tid-128) + 128*j, j < 16 (only 32*BNW/128 of them exist): position = q / (2*BNW),
-        // channel = (q / 2) % BNW, half = q & 1.  Packed weights: [pos][Cin/8][Cout][8] floats.
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int q = (tid - 128) + 128 * j;
-            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
-            const bool ok = q < 32 * BNW && (n0 + co) < p.Cout;
-            voff[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
         }
-    }
+    };
 
     f32x4 reg[16];
     auto issue = [&](int ks) {
@@ -190,90 +289,118 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         }
     };
 
-    issue(0);
-    store(0);
-    __syncthreads();
-    for (int ks = 0; ks + 1 < ksteps; ++ks) {
-        // Pin the order loads(ks+1) | MFMAs(ks) | transform + LDS writes(ks+1): left alone, hipcc either sinks the
-        // loads below the MFMAs or hoists the writes (and the wait for the loads) above them to shorten the 64 live
-        // load registers — both expose the full load latency every K-step.  (Measured: scheduling the transform into
-        // the MFMA gaps needs the MFMAs and the staging code in one basic block, which spills 300-900 VGPRs.)
-        issue(ks + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(ks & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        store((ks + 1) & 1);
-        __syncthreads();
-    }
-    compute((ksteps - 1) & 1);
-
-    // ---- epilogue ---------------------------------------------------------------------------------------------
-    // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
-    // (2) all threads: float4 rows of the staging tile -> scale/shift, LeakyReLU, + residual -> global, 16 B per lane
+    // ---- segments: maximal runs of K-steps of one block inside this workgroup's item range ------------------------
     constexpr int LDC = BNW + 4;
     static_assert((size_t)BT * 4 * LDC * 4 <= (size_t)2 * (STAGE_V + STAGE_U), "output staging must fit in the tile LDS");
     float* cs = reinterpret_cast<float*>(smem);
-    __syncthreads();                 // every wave is done reading the last K-step's tiles
-    {
-        const int col = wn * 32 + (lane & 31);
+    while (item < item_end) {
+        const int blk = (int)(item / ksteps);
+        const int ks0 = (int)(item - (long long)blk * ksteps);
+        const long long blk_end = (long long)(blk + 1) * ksteps;
+        const long long seg_end = blk_end < item_end ? blk_end : item_end;
+        const int ks1 = ks0 + (int)(seg_end - item);          // K-steps [ks0, ks1) of this block
+        setup_tables(blk);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // D layout of the 32x32 MFMA: row (= tile) = (r&3) + 8*(r>>2) + 4*(lane>>5), column (= channel) = lane&31
-            const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float m[16];
+        for (int pos = 0; pos < 16; ++pos)
 #pragma unroll
-            for (int pos = 0; pos < 16; ++pos) m[pos] = acc[pos][r];
-            float s0[4], s1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
-                s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
-            }
-            float* row = cs + (tl * 4) * LDC + col;
-            row[0 * LDC] = s0[0] + s0[1] + s0[2];       // (dy,dx) = (0,0)
-            row[1 * LDC] = s0[1] - s0[2] - s0[3];       // (0,1)
-            row[2 * LDC] = s1[0] + s1[1] + s1[2];       // (1,0)
-            row[3 * LDC] = s1[1] - s1[2] - s1[3];       // (1,1)
+            for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+
+        setup_voff(blk);
+        issue(ks0);
+        store(0);
+        __syncthreads();
+        for (int ks = ks0; ks + 1 < ks1; ++ks) {
+            // Pin the order loads(ks+1) | MFMAs(ks) | transform + LDS writes(ks+1): left alone, hipcc either sinks
+            // the loads below the MFMAs or hoists the writes (and the wait for the loads) above them to shorten the
+            // 64 live load registers — both expose the full load latency every K-step.  (Measured: weaving the
+            // transform into the MFMA gaps by hand was 9 % slower: the loads have not landed after 48 MFMAs.)
+            issue(ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute((ks - ks0) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store((ks - ks0 + 1) & 1);
+            __syncthreads();
         }
+        compute((ks1 - 1 - ks0) & 1);
+
+        // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
+        __syncthreads();                 // every wave is done reading the last K-step's tiles
+        {
+            const int col = wn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // D layout of the 32x32 MFMA: row (= tile) = (r&3) + 8*(r>>2) + 4*(lane>>5), column = lane&31
+                const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float m[16];
+#pragma unroll
+                for (int pos = 0; pos < 16; ++pos) m[pos] = acc[pos][r];
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                    s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+                }
+                float* row = cs + (tl * 4) * LDC + col;
+                row[0 * LDC] = s0[0] + s0[1] + s0[2];       // (dy,dx) = (0,0)
+                row[1 * LDC] = s0[1] - s0[2] - s0[3];       // (0,1)
+                row[2 * LDC] = s1[0] + s1[1] + s1[2];       // (1,0)
+                row[3 * LDC] = s1[1] - s1[2] - s1[3];       // (1,1)
+            }
+        }
+        __syncthreads();
+        if (!STREAMK || (ks0 == 0 && ks1 == ksteps)) {
+            // (2) all threads: float4 rows of the staging tile -> scale/shift, LeakyReLU, + residual -> global
+            wino_store_rows<BT, BNW>(p, cs, tile_pix, tile_ok, n0);
+        } else {
+            // partial block: the output-space sums go to this worker's slot (0 = its first block, 1 = its last)
+            float* slot = p.partial + ((size_t)worker * 2 + (blk == first_blk ? 0 : 1)) * (BT * 4 * BNW);
+            constexpr int C4 = BNW / 4;
+            for (int f = tid; f < BT * 4 * C4; f += 256) {
+                const int rr = f / C4, c4 = f - rr * C4;
+                reinterpret_cast<f32x4*>(slot)[f] = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4);
+            }
+        }
+        if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
+        item = seg_end;
+    }
+}
+
+// Stream-K fix-up: one workgroup per block; blocks computed whole by one worker exit at once, split blocks sum their
+// partial slots in worker (= K) order and run the common tail.
+template <int WGM, int WGN>
+__global__ void __launch_bounds__(256) conv_wino_fixup_kernel(const WinoArgs p) {
+    constexpr int BT = WGM * 32, BNW = WGN * 32, LDC = BNW + 4, C4 = BNW / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* cs = reinterpret_cast<float*>(smem);                         // [BT*4][LDC]
+    int* tile_pix = reinterpret_cast<int*>(smem + (size_t)BT * 4 * LDC * 4);
+    int* tile_ok = tile_pix + BT;
+    const int nbt = (p.T + BT - 1) / BT;
+    const int ksteps = p.Cin / WKC;
+    const long long items = (long long)nbt * ((p.Cout + BNW - 1) / BNW) * ksteps;
+    const int blk = blockIdx.x;
+    const long long i0 = (long long)blk * ksteps, i1 = i0 + ksteps;
+    const int w_lo = wk_owner(items, p.workers, i0), w_hi = wk_owner(items, p.workers, i1 - 1);
+    if (w_lo == w_hi) return;
+    const int tid = threadIdx.x;
+    const int bn = blk / nbt, bt = blk - bn * nbt;
+    if (tid < BT) {
+        int pix, okbits, n, ty, tx;
+        wino_tile_info(p, bt * BT + tid, pix, okbits, n, ty, tx);
+        tile_pix[tid] = pix;
+        tile_ok[tid] = okbits;
+    }
+    for (int f = tid; f < BT * 4 * C4; f += 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int w = w_lo; w <= w_hi; ++w) {
+            const int first = (int)(wk_begin(items, p.workers, w) / ksteps);
+            const float* slot = p.partial + ((size_t)w * 2 + (blk == first ? 0 : 1)) * (BT * 4 * BNW);
+            v += reinterpret_cast<const f32x4*>(slot)[f];
+        }
+        const int rr = f / C4, c4 = f - rr * C4;
+        *reinterpret_cast<f32x4*>(cs + rr * LDC + c4 * 4) = v;
     }
     __syncthreads();
-    {
-        constexpr int C4 = BNW / 4;            // float4 columns per staged row
-        constexpr int RPP = 256 / C4;          // rows per pass
-        constexpr int PASSES = BT * 4 / RPP;
-        const int tc = (tid % C4) * 4, tr = tid / C4;
-        const int co = n0 + tc;
-        const bool cok = co < p.Cout;           // Cout % 4 == 0
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (cok) {
-            sc = *reinterpret_cast<const f32x4*>(p.scale + co);
-            sh = *reinterpret_cast<const f32x4*>(p.shift + co);
-        }
-        size_t off[PASSES];
-        bool ok[PASSES];
-        f32x4 res[PASSES];
-#pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            const int rr = tr + i * RPP;                       // staged row = tile*4 + dy*2 + dx
-            const int tl = rr >> 2, q = rr & 3;
-            const int pix = tile_pix[tl];
-            ok[i] = cok && ((tile_ok[tl] >> q) & 1) != 0;
-            off[i] = ((size_t)(pix + (q >> 1) * p.W + (q & 1))) * p.Cout + co;
-            res[i] = (ok[i] && p.resid) ? *reinterpret_cast<const f32x4*>(p.resid + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            if (!ok[i]) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + i * RPP) * LDC + tc);
-            v = v * sc + sh;
-            if (p.act) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
-            }
-            v += res[i];
-            *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
-        }
-    }
+    wino_store_rows<BT, BNW>(p, cs, tile_pix, tile_ok, bn * BNW);
 }
 
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
@@ -320,8 +447,16 @@ int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int co
     return Y3_OK;
 }
 
+constexpr int WK_WORKERS = 256;     // one persistent workgroup per CU (128 KB of LDS, 256 AGPRs + ~150 VGPRs per wave)
+
+size_t y3_conv_wino_workspace_bytes_impl(const y3_conv_desc* d) {
+    if (!y3_conv_wino_eligible_impl(d)) return 0;
+    return (size_t)WK_WORKERS * 2 * (64 * 4 * 64) * sizeof(float);
+}
+
 int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
-                        const float* shift, const float* residual, float* y) {
+                        const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes,
+                        hipEvent_t mid_event) {
     Y3_CHECK_ARG(d && x && u && scale && shift && y, "y3_conv2d_fwd_wino: null pointer argument");
     Y3_CHECK_ARG(y3_conv_wino_eligible_impl(d),
                  "y3_conv2d_fwd_wino: needs a 3x3 stride-1 conv with Cin %% 32 == 0, Cin >= 64, Cout %% 32 == 0 and no "
@@ -333,17 +468,46 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
     a.TH = (d->h + 1) / 2; a.TW = (d->w + 1) / 2; a.T = d->n * a.TH * a.TW;
+    a.partial = nullptr; a.workers = 0;
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
-    auto kern = conv_wino_f32_kernel<2, 2>;
+    constexpr size_t lds_fix = (size_t)BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
+    auto kern = conv_wino_f32_kernel<2, 2, false>;
+    auto kern_sk = conv_wino_f32_kernel<2, 2, true>;
+    auto fix = conv_wino_fixup_kernel<2, 2>;
     static bool attr_set = false;   // benign race (idempotent)
     if (!attr_set) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fix),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix));
         attr_set = true;
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = (a.Cout + BNW - 1) / BNW;
-    hipLaunchKernelGGL(kern, dim3(nbt * nbn), dim3(256), lds, stream, a);
+    const int blocks = nbt * nbn;
+    // stream-K when the block count is a small non-integer multiple of the 256 resident workgroups (the last round
+    // would run partly empty); Y3_CONV_WINO_STREAMK=0/1 overrides (experiment hook)
+    static int force = -2;
+    if (force == -2) {
+        const char* e = getenv("Y3_CONV_WINO_STREAMK");
+        force = e ? atoi(e) : -1;
+    }
+    const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino_workspace_bytes_impl(d) &&
+                        ((uintptr_t)workspace & 15) == 0;
+    bool sk = has_ws && blocks > WK_WORKERS && blocks < 8 * WK_WORKERS && blocks % WK_WORKERS != 0;
+    if (force >= 0) sk = has_ws && force != 0 && blocks >= WK_WORKERS;
+    if (sk) {
+        a.partial = static_cast<float*>(workspace);
+        a.workers = WK_WORKERS;
+        hipLaunchKernelGGL(kern_sk, dim3(WK_WORKERS), dim3(256), lds, stream, a);
+        Y3_CHECK_HIP(hipGetLastError());
+        if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));
+        hipLaunchKernelGGL(fix, dim3(blocks), dim3(256), lds_fix, stream, a);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
+    }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
