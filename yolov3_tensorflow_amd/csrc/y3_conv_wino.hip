@@ -310,13 +310,28 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         store(0);
         __syncthreads();
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
-            // Pin the order loads(ks+1) | MFMAs(ks) | transform + LDS writes(ks+1): left alone, hipcc either sinks
-            // the loads below the MFMAs or hoists the writes (and the wait for the loads) above them to shorten the
-            // 64 live load registers — both expose the full load latency every K-step.  (Measured: weaving the
-            // transform into the MFMA gaps by hand was 9 % slower: the loads have not landed after 48 MFMAs.)
+            // Order: loads(ks+1) woven into the first MFMAs of K-step ks | remaining MFMAs | transform + LDS writes
+            // (ks+1).  Left alone, hipcc either sinks the loads below the MFMAs or hoists the writes (and the wait
+            // for the loads) above them to shorten the 64 live load registers — both expose the full load latency
+            // every K-step.  s_memtime per K-step: MFMAs 4160 cycles, load issue ~500 (in the gaps), transform +
+            // LDS writes 800-1050 (the LDS write path moves ~80 B/clk: 64 KB per K-step), barrier skew 50-400.
+            // Weaving the transform / writes into the MFMA gaps too was tried twice: it needs MFMAs and staging in
+            // one basic block, and the extra live registers spill (84-900 VGPRs) - slower both times.
             issue(ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
             compute((ks - ks0) & 1);
+            // the 16 loads issue in the gaps of the first position group's 16 MFMAs (a VMEM issue costs the wave
+            // 20-70 cycles; a 32x32x2 fp32 MFMA holds the matrix pipe for 64); the other groups stay as written
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int g = 1; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             store((ks - ks0 + 1) & 1);
             __syncthreads();
