@@ -100,11 +100,11 @@ def conv_flops(table, n, h, w):
     return np.array(flops)
 
 
-def traffic_from_profile():
+def traffic_from_profile(name='r01_pmc_traffic.json'):
     """HBM-side bytes per launch of the dominant kernel: rocprofv3 cannot run inside this process, so the
-    number comes from the committed PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
+    number comes from the committed PMC passes (profiles/r01_pmc_traffic*.json: FETCH_SIZE x2 + WRITE_SIZE,
     collected over this same command); None if the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         with open(path) as f:
             return int(json.load(f)['traffic_bytes_per_launch'])
@@ -336,7 +336,8 @@ def main():
                        "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": None if (bf16 or split or wino) else traffic_from_profile(),
+                         "traffic": (None if (bf16 or split) else
+                                     traffic_from_profile('r01_pmc_traffic_wino.json' if wino else 'r01_pmc_traffic.json')),
                          "kernel": ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; "
                                     "staging-bound, see DESIGN.md)" if bf16 else
                                     "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM "

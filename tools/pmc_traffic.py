@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-launch fabric-side traffic of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> \
+        <algorithmic bytes per launch> <out.json> [min KB to count a dispatch as full-size]
+
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes of 16-B/lane coalesced reads
+(MI355X_MICROARCH.md, HBM section), hence the x2.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] == counter:
+                name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('y3conv::', '')
+                acc[name.split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
+    return acc
+
+
+def main():
+    fetch_csv, write_csv, needle, algo, out = sys.argv[1:6]
+    floor = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
+    fetch, write = per_kernel(fetch_csv, 'FETCH_SIZE'), per_kernel(write_csv, 'WRITE_SIZE')
+    name = [k for k in fetch if needle in k]
+    assert len(name) == 1, name
+    name = name[0]
+    fv = [v for v in fetch[name] if v >= floor]
+    wv = [v for v in write[name] if v >= floor / 4]
+    f_kb, w_kb = sum(fv) / len(fv), sum(wv) / len(wv)
+    res = {
+        "kernel": name,
+        "fetch_size_kb_raw": round(f_kb, 1),
+        "write_size_kb": round(w_kb, 1),
+        "fetch_correction": "x2 (MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports half the bytes of "
+                            "16-B/lane coalesced reads)",
+        "traffic_bytes_per_launch": int((2 * f_kb + w_kb) * 1024),
+        "algorithmic_bytes_per_launch": int(float(algo)),
+        "dispatches_counted": len(fv),
+        "note": "fabric-side (L2 miss) traffic; Infinity-Cache hits are included, so this is an upper bound on HBM "
+                "bytes.  Collected in separate --pmc passes (FETCH_SIZE, then WRITE_SIZE) over `bench.py --steps 3 "
+                "--warmup 1 --no-cpu-baseline`, mean over the full-size dispatches.",
+        "all_kernels": {c: {k: {"dispatches": len(v), "mean_kb": round(sum(v) / len(v), 1)} for k, v in d.items()}
+                        for c, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write))},
+    }
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: res[k] for k in ("kernel", "traffic_bytes_per_launch", "algorithmic_bytes_per_launch",
+                                          "dispatches_counted")}))
+
+
+if __name__ == '__main__':
+    main()
