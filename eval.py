@@ -44,7 +44,8 @@ def build_parser():
                         help="Whether to use the voc 2007 mAP metrics.")
     # additions
     parser.add_argument("--batch_size", type=int, default=32, help="Images per device batch (the reference uses 1).")
-    parser.add_argument("--compute_dtype", type=str, default="f32", help="f32 | f32_bf16x6 (see DESIGN.md 4.3)")
+    parser.add_argument("--compute_dtype", type=str, default="f32_wino",
+                        help="f32_wino (default: exact fp32, Winograd 3x3 kernels) | f32 | f32_bf16x6 (DESIGN.md 4.3-4.4)")
     return parser
 
 

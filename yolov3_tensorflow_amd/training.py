@@ -161,10 +161,22 @@ def forward_train(model, x):
         cout = l['cout']
         ones, zeros = _consts(st, cout, dev)
         planes = _planes(model) if l['cin'] != 3 else 0
-        wp = _packed_weights(st, wvar, planes)
+        wino = (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and
+                engine.wino_eligible(l['k'], l['stride'], int(xin.shape[3]), cout))
         rec = dict(xin=xin)
+        if wino:        # Winograd forward for the stride-1 3x3 convs (the backward kernels are unchanged)
+            key = wvar.op_name + '#wino'
+            hit = st['packed'].get(key)
+            if hit is None or hit[0] != wvar.version:
+                hit = (wvar.version, engine.pack_wino(wvar.tensor))
+                st['packed'][key] = hit
+            z = engine.conv2d_fwd_wino(xin, hit[1], ones, zeros, cout, False)
+            wp = None
+        else:
+            wp = _packed_weights(st, wvar, planes)
         if l['bn']:
-            z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False, planes=planes)
+            if not wino:
+                z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False, planes=planes)
             rows = z.numel() // cout
             stats = torch.empty((4, cout), dtype=torch.float32, device=dev)   # mean, inv_std, scale, shift
             sc = _scratch(st, 'reduce', L.y3_reduce_scratch_bytes(cout), dev)
