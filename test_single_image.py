@@ -29,6 +29,8 @@ def parse_args(argv):
     ap.add_argument("--restore_path", type=str, default="./data/darknet_weights/yolov3.weights",
                     help="darknet .weights or native .npz checkpoint; random weights if the file does not exist")
     ap.add_argument("--output", type=str, default=None, help="write the annotated image here")
+    ap.add_argument("--compute_dtype", type=str, default="f32_wino",
+                    help="f32_wino (exact fp32, Winograd 3x3 kernels) | f32 | f32_bf16x6")
     return ap.parse_args(argv)
 
 
@@ -79,6 +81,7 @@ def main(argv=None):
 
     classes = read_class_names(args.class_name_path)
     model = y3.yolov3(len(classes), parse_anchors(args.anchor_path))
+    model.compute_dtype = args.compute_dtype
     picture = np.asarray(Image.open(args.input_image).convert('RGB'))       # RGB; cv2.imread would give BGR
     net_in, back = to_network_frame(picture, args.new_size, args.letterbox_resize)
     with y3.variable_scope('yolov3'):
