@@ -183,7 +183,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     // ---- staging roles (wave-uniform) ----------------------------------------------------------------------
     // waves 0-1 (threads [0, 128)): activation patch of tile (tid>>1), channel quad (tid&1) of the K-step
     // waves 2-3 (threads [128, 256)): weight pieces: 16 positions x BNW channels x 2 halves = 32*BNW pieces, 16 each
-    static_assert(2 * BT == 128, "waves 0-1 stage one (tile, channel quad) per thread");
+    static_assert(2 * BT == 128 && 32 * BNW == 128 * 16,
+                  "waves 0-1 stage one (tile, channel quad) per thread, waves 2-3 sixteen weight pieces");
     const bool is_a = __builtin_amdgcn_readfirstlane(wave) < 2;
     // one buffer descriptor per wave: the activation tensor for waves 0-1, the packed weights for waves 2-3
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -252,12 +253,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         } else {
             unsigned char* us = Us + buf * STAGE_U;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 16; ++j) {      // 32*BNW = 2048 pieces = 128 threads x 16: every piece exists
                 const int q = (tid - 128) + 128 * j;
-                if (q < 32 * BNW) {
-                    const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
-                    *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = reg[j];
-                }
+                const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+                *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = reg[j];
             }
         }
     };
