@@ -200,6 +200,7 @@ def main():
     import torch
     import torch.distributed as dist
     import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import engine
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -297,8 +298,8 @@ def main():
         flops = conv_flops(table, BATCH, SIZE, SIZE)
         is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
         sk_all = np.array(is_sk, bool)
-        if wino:   # dominant family: the Winograd kernel (every stride-1 3x3 conv with Cin >= 64)
-            is_sk = np.array([k == 3 and s == 1 and cin >= 64 and cin % 32 == 0 and cout % 32 == 0
+        if wino:   # dominant family: the Winograd kernel (every stride-1 3x3 conv but the stem)
+            is_sk = np.array([engine.wino_eligible(k, s, cin, cout)
                               for (k, s, cin, cout, bn) in table])
             main_ms = np.where(is_sk, layer_ms, main_ms)
         if bf16:   # dominant family: the 3x3 convs on 128x128 tiles (conv_mfma_bf16_kernel<128,128,2,2,3,false>)

@@ -211,6 +211,7 @@ WINO_CASES = [
     (32, 13, 13, 64, 1024, True, False),   # BASELINE-size 13x13 map: 25 x 16 = 400 blocks, stream-K, ragged last tile block
     (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear
     (1, 2, 2, 96, 32, True, False),        # one tile per image; Cin not a power of two
+    (2, 40, 36, 32, 64, True, True),       # the 208x208 stage's shape class: 4 K-steps per block
 ]
 
 
@@ -244,11 +245,11 @@ def test_winograd_eligibility_and_errors():
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
     L = _lib.lib()
     for args, ok in (((1, 8, 8, 64, 0, 64, 3, 1, 1), 1), ((1, 8, 8, 64, 0, 64, 3, 2, 1), 0),
-                     ((1, 8, 8, 64, 0, 64, 1, 1, 1), 0), ((1, 8, 8, 32, 0, 64, 3, 1, 1), 0),
+                     ((1, 8, 8, 64, 0, 64, 1, 1, 1), 0), ((1, 8, 8, 32, 0, 64, 3, 1, 1), 1), ((1, 8, 8, 48, 0, 64, 3, 1, 1), 0),
                      ((1, 8, 8, 64, 0, 255, 3, 1, 1), 0), ((1, 8, 8, 96, 32, 64, 3, 1, 1), 0)):
         assert L.y3_conv_wino_eligible(_lib.ConvDesc(*args)) == ok, args
     dev = fw.default_device()
-    x = torch.zeros((1, 8, 8, 32), device=dev)
+    x = torch.zeros((1, 8, 8, 48), device=dev)
     with pytest.raises(ValueError):
-        engine.conv2d_fwd_wino(x, torch.zeros(16 * 32 * 64, device=dev), torch.ones(64, device=dev),
+        engine.conv2d_fwd_wino(x, torch.zeros(16 * 48 * 64, device=dev), torch.ones(64, device=dev),
                                torch.zeros(64, device=dev), 64, True)

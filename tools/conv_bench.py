@@ -61,7 +61,7 @@ def main():
         sh = torch.zeros(cout, device=dev)
         r = torch.randn((n, h // s, h // s, cout), device=dev) if resid else None
         run = lambda: engine.conv2d_fwd(x, wp, sc, sh, k, s, cout, True, residual=r, x_up=xu, planes=a.planes)
-        if a.wino and k == 3 and s == 1 and cin >= 64:
+        if a.wino and engine.wino_eligible(k, s, cin, cout, c_up):
             wu = engine.pack_wino(w)
             run = lambda: engine.conv2d_fwd_wino(x, wu, sc, sh, cout, True, residual=r)
         for _ in range(3):

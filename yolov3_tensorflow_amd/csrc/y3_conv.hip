@@ -368,6 +368,10 @@ template <int KS, bool UPCAT, bool TMODE = false>
 int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
     if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT, TMODE>(stream, a);
     if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT, TMODE>(stream, a);
+    // 1x1 layers have 8-32 K-steps per tile: 64x64 tiles (37 KB of LDS, 72 VGPRs -> 4 workgroups per CU) hide one
+    // tile's prologue/epilogue under its neighbours' MFMAs and quantise the 172-1352-tile grids of the network 4x
+    // finer (measured, batch 32: 52x52 -10 %, 26x26 -19 %, 13x13 -21 % against the 128x128 tile)
+    if (KS == 1 && !TMODE) return launch_data_parallel<64, 64, 2, 2, KS, UPCAT, TMODE>(stream, a);
     return launch_data_parallel<128, 128, 2, 2, KS, UPCAT, TMODE>(stream, a);
 }
 
