@@ -216,8 +216,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     unsigned voff[16];            // A: byte offsets of the 16 patch pixels (OOB where padded); U: piece offsets
     const int a_tile = tid >> 1, a_quad = tid & 1;
     int t0 = 0, n0 = 0;
-    // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers.  (Fetching the next
-    // block's first K-step ahead of the epilogue was measured: the 64 extra live registers spill there, -13 %.)
+    // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers
     auto setup_tables = [&](int blk) {
         const int bn = blk / nbt, bt = blk - bn * nbt;
         t0 = bt * BT;
@@ -317,6 +316,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     constexpr int LDC = BNW + 4;
     static_assert((size_t)BT * 4 * LDC * 4 <= (size_t)2 * (STAGE_V + STAGE_U), "output staging must fit in the tile LDS");
     float* cs = reinterpret_cast<float*>(smem);
+    setup_voff(first_blk);
+    issue((int)(item - (long long)first_blk * ksteps));
     while (item < item_end) {
         const int blk = (int)(item / ksteps);
         const int ks0 = (int)(item - (long long)blk * ksteps);
@@ -329,9 +330,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
 
-        setup_voff(blk);
-        issue(ks0);
-        store(0);
+        store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
         __syncthreads();
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
             // Order: loads(ks+1) woven into the first MFMAs of K-step ks | remaining MFMAs | transform + LDS writes
@@ -393,6 +392,13 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             }
         }
         __syncthreads();
+        if (STREAMK && seg_end < item_end) {
+            // the next block's first K-step is fetched under this block's tail (its registers are free: the tail
+            // holds 81 and the accumulators are dead)
+            setup_voff(blk + 1);
+            issue(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (whole) {
             // (2) all threads: float4 rows of the staging tile -> scale/shift, LeakyReLU, + residual -> global
             rows.finish(p, cs, n0);
