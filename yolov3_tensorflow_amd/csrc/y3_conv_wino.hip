@@ -50,6 +50,8 @@ __device__ __host__ __forceinline__ int wk_owner(long long items, int workers, l
     return (int)(r + (item - r * (q + 1)) / q);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int WKC = 8;                   // input channels per K-step
 constexpr int WROW = 32;                 // LDS bytes per row (8 floats)
 constexpr unsigned OOB = 0x80000000u;
@@ -64,8 +66,9 @@ __device__ __forceinline__ int opaque(int v) {
 __device__ __forceinline__ int lds_off(int row, int half) { return row * WROW + ((half ^ ((row >> 3) & 1)) << 4); }
 
 // B^T d B on float4s (4 channels at once).  d[i][j], i = patch row, j = patch column; result v[i*4+j].
-__device__ __forceinline__ void input_transform(const f32x4 (&d)[16], f32x4 (&v)[16]) {
-    f32x4 t[16];
+template <typename V>
+__device__ __forceinline__ void input_transform(const V (&d)[16], V (&v)[16]) {
+    V t[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {          // rows: B^T d
         t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
@@ -203,25 +206,26 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     if (item >= item_end) return;
     const int first_blk = (int)(item / ksteps);
 
-    // ---- staging roles (wave-uniform) ----------------------------------------------------------------------
-    // waves 0-1 (threads [0, 128)): activation patch of tile (tid>>1), channel quad (tid&1) of the K-step
-    // waves 2-3 (threads [128, 256)): weight pieces: 16 positions x BNW channels x 2 halves = 32*BNW pieces, 16 each
-    static_assert(2 * BT == 128 && 32 * BNW == 128 * 16,
-                  "waves 0-1 stage one (tile, channel quad) per thread, waves 2-3 sixteen weight pieces");
-    const bool is_a = __builtin_amdgcn_readfirstlane(wave) < 2;
-    // one buffer descriptor per wave: the activation tensor for waves 0-1, the packed weights for waves 2-3
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(is_a ? p.x : p.u), 0,
-        (unsigned)(is_a ? (size_t)p.N * p.H * p.W * p.Cin * 4 : (size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
-    unsigned voff[16];            // A: byte offsets of the 16 patch pixels (OOB where padded); U: piece offsets
-    const int a_tile = tid >> 1, a_quad = tid & 1;
+    // ---- staging: every thread does a 1/256 share of both operands, so that the whole K-step (loads, MFMAs,
+    // input transform, LDS writes) is ONE basic block that the scheduling hints below can interleave ------------
+    //   activations: thread = (tile tid>>2, channel pair tid&3): the 4x4 patch as 16 bounds-checked 8-byte loads
+    //                (padding = OOB = 0), B^T d B on the float2s (32 packed adds), 16 8-byte LDS writes
+    //   weights:     16 positions x BNW channels x 2 halves = 32*BNW 16-byte pieces, 8 per thread
+    static_assert(4 * BT == 256 && 32 * BNW == 256 * 8, "one (tile, channel pair) and eight weight pieces per thread");
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.u), 0, (unsigned)((size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
+    unsigned voff_a[16];          // byte offsets of the 16 patch pixels (OOB where padded)
+    unsigned voff_u[8];           // byte offsets of the 8 weight pieces
+    const int a_tile = tid >> 2, a_pair = tid & 3;
     int t0 = 0, n0 = 0;
     // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers
     auto setup_tables = [&](int blk) {
         const int bn = blk / nbt, bt = blk - bn * nbt;
         t0 = bt * BT;
         n0 = bn * BNW;
-        if (is_a && a_quad == 0) {
+        if (a_pair == 0) {
             int pix, okbits, n, ty, tx;
             wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
             tile_pix[a_tile] = pix;
@@ -232,8 +236,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         const int bn = blk / nbt, bt = blk - bn * nbt;
         const int t0 = bt * BT, n0 = bn * BNW;
         const int tid = opaque(threadIdx.x);
-        if (is_a) {
-            const int a_tile = tid >> 1, a_quad = tid & 1;
+        {
+            const int a_tile = tid >> 2, a_pair = tid & 3;
             int pix, okbits, n, ty, tx;
             wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
             const bool tok = pix >= 0;
@@ -244,45 +248,46 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
                 for (int j = 0; j < 4; ++j) {
                     const int yy = y0 + i, xx = x0 + j;
                     const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    voff[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_quad * 4) * 4u : OOB;
+                    voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
                 }
-        } else {
-            // piece q = (tid-128) + 128*j, j < 16 (only 32*BNW/128 of them exist): position = q / (2*BNW),
-            // channel = (q / 2) % BNW, half = q & 1.  Packed weights: [pos][Cin/8][Cout][8] floats.
+        }
+        // piece q = tid + 256*j, j < 8: position = q / (2*BNW), channel = (q / 2) % BNW, half = q & 1.
+        // Packed weights: [pos][Cin/8][Cout][8] floats.
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int q = (tid - 128) + 128 * j;
-                const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
-                const bool ok = q < 32 * BNW && (n0 + co) < p.Cout;
-                voff[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int q = tid + 256 * j;
+            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+            const bool ok = (n0 + co) < p.Cout;
+            voff_u[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
         }
     };
 
-    f32x4 reg[16];
+    f32x2 ra[16];
+    f32x4 ru[8];
     auto issue = [&](int ks) {
-        // A: channels ks*8 + quad*4 .. +3 of the 16 patch pixels.  U: slab (pos, ks) = [Cout][8] floats.
-        const unsigned soff = is_a ? (unsigned)(ks * WKC) * 4u : (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
+        // A: channels ks*8 + pair*2, +1 of the 16 patch pixels.  U: slab (pos, ks) = [Cout][8] floats.
+        const unsigned soff_a = (unsigned)(ks * WKC) * 4u, soff_u = (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            reg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j], soff, 0));
+            ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            ru[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[j], soff_u, 0));
     };
+    const int st_a = lds_off(a_tile, a_pair >> 1) + (a_pair & 1) * 8;
     auto store = [&](int buf) {
-        if (is_a) {
-            f32x4 v[16];
-            input_transform(reg, v);
-            unsigned char* vs = Vs + buf * STAGE_V + lds_off(a_tile, a_quad);
+        unsigned char* us = Us + buf * STAGE_U;
 #pragma unroll
-            for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x4*>(vs + pos * PLANE_V) = v[pos];
-        } else {
-            unsigned char* us = Us + buf * STAGE_U;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {      // 32*BNW = 2048 pieces = 128 threads x 16: every piece exists
-                const int q = (tid - 128) + 128 * j;
-                const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
-                *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = reg[j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int q = tid + 256 * j;
+            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+            *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = ru[j];
         }
+        f32x2 v[16];
+        input_transform(ra, v);
+        unsigned char* vs = Vs + buf * STAGE_V + st_a;
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2*>(vs + pos * PLANE_V) = v[pos];
     };
 
     f32x16 acc[16];
@@ -333,30 +338,42 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
         __syncthreads();
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
-            // Order: loads(ks+1) woven into the first MFMAs of K-step ks | remaining MFMAs | transform + LDS writes
-            // (ks+1).  Left alone, hipcc either sinks the loads below the MFMAs or hoists the writes (and the wait
-            // for the loads) above them to shorten the 64 live load registers — both expose the full load latency
-            // every K-step.  s_memtime per K-step: MFMAs 4160 cycles, load issue ~500 (in the gaps), transform +
-            // LDS writes 800-1050 (the LDS write path moves ~80 B/clk: 64 KB per K-step), barrier skew 50-400.
-            // Weaving the transform / writes into the MFMA gaps too was tried twice: it needs MFMAs and staging in
-            // one basic block, and the extra live registers spill (84-900 VGPRs) - slower both times.
+            // One basic block per K-step: loads(ks+1) | 64 MFMAs of K-step ks | input transform + LDS writes (ks+1)
+            // into the other LDS stage, all interleaved by the hints below so that only the barrier is serial:
+            //   group 0: 16 x (MFMA, activation load)        group 1: 8 x (MFMA, weight load), 8 MFMAs
+            //   group 2: 8 MFMAs, 8 x (MFMA, weight write)   group 3: 16 x (MFMA, activation write)
+            // (a VMEM issue costs the wave 20-70 cycles, an LDS write ~16, a 32x32x2 fp32 MFMA holds the matrix pipe
+            // for 64; the transform's 32 packed adds float between the MFMAs of groups 2-3).  The loaded registers
+            // are first read ~2000 cycles after the last load issues.
             issue(ks + 1);
             compute((ks - ks0) & 1);
-            // the 16 loads issue in the gaps of the first position group's 16 MFMAs (a VMEM issue costs the wave
-            // 20-70 cycles; a 32x32x2 fp32 MFMA holds the matrix pipe for 64); the other groups stay as written
+            store((ks - ks0 + 1) & 1);
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-            for (int g = 1; g < 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            store((ks - ks0 + 1) & 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
             __syncthreads();
         }
         compute((ks1 - 1 - ks0) & 1);
