@@ -298,29 +298,33 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 
     const int frag_a = lds_off(wm * 32 + (lane & 31), lane >> 5);
     const int frag_b = lds_off(wn * 32 + (lane & 31), lane >> 5);
-    auto compute = [&](int buf) {
+    // fragments of position group g (four positions: 8 reads) and its MFMAs for k pairs [j0, j1) of the K-step
+    auto frags = [&](int buf, int g, f32x4 (&a)[4], f32x4 (&b)[4]) {
         const unsigned char* vs = Vs + buf * STAGE_V + frag_a;
         const unsigned char* us = Us + buf * STAGE_U + frag_b;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {            // four positions at a time: 8 fragment reads, 16 MFMAs
-            f32x4 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 4 + i) * PLANE_V);
-                b[i] = *reinterpret_cast<const f32x4*>(us + (g * 4 + i) * PLANE_U);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[g * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[i][j], acc[g * 4 + i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 4 + i) * PLANE_V);
+            b[i] = *reinterpret_cast<const f32x4*>(us + (g * 4 + i) * PLANE_U);
         }
     };
+    auto mfmas = [&](int g, const f32x4 (&a)[4], const f32x4 (&b)[4], int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[g * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[i][j], acc[g * 4 + i], 0, 0, 0);
+    };
+    f32x4 a0[4], b0[4];            // group 0 of the current K-step: read one half group ahead of the barrier
 
     // ---- segments: maximal runs of K-steps of one block inside this workgroup's item range ------------------------
     constexpr int LDC = BNW + 4;
     static_assert((size_t)BT * 4 * LDC * 4 <= (size_t)2 * (STAGE_V + STAGE_U), "output staging must fit in the tile LDS");
     float* cs = reinterpret_cast<float*>(smem);
+#ifdef Y3_WINO_CLOCK   // probe build (tools/wino_clock_probe.py): shader-clock cycles of workgroup 0 -> first bytes of y
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long clk_loop = 0, clk_steps = 0;
+#endif
     setup_voff(first_blk);
     issue((int)(item - (long long)first_blk * ksteps));
     while (item < item_end) {
@@ -337,6 +341,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 
         store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
         __syncthreads();
+        frags(0, 0, a0, b0);
+#ifdef Y3_WINO_CLOCK
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
+#endif
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
             // One basic block per K-step: loads(ks+1) | 64 MFMAs of K-step ks | input transform + LDS writes (ks+1)
             // into the other LDS stage, all interleaved by the hints below so that only the barrier is serial:
@@ -345,38 +353,75 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             // (a VMEM issue costs the wave 20-70 cycles, an LDS write ~16, a 32x32x2 fp32 MFMA holds the matrix pipe
             // for 64; the transform's 32 packed adds float between the MFMAs of groups 2-3).  The loaded registers
             // are first read ~2000 cycles after the last load issues.
+            const int cur = (ks - ks0) & 1;
+            f32x4 a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
             issue(ks + 1);
-            compute((ks - ks0) & 1);
-            store((ks - ks0 + 1) & 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            frags(cur, 1, a1, b1);
+            mfmas(0, a0, b0, 0, 4);
+            frags(cur, 2, a2, b2);
+            mfmas(1, a1, b1, 0, 4);
+            frags(cur, 3, a3, b3);
+            mfmas(2, a2, b2, 0, 4);
+            mfmas(3, a3, b3, 0, 2);
+            store(cur ^ 1);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {                            // group 0: activation loads ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i) {                            // ... and the fragments of group 1
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                            // group 1: weight loads ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i) {                            // ... and the fragments of group 2
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                            // group 2: weight writes ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8; ++i) {                            // ... and the fragments of group 3
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                            // group 3, first half: activation writes
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
             __syncthreads();
+            // the second half of group 3 covers the latency of the next K-step's first fragment reads
+            frags(cur ^ 1, 0, a0, b0);
+            mfmas(3, a3, b3, 2, 4);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
-        compute((ks1 - 1 - ks0) & 1);
+#ifdef Y3_WINO_CLOCK
+        clk_loop += __builtin_amdgcn_s_memtime() - clk1;
+        clk_steps += ks1 - 1 - ks0;
+#endif
+        {
+            const int cur = (ks1 - 1 - ks0) & 1;
+            f32x4 a1[4], b1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) frags(cur, g + 1, a1, b1);
+                mfmas(g, a0, b0, 0, 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; }
+            }
+        }
 
         // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
         __syncthreads();                 // every wave is done reading the last K-step's tiles
@@ -431,6 +476,14 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
         item = seg_end;
     }
+#ifdef Y3_WINO_CLOCK
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.y);
+        out[0] = __builtin_amdgcn_s_memtime() - clk0;
+        out[1] = clk_loop;
+        out[2] = clk_steps;
+    }
+#endif
 }
 
 // Stream-K fix-up: one workgroup per block; blocks computed whole by one worker exit at once, split blocks sum their
