@@ -51,6 +51,7 @@ __device__ __host__ __forceinline__ int wk_owner(long long items, int workers, l
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int WKC = 8;                   // input channels per K-step
 constexpr int WROW = 32;                 // LDS bytes per row (8 floats)
@@ -121,7 +122,10 @@ struct WinoRows {
         }
     }
 
-    __device__ __forceinline__ void finish(const WinoArgs& p, const float* cs, int n0) const {
+    // between(i) runs after the i-th row's store was issued: the tail is bound by store issue (~500 cycles per 1 KB
+    // wave store), so independent register work placed there is free (the kernel resets its accumulators)
+    template <typename F>
+    __device__ __forceinline__ void finish(const WinoArgs& p, const float* cs, int n0, F between) const {
         const int tid = threadIdx.x;
         const int tc = (tid % C4) * 4, tr = tid / C4;
         const int co = n0 + tc;
@@ -130,9 +134,11 @@ struct WinoRows {
             sc = *reinterpret_cast<const f32x4*>(p.scale + co);
             sh = *reinterpret_cast<const f32x4*>(p.shift + co);
         }
+        // branch-free stores: rows that do not exist go to an out-of-range offset, which the buffer store drops
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+            p.y, 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            if (!((ok >> i) & 1)) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + i * RPP) * LDC + tc);
             v = v * sc + sh;
             if (p.act) {
@@ -140,10 +146,22 @@ struct WinoRows {
                 for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
             }
             v += res[i];
-            *reinterpret_cast<f32x4*>(p.y + off[i]) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_y,
+                                                   ((ok >> i) & 1) ? off[i] * 4u : OOB, 0, 0);
+            between(i);
         }
     }
 };
+
+// t / d for 0 <= t < 2^24 and a quotient below 2^20: float reciprocal estimate (off by at most one) + correction; ~8 instructions
+// instead of the ~45 of the integer division expansion (the per-block set-up runs four of these per thread)
+__device__ __forceinline__ int fastdiv(int t, int d) {
+    int q = (int)((float)t * __frcp_rn((float)d));
+    const int r = t - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
 
 // pixel index of output (n, 2ty, 2tx) of tile t (-1: no such tile) and which of its 2x2 outputs exist
 __device__ __forceinline__ void wino_tile_info(const WinoArgs& p, int t, int& pix, int& okbits, int& n, int& ty,
@@ -152,9 +170,9 @@ __device__ __forceinline__ void wino_tile_info(const WinoArgs& p, int t, int& pi
     pix = -1;
     okbits = 0;
     if (t < p.T) {
-        n = t / (p.TH * p.TW);
+        n = fastdiv(t, p.TH * p.TW);
         const int rem = t - n * p.TH * p.TW;
-        ty = rem / p.TW;
+        ty = fastdiv(rem, p.TW);
         tx = rem - ty * p.TW;
         pix = (n * p.H + 2 * ty) * p.W + 2 * tx;
         okbits = 1 | ((2 * tx + 1 < p.W) ? 2 : 0) | ((2 * ty + 1 < p.H) ? 4 : 0) |
@@ -222,7 +240,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     int t0 = 0, n0 = 0;
     // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers
     auto setup_tables = [&](int blk) {
-        const int bn = blk / nbt, bt = blk - bn * nbt;
+        const int bn = fastdiv(blk, nbt), bt = blk - bn * nbt;
         t0 = bt * BT;
         n0 = bn * BNW;
         if (a_pair == 0) {
@@ -233,7 +251,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         }
     };
     auto setup_voff = [&](int blk) {
-        const int bn = blk / nbt, bt = blk - bn * nbt;
+        const int bn = fastdiv(blk, nbt), bt = blk - bn * nbt;
         const int t0 = bt * BT, n0 = bn * BNW;
         const int tid = opaque(threadIdx.x);
         {
@@ -284,7 +302,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = ru[j];
         }
         f32x2 v[16];
-        input_transform(ra, v);
+        input_transform(ra, v);       // 32 v_pk_add_f32 (two scalar transforms were measured: +14 % per K-step)
         unsigned char* vs = Vs + buf * STAGE_V + st_a;
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2*>(vs + pos * PLANE_V) = v[pos];
@@ -323,7 +341,17 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     float* cs = reinterpret_cast<float*>(smem);
 #ifdef Y3_WINO_CLOCK   // probe build (tools/wino_clock_probe.py): shader-clock cycles of workgroup 0 -> first bytes of y
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
-    unsigned long long clk_loop = 0, clk_steps = 0;
+    unsigned long long clk_loop = 0, clk_steps = 0, clk_last = clk0, clk_phase[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k) {     // cycles since the previous stamp -> phase k
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        clk_phase[k] += t - clk_last;
+        clk_last = t;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define Y3_STAMP(k) stamp(k)
+#else
+#define Y3_STAMP(k)
 #endif
     setup_voff(first_blk);
     issue((int)(item - (long long)first_blk * ksteps));
@@ -334,14 +362,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         const long long seg_end = blk_end < item_end ? blk_end : item_end;
         const int ks1 = ks0 + (int)(seg_end - item);          // K-steps [ks0, ks1) of this block
         setup_tables(blk);
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
-
         store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
         __syncthreads();
         frags(0, 0, a0, b0);
+        Y3_STAMP(0);    // block prologue: tile tables, accumulator reset, first transform + LDS writes, barrier
 #ifdef Y3_WINO_CLOCK
         const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -355,7 +379,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             // are first read ~2000 cycles after the last load issues.
             const int cur = (ks - ks0) & 1;
             f32x4 a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+#if !(defined(Y3_WINO_KO) && (Y3_WINO_KO & 1))
             issue(ks + 1);
+#endif
             frags(cur, 1, a1, b1);
             mfmas(0, a0, b0, 0, 4);
             frags(cur, 2, a2, b2);
@@ -363,7 +389,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             frags(cur, 3, a3, b3);
             mfmas(2, a2, b2, 0, 4);
             mfmas(3, a3, b3, 0, 2);
+#if !(defined(Y3_WINO_KO) && (Y3_WINO_KO & 2))
             store(cur ^ 1);
+#endif
 #pragma unroll
             for (int i = 0; i < 8; ++i) {                            // group 0: activation loads ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -411,6 +439,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         clk_loop += __builtin_amdgcn_s_memtime() - clk1;
         clk_steps += ks1 - 1 - ks0;
 #endif
+        Y3_STAMP(1);    // K-loop
         {
             const int cur = (ks1 - 1 - ks0) & 1;
             f32x4 a1[4], b1[4];
@@ -425,6 +454,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 
         // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
         __syncthreads();                 // every wave is done reading the last K-step's tiles
+        Y3_STAMP(2);    // last K-step's MFMAs + barrier
         const bool whole = !STREAMK || (ks0 == 0 && ks1 == ksteps);
         WinoRows<BT, BNW> rows;
         rows.prepare(p, tile_pix, tile_ok, n0);   // residual loads fly under the output transform (unconditional:
@@ -437,7 +467,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
                 const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float m[16];
 #pragma unroll
-                for (int pos = 0; pos < 16; ++pos) m[pos] = acc[pos][r];
+                for (int pos = 0; pos < 16; ++pos) {
+                    m[pos] = acc[pos][r];
+                    asm volatile("" : "+v"(m[pos]));      // one AGPR read per value (hipcc re-reads them otherwise)
+                }
                 float s0[4], s1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -454,6 +487,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             }
         }
         __syncthreads();
+        Y3_STAMP(3);    // residual loads issued, A^T M A, staging writes, barrier
         if (STREAMK && seg_end < item_end) {
             // the next block's first K-step is fetched under this block's tail (its registers are free: the tail
             // holds 81 and the accumulators are dead)
@@ -461,10 +495,19 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             issue(0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        Y3_STAMP(4);    // next block's offsets + loads issued
         if (whole) {
             // (2) all threads: float4 rows of the staging tile -> scale/shift, LeakyReLU, + residual -> global
-            rows.finish(p, cs, n0);
+            static_assert(WinoRows<BT, BNW>::PASSES == 16, "one accumulator set is reset per store pass");
+            rows.finish(p, cs, n0, [&](int i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            });
         } else {
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
             // partial block: the output-space sums go to this worker's slot (0 = its first block, 1 = its last)
             float* slot = p.partial + ((size_t)worker * 2 + (blk == first_blk ? 0 : 1)) * (BT * 4 * BNW);
             constexpr int C4 = BNW / 4;
@@ -474,6 +517,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             }
         }
         if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
+        Y3_STAMP(5);    // scale/shift/activation/residual/stores (or the partial-slot copy), barrier
         item = seg_end;
     }
 #ifdef Y3_WINO_CLOCK
@@ -482,6 +526,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         out[0] = __builtin_amdgcn_s_memtime() - clk0;
         out[1] = clk_loop;
         out[2] = clk_steps;
+        for (int k = 0; k < 6; ++k) out[3 + k] = clk_phase[k];
     }
 #endif
 }
@@ -503,7 +548,7 @@ __global__ void __launch_bounds__(256) conv_wino_fixup_kernel(const WinoArgs p) 
     const int w_lo = wk_owner(items, p.workers, i0), w_hi = wk_owner(items, p.workers, i1 - 1);
     if (w_lo == w_hi) return;
     const int tid = threadIdx.x;
-    const int bn = blk / nbt, bt = blk - bn * nbt;
+    const int bn = fastdiv(blk, nbt), bt = blk - bn * nbt;
     if (tid < BT) {
         int pix, okbits, n, ty, tx;
         wino_tile_info(p, bt * BT + tid, pix, okbits, n, ty, tx);
@@ -524,7 +569,7 @@ __global__ void __launch_bounds__(256) conv_wino_fixup_kernel(const WinoArgs p) 
         *reinterpret_cast<f32x4*>(cs + rr * LDC + c4 * 4) = v;
     }
     __syncthreads();
-    rows.finish(p, cs, bn * BNW);
+    rows.finish(p, cs, bn * BNW, [](int) {});
 }
 
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
