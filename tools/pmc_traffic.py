@@ -28,8 +28,8 @@ def main():
     floor = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
     fetch, write = per_kernel(fetch_csv, 'FETCH_SIZE'), per_kernel(write_csv, 'WRITE_SIZE')
     name = [k for k in fetch if needle in k]
-    assert len(name) == 1, name
-    name = name[0]
+    assert name, sorted(fetch)
+    name = max(name, key=lambda k: len(fetch[k]))      # several instantiations: the one with most dispatches
     fv = [v for v in fetch[name] if v >= floor]
     wv = [v for v in write[name] if v >= floor / 4]
     f_kb, w_kb = sum(fv) / len(fv), sum(wv) / len(wv)

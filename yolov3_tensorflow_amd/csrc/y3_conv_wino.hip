@@ -35,7 +35,8 @@ struct WinoArgs {
     float* y;            // [N,H,W,Cout]
     int N, H, W, Cin, Cout, act;
     int TH, TW, T;       // 2x2 output tiles per image column / row, and in total
-    float* partial;      // stream-K scratch: [workers][2][BT*4][BNW] output-space partial sums (pre scale/shift)
+    float* partial;      // stream-K scratch: [workers][BT*4][BNW] output-space partial sums (pre scale/shift)
+    unsigned* flags;     // stream-K scratch: [workers] "partial published" words, zeroed ahead of every launch
     int workers;         // stream-K grid size (0 = one workgroup per block)
 };
 
@@ -52,6 +53,26 @@ __device__ __host__ __forceinline__ int wk_owner(long long items, int workers, l
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// Stream-K work split.  The blocks are first divided, whole, among the 8 XCD groups (group x = workgroups with
+// blockIdx % 8 == x: they share an L2, and a group's blocks share weight panels); inside a group its G = workers/8
+// workers own equal contiguous ranges of (block, K-step) items.  A block cut by a range boundary is finished INSIDE
+// the kernel (no fix-up launch): the worker that owns the block's later K-steps meets them first in its range, writes
+// its output-space partial sums write-through and publishes a flag; the worker that owns the block's K-step 0 meets
+// the block last, adds the published partials in worker order (deterministic) and runs the normal tail.
+// Local worker j runs in workgroup blockIdx = x + 8*(G-1-j): every consumer j waits only for workers j+1.. of its own
+// group, which have SMALLER workgroup ids, i.e. were dispatched earlier - the wait cannot deadlock even when fewer
+// than `workers` workgroups are resident.
+__device__ __host__ __forceinline__ void wk_range(int blocks, int ksteps, int workers, int x, int j, long long& begin,
+                                                  long long& end) {
+    const int G = workers >> 3;
+    const long long b0 = wk_begin(blocks, 8, x), b1 = wk_begin(blocks, 8, x + 1);
+    const long long items = (b1 - b0) * ksteps;
+    begin = b0 * ksteps + wk_begin(items, G, j);
+    end = b0 * ksteps + wk_begin(items, G, j + 1);
+}
+
+typedef __attribute__((address_space(1))) unsigned gu32;   // flags are only ever touched by agent-scope global atomics
 
 constexpr int WKC = 8;                   // input channels per K-step
 constexpr int WROW = 32;                 // LDS bytes per row (8 floats)
@@ -124,8 +145,11 @@ struct WinoRows {
 
     // between(i) runs after the i-th row's store was issued: the tail is bound by store issue (~500 cycles per 1 KB
     // wave store), so independent register work placed there is free (the kernel resets its accumulators)
+    // n_extra consecutive published partial-sum slots ([BT*4][BNW] floats each) starting `extra_base` bytes into
+    // p.partial are added to the staged sums, in slot order, before scale/shift (the stream-K consumer; 0 elsewhere).
     template <typename F>
-    __device__ __forceinline__ void finish(const WinoArgs& p, const float* cs, int n0, F between) const {
+    __device__ __forceinline__ void finish(const WinoArgs& p, const float* cs, int n0, F between,
+                                           int n_extra = 0, unsigned extra_base = 0) const {
         const int tid = threadIdx.x;
         const int tc = (tid % C4) * 4, tr = tid / C4;
         const int co = n0 + tc;
@@ -134,12 +158,18 @@ struct WinoRows {
             sc = *reinterpret_cast<const f32x4*>(p.scale + co);
             sh = *reinterpret_cast<const f32x4*>(p.shift + co);
         }
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            p.partial, 0, n_extra ? (unsigned)((size_t)p.workers * BT * 4 * BNW * 4) : 0u, 0x00020000);
         // branch-free stores: rows that do not exist go to an out-of-range offset, which the buffer store drops
         const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
             p.y, 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + i * RPP) * LDC + tc);
+            for (int e = 0; e < n_extra; ++e)
+                v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                         rs_x, (unsigned)((tr + i * RPP) * BNW + tc) * 4u,
+                         extra_base + (unsigned)e * (unsigned)(BT * 4 * BNW * 4), 0));
             v = v * sc + sh;
             if (p.act) {
 #pragma unroll
@@ -206,16 +236,17 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     // work range: items = (block, K-step), blocks column-major (bn outer) so that the workgroups of one XCD share a
     // weight panel; workgroup b runs on XCD b%8 and gets a contiguous eighth of the id space
     long long item, item_end;
-    int worker = 0;
+    int worker = 0, grp = 0, lw = 0;     // stream-K: global worker index, XCD group, local worker in the group
+    const int nblocks = nbt * ((p.Cout + BNW - 1) / BNW);
     {
         const int nt = gridDim.x;
         const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
         const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
         if (STREAMK) {
-            const long long items = (long long)nbt * ((p.Cout + BNW - 1) / BNW) * ksteps;
-            worker = id;
-            item = wk_begin(items, p.workers, worker);
-            item_end = wk_begin(items, p.workers, worker + 1);
+            grp = xcd;
+            lw = (p.workers >> 3) - 1 - k8;
+            worker = grp * (p.workers >> 3) + lw;
+            wk_range(nblocks, ksteps, p.workers, grp, lw, item, item_end);
         } else {
             item = (long long)id * ksteps;
             item_end = item + ksteps;
@@ -455,7 +486,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
         __syncthreads();                 // every wave is done reading the last K-step's tiles
         Y3_STAMP(2);    // last K-step's MFMAs + barrier
-        const bool whole = !STREAMK || (ks0 == 0 && ks1 == ksteps);
+        const bool producer = STREAMK && ks0 > 0;       // later K-steps of a cut block: publish partial sums
         WinoRows<BT, BNW> rows;
         rows.prepare(p, tile_pix, tile_ok, n0);   // residual loads fly under the output transform (unconditional:
                                                   // a partial block wastes them, a branch here makes hipcc spill them)
@@ -488,6 +519,30 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         }
         __syncthreads();
         Y3_STAMP(3);    // residual loads issued, A^T M A, staging writes, barrier
+        int n_extra = 0;
+        if (STREAMK && ks1 < ksteps) {
+            // this worker owns K-steps [0, ks1) of a cut block: the rest was summed by the next workers of its
+            // group, at the START of their ranges.  One lane polls their flags, one acquire, then plain loads.
+            const int G = p.workers >> 3;
+            for (int jj = lw + 1; jj < G; ++jj) {
+                long long b, e;
+                wk_range(nblocks, ksteps, p.workers, grp, jj, b, e);
+                if (b >= blk_end) break;
+                ++n_extra;
+            }
+            if (tid == 0) {
+                for (int e = 0; e < n_extra; ++e) {
+                    gu32* flag = (gu32*)(p.flags + worker + 1 + e);
+                    // bounded: on expiry the result is wrong (the tests catch it) but the launch ends
+                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
         if (STREAMK && seg_end < item_end) {
             // the next block's first K-step is fetched under this block's tail (its registers are free: the tail
             // holds 81 and the accumulators are dead)
@@ -496,25 +551,34 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             __builtin_amdgcn_sched_barrier(0);
         }
         Y3_STAMP(4);    // next block's offsets + loads issued
-        if (whole) {
-            // (2) all threads: float4 rows of the staging tile -> scale/shift, LeakyReLU, + residual -> global
+        if (!producer) {
+            // (2) all threads: float4 rows of the staging tile (+ the partial sums other workers published for this
+            // block) -> scale/shift, LeakyReLU, + residual -> global
             static_assert(WinoRows<BT, BNW>::PASSES == 16, "one accumulator set is reset per store pass");
             rows.finish(p, cs, n0, [&](int i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            });
+            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4));
         } else {
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
-            // partial block: the output-space sums go to this worker's slot (0 = its first block, 1 = its last)
-            float* slot = p.partial + ((size_t)worker * 2 + (blk == first_blk ? 0 : 1)) * (BT * 4 * BNW);
+            // producer: the output-space sums go to this worker's slot, write-through (sc1), then the flag
+            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial, 0, (unsigned)((size_t)p.workers * BT * 4 * BNW * 4), 0x00020000);
+            const unsigned slot_off = (unsigned)worker * (unsigned)(BT * 4 * BNW * 4);
             constexpr int C4 = BNW / 4;
             for (int f = tid; f < BT * 4 * C4; f += 256) {
                 const int rr = f / C4, c4 = f - rr * C4;
-                reinterpret_cast<f32x4*>(slot)[f] = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_part,
+                                                       slot_off + (unsigned)f * 16u, 0, 16);   // aux 16 = sc1
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
+            __syncthreads();
+            if (tid == 0)                                          // ... before one lane raises the flag
+                __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
         Y3_STAMP(5);    // scale/shift/activation/residual/stores (or the partial-slot copy), barrier
@@ -529,47 +593,6 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         for (int k = 0; k < 6; ++k) out[3 + k] = clk_phase[k];
     }
 #endif
-}
-
-// Stream-K fix-up: one workgroup per block; blocks computed whole by one worker exit at once, split blocks sum their
-// partial slots in worker (= K) order and run the common tail.
-template <int WGM, int WGN>
-__global__ void __launch_bounds__(256) conv_wino_fixup_kernel(const WinoArgs p) {
-    constexpr int BT = WGM * 32, BNW = WGN * 32, LDC = BNW + 4, C4 = BNW / 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* cs = reinterpret_cast<float*>(smem);                         // [BT*4][LDC]
-    int* tile_pix = reinterpret_cast<int*>(smem + (size_t)BT * 4 * LDC * 4);
-    int* tile_ok = tile_pix + BT;
-    const int nbt = (p.T + BT - 1) / BT;
-    const int ksteps = p.Cin / WKC;
-    const long long items = (long long)nbt * ((p.Cout + BNW - 1) / BNW) * ksteps;
-    const int blk = blockIdx.x;
-    const long long i0 = (long long)blk * ksteps, i1 = i0 + ksteps;
-    const int w_lo = wk_owner(items, p.workers, i0), w_hi = wk_owner(items, p.workers, i1 - 1);
-    if (w_lo == w_hi) return;
-    const int tid = threadIdx.x;
-    const int bn = fastdiv(blk, nbt), bt = blk - bn * nbt;
-    if (tid < BT) {
-        int pix, okbits, n, ty, tx;
-        wino_tile_info(p, bt * BT + tid, pix, okbits, n, ty, tx);
-        tile_pix[tid] = pix;
-        tile_ok[tid] = okbits;
-    }
-    __syncthreads();
-    WinoRows<BT, BNW> rows;
-    rows.prepare(p, tile_pix, tile_ok, bn * BNW);
-    for (int f = tid; f < BT * 4 * C4; f += 256) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int w = w_lo; w <= w_hi; ++w) {
-            const int first = (int)(wk_begin(items, p.workers, w) / ksteps);
-            const float* slot = p.partial + ((size_t)w * 2 + (blk == first ? 0 : 1)) * (BT * 4 * BNW);
-            v += reinterpret_cast<const f32x4*>(slot)[f];
-        }
-        const int rr = f / C4, c4 = f - rr * C4;
-        *reinterpret_cast<f32x4*>(cs + rr * LDC + c4 * 4) = v;
-    }
-    __syncthreads();
-    rows.finish(p, cs, bn * BNW, [](int) {});
 }
 
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
@@ -618,9 +641,13 @@ int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int co
 
 constexpr int WK_WORKERS = 256;     // one persistent workgroup per CU (128 KB of LDS, 256 AGPRs + ~150 VGPRs per wave)
 
+// stream-K scratch: one partial-sum slot per worker, then one flag word per worker
+constexpr size_t WK_SLOT_BYTES = (size_t)64 * 4 * 64 * sizeof(float);
+constexpr size_t WK_FLAGS_OFFSET = (size_t)WK_WORKERS * WK_SLOT_BYTES;
+
 size_t y3_conv_wino_workspace_bytes_impl(const y3_conv_desc* d) {
     if (!y3_conv_wino_eligible_impl(d)) return 0;
-    return (size_t)WK_WORKERS * 2 * (64 * 4 * 64) * sizeof(float);
+    return WK_FLAGS_OFFSET + (size_t)WK_WORKERS * sizeof(unsigned);
 }
 
 int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
@@ -637,21 +664,17 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
     a.TH = (d->h + 1) / 2; a.TW = (d->w + 1) / 2; a.T = d->n * a.TH * a.TW;
-    a.partial = nullptr; a.workers = 0;
+    a.partial = nullptr; a.flags = nullptr; a.workers = 0;
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
-    constexpr size_t lds_fix = (size_t)BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
     auto kern = conv_wino_f32_kernel<2, 2, false>;
     auto kern_sk = conv_wino_f32_kernel<2, 2, true>;
-    auto fix = conv_wino_fixup_kernel<2, 2>;
     static bool attr_set = false;   // benign race (idempotent)
     if (!attr_set) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fix),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fix));
         attr_set = true;
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = (a.Cout + BNW - 1) / BNW;
@@ -666,17 +689,18 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     bool sk = has_ws && blocks > WK_WORKERS && blocks < 8 * WK_WORKERS && blocks % WK_WORKERS != 0;
-    if (force >= 0) sk = has_ws && force != 0 && blocks >= WK_WORKERS;
+    if (force >= 0) sk = has_ws && force != 0 && blocks >= WK_WORKERS;     // (>= workers: no worker range is empty)
     if (sk) {
         a.partial = static_cast<float*>(workspace);
+        a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + WK_FLAGS_OFFSET);
         a.workers = WK_WORKERS;
+        // every polled word is zeroed ahead of every launch (no state is assumed in the caller's workspace)
+        Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)WK_WORKERS * sizeof(unsigned), stream));
         hipLaunchKernelGGL(kern_sk, dim3(WK_WORKERS), dim3(256), lds, stream, a);
-        Y3_CHECK_HIP(hipGetLastError());
-        if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));
-        hipLaunchKernelGGL(fix, dim3(blocks), dim3(256), lds_fix, stream, a);
     } else {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
     }
+    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));   // (profiling hook; no second kernel any more)
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
