@@ -60,12 +60,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
 
     // ---- this workgroup's range of work items (item = tile * S + kstep) ----------------------------
     long long item, item_end;
-    int worker = 0;
+    SkWorker skw = {};
+    const int ntiles = nbm * nbn;
     if (STREAMK) {
-        const long long items = (long long)((p.M + BM - 1) / BM) * nbn * S;
-        worker = sk_worker_id(blockIdx.x, p.workers);
-        item = sk_begin(items, p.workers, worker);
-        item_end = sk_begin(items, p.workers, worker + 1);
+        skw = sk_worker(blockIdx.x, ntiles, S, p.workers);
+        item = skw.begin;
+        item_end = skw.end;
     } else {
         // workgroup b runs on XCD b%8 (observed): give each XCD a contiguous eighth of the tile ids
         const int nt = gridDim.x;
@@ -75,7 +75,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         item_end = item + S;
     }
     if (item >= item_end) return;
-    const long long first_tile = item / S;
 
     // ---- per-thread staging coordinates: float4 column c4 of rows r0 + 32*j ---------------------
     const int c4 = (tid & 7) * 4;
@@ -306,21 +305,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         compute_tile((nsteps - 1) & 1);
         __syncthreads();
 
-        if (!STREAMK || (ks == 0 && seg_end == tile_end)) {
-            epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, m0, n0);
+        if (STREAMK && ks > 0) {
+            // later K-steps of a cut tile (this worker's first segment): publish the raw accumulators
+            sk_publish<BM, BN, WGM, WGN>(p, skw.id, acc);
         } else {
-            // partial tile: raw accumulators to this worker's slot (0 = its first tile, 1 = its last)
-            float* slot = p.partial + ((size_t)worker * 2 + (tile == (int)first_tile ? 0 : 1)) * (BM * BN);
-            f32x4* slot4 = reinterpret_cast<f32x4*>(slot);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)   // 16 bytes per lane: registers 4g..4g+3
-                        slot4[((mi * NI + ni) * 4 + g) * 256 + tid] =
-                            f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2],
-                                  acc[mi][ni][4 * g + 3]};
+            // whole tile, or K-steps [0, k) of a cut tile (this worker's last segment): add what the next workers
+            // of the group published for it, then the common epilogue
+            if (STREAMK && seg_end < tile_end) sk_consume<BM, BN, WGM, WGN>(p, skw, ntiles, S, tile_end, acc);
+            epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, m0, n0);
         }
         if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
@@ -348,19 +340,14 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) 
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
     auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true, TMODE>;
-    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS, TMODE>;
     static bool attr_set = false;
     if (!attr_set) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
-        if (int rc = set_lds_attr(fix, G::LDS_BYTES)) return rc;
         attr_set = true;
     }
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
-    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));  // profiling: main kernel | fix-up
-    hipLaunchKernelGGL(fix, dim3(tiles), dim3(256), G::LDS_BYTES, stream, a);
-    Y3_CHECK_HIP(hipGetLastError());
+    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));  // (profiling hook; no second kernel any more)
     return Y3_OK;
 }
 
@@ -389,7 +376,7 @@ int y3_conv_schedule_impl(const y3_conv_desc* d) {
 
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d) {
     if (!d || d->k != 3 || d->cout < 128 || d->c_up > 0) return 0;
-    return (size_t)SK_WORKERS * 2 * 128 * 128 * sizeof(float);
+    return SK_WORKSPACE_BYTES;
 }
 
 int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
@@ -406,7 +393,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     Y3_CHECK_ARG((x_up != nullptr) == (d->c_up > 0), "y3_conv2d_fwd: x_up and c_up must agree");
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
-    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0; a.bkk = BK;
+    a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -438,8 +425,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     if (use_streamk(a, d->k, has_ws)) {
-        a.partial = static_cast<float*>(workspace);
-        a.workers = SK_WORKERS;
+        if (int rc = sk_prepare(stream, a, workspace)) return rc;
         return launch_streamk<3>(stream, a, mid_event);
     }
     return dispatch_bn<3, false>(stream, a);
@@ -465,7 +451,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     ConvArgs a;
     a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
     a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.workers = 0;
-    a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0; a.bkk = BK;
+    a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
     a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;
     a.Ho = fwd->h; a.Wo = fwd->w;
@@ -474,7 +460,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
                  "y3_conv2d_dgrad: tensor exceeds 2^29 elements (32-bit byte offsets)");
     a.M = (int)M;
     if (fwd->k == 1) return dispatch_bn<1, false>(stream, a);
-    const bool has_ws = workspace != nullptr && workspace_bytes >= (size_t)SK_WORKERS * 2 * 128 * 128 * sizeof(float) &&
+    const bool has_ws = workspace != nullptr && workspace_bytes >= SK_WORKSPACE_BYTES &&
                         ((uintptr_t)workspace & 15) == 0;
     if (fwd->stride == 2) {
         // four output parity classes, each a dense conv over N*Ho*Wo rows with 1/2/2/4 taps
@@ -486,9 +472,8 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
             a.partial = nullptr; a.workers = 0;
             int rc;
             if (use_streamk(a, 3, has_ws)) {
-                a.partial = static_cast<float*>(workspace);
-                a.workers = SK_WORKERS;
-                rc = launch_streamk<3, true>(stream, a, nullptr);
+                rc = sk_prepare(stream, a, workspace);
+                if (rc == Y3_OK) rc = launch_streamk<3, true>(stream, a, nullptr);
             } else {
                 rc = dispatch_bn<3, false, true>(stream, a);
             }
@@ -497,8 +482,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
         return Y3_OK;
     }
     if (use_streamk(a, 3, has_ws)) {
-        a.partial = static_cast<float*>(workspace);
-        a.workers = SK_WORKERS;
+        if (int rc = sk_prepare(stream, a, workspace)) return rc;
         return launch_streamk<3>(stream, a, nullptr);
     }
     return dispatch_bn<3, false>(stream, a);

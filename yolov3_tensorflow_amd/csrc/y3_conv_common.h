@@ -15,7 +15,8 @@ struct ConvArgs {
     const float* shift;  // [Cout]
     const float* resid;  // [M,Cout] or nullptr
     float* y;            // [M,Cout]
-    float* partial;      // stream-K scratch: [workers][2][BM*BN] raw accumulators
+    float* partial;      // stream-K scratch: [workers][BM*BN] raw accumulators of the cut tiles' later K-ranges
+    unsigned* flags;     // stream-K scratch: [workers] "partial published" words, zeroed ahead of every launch
     int N, H, W, Cin, Cu, Cx;
     int Ho, Wo, Cout;
     int stride, pad, act;
@@ -27,7 +28,6 @@ struct ConvArgs {
                          //    the class pixels (2y'+cy, 2x'+cx); only the taps whose parity matches contribute
                          //    (1, 2, 2 or 4 of the 9), reading x[y'+dy, x'+dx] with dy,dx in {0,1}
     int cy, cx, ntaps;   // tmode only
-    int bkk;             // K elements per K-step of the kernel that produced the stream-K partials (fix-up)
 };
 
 constexpr int BK = 32;
@@ -164,62 +164,135 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
     }
 }
 
+// ---- stream-K schedule ---------------------------------------------------------------------------------------
 // Balanced contiguous partition of `items` over `workers`: worker w owns [begin(w), begin(w+1)).
 __device__ __host__ __forceinline__ long long sk_begin(long long items, int workers, int w) {
     const long long q = items / workers, r = items % workers;
     return (long long)w * q + (w < r ? w : r);
 }
-__device__ __host__ __forceinline__ int sk_owner(long long items, int workers, long long item) {
-    const long long q = items / workers, r = items % workers;
-    if (item < r * (q + 1)) return (int)(item / (q + 1));
-    return (int)(r + (item - r * (q + 1)) / q);
+// The output tiles are first divided, whole, among the 8 XCD groups (group x = workgroups with blockIdx % 8 == x:
+// one L2; a group's tiles are neighbours, so they share A halos / B panels); inside a group its G = workers/8
+// workers own equal contiguous ranges of (tile, K-step) items.  A tile cut by a range boundary is finished INSIDE
+// the kernel: the worker that owns the tile's later K-steps meets them FIRST in its range, writes its raw
+// accumulators write-through and raises a flag; the worker that owns the tile's K-step 0 meets the tile LAST, adds
+// the published accumulators in worker order (deterministic) and runs the normal epilogue.
+// Local worker j runs in workgroup blockIdx = x + 8*(G-1-j): a consumer j waits only for workers j+1.. of its own
+// group, which have SMALLER workgroup ids, i.e. were dispatched earlier - the wait cannot deadlock even when fewer
+// than `workers` workgroups are resident.  (workers % 8 == 0, items of a group >= G.)
+// (32-bit arithmetic: the launchers keep tiles * S below 2^31; the 64-bit division expansion costs ~40 registers
+// where this runs, next to live accumulators)
+__device__ __host__ __forceinline__ int sk_begin32(int items, int workers, int w) {
+    const int q = items / workers, r = items - q * workers;
+    return w * q + (w < r ? w : r);
 }
-// XCD-aware worker id: workgroup b runs on XCD b%8 (observed, speed only); give each XCD a contiguous
-// eighth of the item space so neighbouring tiles share their A halo / B panel in one L2.
-__device__ __forceinline__ int sk_worker_id(int b, int workers) {
-    return (workers & 7) == 0 ? (b & 7) * (workers >> 3) + (b >> 3) : b;
+__device__ __host__ __forceinline__ void sk_range(int tiles, int S, int workers, int x, int j, long long& begin,
+                                                  long long& end) {
+    const int G = workers >> 3;
+    const int t0 = sk_begin32(tiles, 8, x), t1 = sk_begin32(tiles, 8, x + 1);
+    const int items = (t1 - t0) * S;
+    const int q = items / G, r = items - q * G;
+    begin = t0 * S + (j * q + (j < r ? j : r));
+    end = t0 * S + ((j + 1) * q + (j + 1 < r ? j + 1 : r));
+}
+struct SkWorker {
+    int grp, lw, id;     // XCD group, local worker in the group, global worker index (slot / flag index)
+    long long begin, end;
+};
+__device__ __forceinline__ SkWorker sk_worker(int b, int tiles, int S, int workers) {
+    SkWorker w;
+    w.grp = b & 7;
+    w.lw = (workers >> 3) - 1 - (b >> 3);
+    w.id = w.grp * (workers >> 3) + w.lw;
+    sk_range(tiles, S, workers, w.grp, w.lw, w.begin, w.end);
+    return w;
 }
 
-// Stream-K fix-up: one workgroup per output tile; tiles computed whole by one worker exit at once, split
-// tiles sum their partials in worker (= K) order and run the common epilogue.
-template <int BM, int BN, int WGM, int WGN, int KS, bool TMODE>
-__global__ void __launch_bounds__(256, 2) conv_streamk_fixup_kernel(const ConvArgs p) {
+typedef __attribute__((address_space(1))) unsigned gu32;   // flags: agent-scope global atomics only
+typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
+
+// Producer: this worker's accumulators of a cut tile's later K-range -> its slot, 16 B per lane write-through
+// (sc1: no release fence needed), every storing wave drains, then ONE lane raises the flag.
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void sk_publish(const ConvArgs& p, int worker,
+                                           const f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI]) {
     using G = Geo<BM, BN, WGM, WGN>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nbn = (p.Cout + BN - 1) / BN;
-    const int S = (TMODE ? p.ntaps : KS * KS) * (p.Cin / p.bkk);
-    const long long items = (long long)((p.M + BM - 1) / BM) * nbn * S;
-    const int tile = blockIdx.x;
-    const long long t0 = (long long)tile * S, t1 = t0 + S;
-    const int w_lo = sk_owner(items, p.workers, t0), w_hi = sk_owner(items, p.workers, t1 - 1);
-    if (w_lo == w_hi) return;
     const int tid = threadIdx.x;
-    f32x16 acc[G::MI][G::NI];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.partial, 0, (unsigned)((size_t)p.workers * BM * BN * 4), 0x00020000);
+    const unsigned base = (unsigned)worker * (unsigned)(BM * BN * 4);
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    for (int w = w_lo; w <= w_hi; ++w) {
-        const long long wb = sk_begin(items, p.workers, w);
-        const int first = (int)(wb / S);
-        const float* slot = p.partial + ((size_t)w * 2 + (tile == first ? 0 : 1)) * (BM * BN);
-        const f32x4* slot4 = reinterpret_cast<const f32x4*>(slot);
+            for (int g = 0; g < 4; ++g) {   // 16 bytes per lane: registers 4g..4g+3
+                const f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2],
+                                 acc[mi][ni][4 * g + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_u32x4, v), rs,
+                                                       (unsigned)((((mi * G::NI + ni) * 4 + g) * 256 + tid) * 16),
+                                                       base, 16);   // aux 16 = sc1
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Consumer: the worker that owns K-steps [0, k) of a cut tile (its LAST segment, ending at item `seg_end` inside
+// the tile that ends at `tile_end`).  Counts the following workers of its group whose ranges start inside the tile,
+// waits for their flags (one lane polls, one acquire), and adds their slots to `acc` in worker order.
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void sk_consume(const ConvArgs& p, const SkWorker& w, int tiles, int S, long long tile_end,
+                                           f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI]) {
+    using G = Geo<BM, BN, WGM, WGN>;
+    const int tid = threadIdx.x;
+    // following workers whose range starts inside the tile; an empty range publishes nothing
+    const int G8 = p.workers >> 3;
+    const int t0 = sk_begin32(tiles, 8, w.grp), t1 = sk_begin32(tiles, 8, w.grp + 1);
+    const int gitems = (t1 - t0) * S, gq = gitems / G8, gr = gitems - gq * G8;
+    const int rel_end = (int)(tile_end - (long long)t0 * S);
+    int n = 0;
+    unsigned live = 0;   // bit e: worker w.id + 1 + e has a non-empty range (n <= 32 by the launcher's size rule)
+    for (int jj = w.lw + 1; jj < G8; ++jj) {
+        const int b = jj * gq + (jj < gr ? jj : gr), e = (jj + 1) * gq + (jj + 1 < gr ? jj + 1 : gr);
+        if (b >= rel_end) break;
+        n = jj - w.lw;
+        live |= (b < e ? 1u : 0u) << (n - 1);
+    }
+    if (tid == 0) {
+        for (int e = 0; e < n; ++e) {
+            if (!((live >> e) & 1)) continue;
+            gu32* flag = (gu32*)(p.flags + w.id + 1 + e);
+            // bounded: on expiry the result is wrong (the tests catch it) but the launch ends
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+        p.partial, 0, (unsigned)((size_t)p.workers * BM * BN * 4), 0x00020000);
+    for (int e = 0; e < n; ++e) {
+        if (!((live >> e) & 1)) continue;
 #pragma unroll
         for (int mi = 0; mi < G::MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < G::NI; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = slot4[((mi * G::NI + ni) * 4 + g) * 256 + tid];
+                    // system-scope loads (aux 17 = sc0 sc1): measured necessary - plain loads after the one-lane
+                    // acquire still returned stale lines for consumers that arrive right when the flag flips
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rs_c, (unsigned)((((mi * G::NI + ni) * 4 + g) * 256 + tid) * 16),
+                        (unsigned)(w.id + 1 + e) * (unsigned)(BM * BN * 4), 17));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[mi][ni][4 * g + q] += v[q];
+                    if (g & 1) __builtin_amdgcn_sched_barrier(0);   // two loads in flight: registers are scarce here
                 }
     }
-    const int nbm = (p.M + BM - 1) / BM;
-    const int bn = tile / nbm, bm = tile - bn * nbm;
-    epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, bm * BM, bn * BN);
 }
 
 // ---- stem conv: 3x3, Cin = 3 -> COUT (=32), stride 1 ------------------------------------------------
@@ -315,6 +388,19 @@ inline int set_lds_attr(K kern, size_t lds) {
 }
 
 constexpr int SK_WORKERS = 512;  // 256 CUs x 2 co-resident 128x128 workgroups (73.7 KB LDS, 176 VGPRs)
+// stream-K scratch: one accumulator slot per worker, then one flag word per worker
+constexpr size_t SK_SLOT_BYTES = (size_t)128 * 128 * sizeof(float);
+constexpr size_t SK_FLAGS_OFFSET = (size_t)SK_WORKERS * SK_SLOT_BYTES;
+constexpr size_t SK_WORKSPACE_BYTES = SK_FLAGS_OFFSET + (size_t)SK_WORKERS * sizeof(unsigned);
+
+// points the kernel arguments at the scratch and zeroes every polled word ahead of the launch
+inline int sk_prepare(hipStream_t stream, ConvArgs& a, void* workspace) {
+    a.partial = static_cast<float*>(workspace);
+    a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + SK_FLAGS_OFFSET);
+    a.workers = SK_WORKERS;
+    Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)SK_WORKERS * sizeof(unsigned), stream));
+    return Y3_OK;
+}
 
 // Schedule choice: stream-K for 3x3 convs on 128x128 tiles whose tile count is within a few multiples
 // of the co-resident workgroup count (tail quantisation dominates there); Y3_CONV_STREAMK=0/1 overrides
@@ -328,6 +414,10 @@ inline bool use_streamk(const ConvArgs& a, int k, bool has_ws) {
     }
     if (force == 0) return false;
     const int tiles = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    // every worker of every XCD group gets at least one (tile, K-step) item, and a tile is cut into < 32 ranges
+    const long long S = (long long)(a.tmode ? a.ntaps : k * k) * (a.Cin / 32);
+    if (tiles < 32 || (tiles / 8) * S < SK_WORKERS / 8) return false;   // (tiles/8 >= 4: a tile spans <= 18 ranges)
+    if ((long long)tiles * S >= (1LL << 31)) return false;
     if (force == 1) return true;
     return tiles < 4 * SK_WORKERS;
 }

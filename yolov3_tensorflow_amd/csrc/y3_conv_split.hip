@@ -64,12 +64,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
 
     // ---- this workgroup's range of work items (item = tile * S + pair) --------------------------------
     long long item, item_end;
-    int worker = 0;
+    SkWorker skw = {};
+    const int ntiles = nbm * nbn;
     if (STREAMK) {
-        const long long items = (long long)nbm * nbn * S;
-        worker = sk_worker_id(blockIdx.x, p.workers);
-        item = sk_begin(items, p.workers, worker);
-        item_end = sk_begin(items, p.workers, worker + 1);
+        skw = sk_worker(blockIdx.x, ntiles, S, p.workers);
+        item = skw.begin;
+        item_end = skw.end;
     } else {
         const int nt = gridDim.x;
         const int q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -78,7 +78,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         item_end = item + S;
     }
     if (item >= item_end) return;
-    const int first_tile = (int)(item / S);
 
     // staging coordinates.  A: float4 column c4 of rows r0 + 64*j.  B: 16-byte half `tid&1` (8 bf16) of row tid>>1.
     const int brow = tid >> 1, bhalf = tid & 1;
@@ -283,21 +282,14 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         compute(1);
         __syncthreads();
 
-        if (!STREAMK || (pair0 == 0 && seg_end == tile_end)) {
-            epilogue<BM, BN, WGM, WGN, false>(p, reinterpret_cast<float*>(smem_raw), acc, bm * BM, bn * BN);
+        if (STREAMK && pair0 > 0) {
+            // later K-steps of a cut tile (this worker's first segment): publish the raw accumulators
+            sk_publish<BM, BN, WGM, WGN>(p, skw.id, acc);
         } else {
-            // partial tile: raw accumulators to this worker's slot (0 = its first tile, 1 = its last)
-            float* slot = p.partial + ((size_t)worker * 2 + (tile == first_tile ? 0 : 1)) * (BM * BN);
-            f32x4* slot4 = reinterpret_cast<f32x4*>(slot);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        slot4[((mi * NI + ni) * 4 + q) * 256 + tid] =
-                            f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2],
-                                  acc[mi][ni][4 * q + 3]};
+            // whole tile, or the first K-steps of a cut tile (this worker's last segment): add what the next workers
+            // of the group published for it, then the common epilogue
+            if (STREAMK && seg_end < tile_end) sk_consume<BM, BN, WGM, WGN>(p, skw, ntiles, S, tile_end, acc);
+            epilogue<BM, BN, WGM, WGN, false>(p, reinterpret_cast<float*>(smem_raw), acc, bm * BM, bn * BN);
         }
         if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
@@ -323,22 +315,16 @@ int launch_dp(hipStream_t stream, const ConvArgs& a) {
 template <int KS, int NP>
 int launch_sk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
-    using G = Geo<BM, BN, WGM, WGN>;
     auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, false, true, NP>;
-    auto fix = conv_streamk_fixup_kernel<BM, BN, WGM, WGN, KS, false>;
     constexpr size_t lds = split_lds_bytes<BM, BN, NP>();
     static bool attr_set = false;
     if (!attr_set) {
         if (int rc = set_lds_attr(kern, lds)) return rc;
-        if (int rc = set_lds_attr(fix, G::LDS_BYTES)) return rc;
         attr_set = true;
     }
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), lds, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
-    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));
-    hipLaunchKernelGGL(fix, dim3(tiles), dim3(256), G::LDS_BYTES, stream, a);
-    Y3_CHECK_HIP(hipGetLastError());
+    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));   // (profiling hook; no second kernel any more)
     return Y3_OK;
 }
 
@@ -357,8 +343,7 @@ int launch_np(hipStream_t stream, const y3_conv_desc* d, ConvArgs& a, void* work
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     if (use_streamk(a, d->k, has_ws)) {
-        a.partial = static_cast<float*>(workspace);
-        a.workers = SK_WORKERS;
+        if (int rc = sk_prepare(stream, a, workspace)) return rc;
         return launch_sk<3, NP>(stream, a, mid_event);
     }
     return dispatch_bn<3, false, NP>(stream, a);
@@ -410,8 +395,7 @@ int check_desc(const y3_conv_desc* d, const void* x_up, const char* who) {
 }
 
 void fill_args(ConvArgs& a, const y3_conv_desc* d) {
-    a.partial = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
-    a.bkk = 2 * SBK;   // stream-K items are K-step pairs
+    a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;

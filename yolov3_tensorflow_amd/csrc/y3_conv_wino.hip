@@ -169,7 +169,9 @@ struct WinoRows {
             for (int e = 0; e < n_extra; ++e)
                 v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                          rs_x, (unsigned)((tr + i * RPP) * BNW + tc) * 4u,
-                         extra_base + (unsigned)e * (unsigned)(BT * 4 * BNW * 4), 0));
+                         extra_base + (unsigned)e * (unsigned)(BT * 4 * BNW * 4), 17));   // aux 17 = sc0 sc1:
+                // system-scope loads; plain loads after the one-lane acquire were measured to return stale lines
+                // when the consumer arrives right as the flag flips (y3_conv_common.h, sk_consume)
             v = v * sc + sh;
             if (p.act) {
 #pragma unroll
