@@ -14,8 +14,9 @@ and the max-over-ranks of the elapsed time.  Prints ONE JSON line on rank 0.
 roofline: the dominant kernel is conv_mfma_f32_kernel<128,128,2,2,3,false,true> — the 3x3 implicit-GEMM MFMA
 conv in its stream-K schedule (32 of the 75 conv layers, ~84 % of the FLOPs, ~70 % of the time).  It is
 matrix-pipe bound in fp32: achieved = algorithmic FLOPs of those 32 launches / the sum of
-their durations, measured with hipEvents recorded on the launch stream inside the timed region (one event
-before the kernel, one between it and its fix-up kernel), peak = 157.3 TFLOP/s (fp32 MFMA).
+their durations, measured with hipEvents recorded on the launch stream inside the timed region (one event per
+layer boundary), peak = 157.3 TFLOP/s (fp32 MFMA).  In the default precision the dominant kernel is the Winograd
+kernel conv_wino_f32_kernel<2,2> and `achieved` counts the algorithmic (direct) FLOPs.
 fast_path: after the timed region the same steps are repeated with compute_dtype='f32_bf16x6' (fp32 tensors, every
 product rebuilt from six bf16 matrix-pipe products, fp32 accumulation) and reported next to the
 exact-fp32 `value` together with the max deviation between the two sets of feature maps.  It is never `value`.

@@ -81,7 +81,9 @@ typedef struct y3_conv_desc {
     int act;       /* 0 linear, 1 leaky(0.1) */
 } y3_conv_desc;
 
-/* Scratch the stream-K schedule of this conv may use (0 if it never does).  Passing workspace = NULL to
+/* Scratch the stream-K schedule of this conv may use (0 if it never does): one accumulator slot per persistent
+ * workgroup + one flag word each; uninitialised memory is fine (the library zeroes the words it polls ahead of every
+ * launch) and it must not be shared by launches on different streams.  Passing workspace = NULL to
  * y3_conv2d_fwd is allowed and selects the data-parallel schedule; results of the two schedules differ in
  * the last bits (the K sum of a split tile is associated differently), each is deterministic. */
 size_t y3_conv_workspace_bytes(const y3_conv_desc* d);
@@ -100,10 +102,12 @@ int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const 
 
 /* ---- Winograd F(2x2,3x3) form of the stride-1 3x3 conv (exact fp32 arithmetic, 2.25x fewer multiplies) ------------
  * Same tensors and epilogue as y3_conv2d_fwd (utils/layer_utils.py:9-22,25-32) for the convs
- * y3_conv_wino_eligible accepts (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cin >= 64,
+ * y3_conv_wino_eligible accepts (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0,
  * Cout %% 32 == 0).  w_wino = G g G^T per (cin, cout), packed [16][cin/8][cout][8] fp32 (16*cin*cout floats) by
  * y3_pack_conv_weights_wino.  Results differ from the direct kernel by a few fp32 roundings per term.  With a
- * workspace the kernel may pick a stream-K schedule (persistent grid + deterministic fix-up), as y3_conv2d_fwd does. */
+ * workspace the kernel may pick a stream-K schedule (persistent grid; cut blocks are summed inside the kernel in a fixed
+ * order, so results are run-to-run bit-exact), as y3_conv2d_fwd does.  The workspace needs no initialisation: the
+ * library zeroes the words it polls ahead of every launch. */
 int y3_conv_wino_eligible(const y3_conv_desc* d);
 int y3_pack_conv_weights_wino(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino);
 size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d);   /* stream-K scratch; workspace = NULL is allowed */
@@ -192,8 +196,8 @@ int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* works
  * the per-layer elapsed ms averaged over the forwards recorded since the previous call, and resets. */
 int y3_net_set_profiling(y3_net* net, int enabled);
 int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int count);
-/* ms_tail (nullable): for layers that launch two kernels (stream-K conv + its fix-up) the part of ms[i]
- * spent after the main kernel; equals ms[i] for single-kernel layers (their mark precedes the launch). */
+/* ms_tail (nullable): the part of ms[i] spent after the layer's kernel (kept for ABI stability: every layer is one
+ * kernel now, so it is ~0 for stream-K layers and equals ms[i] for the others, whose mark precedes the launch). */
 int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w);
 
 /* graph topology of y3_net (tensor ids: 0 = network input, 1.. = conv outputs in creation order; -1 = none) */

@@ -1,6 +1,6 @@
 // Shared pieces of the implicit-GEMM conv kernels (exact-fp32 MFMA kernel in y3_conv.hip, split-bf16 kernel in
 // y3_conv_split.hip): argument block, tile geometry, the LDS-staged epilogue, the stream-K partition and its
-// fix-up kernel.
+// in-kernel hand-off of cut tiles.
 #pragma once
 #include <cstdlib>
 #include "y3_internal.h"
@@ -71,7 +71,7 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[NP]) {
         o[pl][1] = (h[pl][2] >> 16) | h[pl][3];
     }
 }
-// ---- epilogue shared by the conv kernel and the stream-K fix-up kernel ------------------------------
+// ---- epilogue shared by the conv kernels ------------------------------------------------------------
 // D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int BM, int BN, int WGM, int WGN, bool TMODE>
 __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,

@@ -10,15 +10,17 @@
 //   * a workgroup owns BT = 64 output tiles x 64 output channels for ALL 16 transform positions: each of its four
 //     waves accumulates 16 independent 32(tiles) x 32(channels) products = 256 accumulator registers, so the kernel
 //     runs one wave per SIMD with the accumulators in AGPRs;
-//   * K-step = 8 input channels = 64 MFMAs (4096 cycles) per wave.  Waves 0-1 stage the activations: each thread
-//     gathers the 4x4 input patch of one tile for 4 channels (16 bounds-checked 16-byte loads, padding = OOB = 0),
-//     applies B^T d B on the float4s in registers (32 vector adds) and writes the 16 transformed float4s to the LDS;
-//     waves 2-3 copy the K-step's weight slabs.  Loads for K-step s+1 are issued before the MFMAs of K-step s
-//     (register prefetch, double-buffered LDS);
+//   * K-step = 8 input channels = 64 MFMAs (4096 cycles) per wave, ONE basic block: every thread stages a 1/256 share
+//     of both operands - the 4x4 input patch of one (tile, channel pair) as 16 bounds-checked 8-byte loads (padding =
+//     OOB = 0), B^T d B on the float2s (32 packed adds), 16 8-byte LDS writes, and eight 16-byte weight pieces - and
+//     sched_group_barrier hints weave the loads of K-step s+1, the transform and the LDS writes into the gaps of the
+//     MFMAs of K-step s (register prefetch, double-buffered LDS, fragment reads pipelined across the barrier);
 //   * LDS rows are 32 bytes (8 channels) per (position, tile|channel), halves XOR-swizzled as in y3_conv_split.hip;
 //   * epilogue: the 16 position sums of one (tile, channel) live in the same lane and register index of the 16
-//     accumulator sets, so A^T M A is 24 adds per output tile in registers; then scale/shift, LeakyReLU, residual,
-//     and 128-byte-per-half-wave stores.
+//     accumulator sets, so A^T M A is 24 adds per output tile in registers; then (through an LDS staging tile)
+//     scale/shift, LeakyReLU, residual and 16-byte row-contiguous branch-free buffer stores;
+//   * block counts that do not fill the last round of the 256 resident workgroups run a persistent stream-K schedule
+//     whose cut blocks are finished inside the kernel (wk_range below).
 // Numerics: the transforms use only additions and the constants 1/2, so the result differs from the direct sum by a
 // few fp32 roundings per term (tests/test_conv_gpu.py holds it to the same 1e-4 tolerance against fp64).
 #include <cstdlib>
@@ -107,8 +109,7 @@ __device__ __forceinline__ void input_transform(const V (&d)[16], V (&v)[16]) {
     }
 }
 
-// Shared tail of the kernel and the fix-up, in two steps so that the residual loads fly while the caller still works
-// (the kernel's output transform, the fix-up's partial sums): prepare() computes the output offsets of this thread's
+// The kernel's tail, in two steps so that the residual loads fly under the output transform: prepare() computes the output offsets of this thread's
 // float4 rows of the staging tile cs[BT*4][LDC] and issues the residual loads; finish() reads the staged rows ->
 // scale/shift, LeakyReLU, + residual -> global.  tile_pix / tile_ok describe the workgroup's tiles (see the kernel).
 template <int BT, int BNW>
@@ -214,7 +215,7 @@ __device__ __forceinline__ void wino_tile_info(const WinoArgs& p, int t, int& pi
 
 // STREAMK: a persistent grid of p.workers workgroups (one per CU), each owning an equal contiguous range of
 // (block, K-step) work items; a block computed by several workers is summed in output space by
-// conv_wino_fixup_kernel (fixed worker order: deterministic).
+// the consumer worker inside the kernel (fixed worker order: deterministic; wk_range above).
 template <int WGM, int WGN, bool STREAMK>
 __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");

@@ -178,8 +178,8 @@ class yolov3(object):
     def read_layer_ms(self, device=None, with_main=False, shape=None):
         """Per-layer ms averaged over the forwards recorded since the last read (synchronises), plus the
         layer table [(k, stride, cin, cout, has_bn)].  with_main=True also returns, per layer, the duration
-        of the layer's main kernel alone (differs from the total only for stream-K layers, whose fix-up
-        kernel is timed separately) and the stream-K flags; needs shape=(n, h, w)."""
+        of the layer's kernel alone (y3_net_get_layer_ms's ms_tail; the same as the total now that a stream-K
+        layer is one kernel) and the stream-K flags; needs shape=(n, h, w)."""
         ent = self._get_net(device if device is not None else fw.default_device())
         nl = len(ent['table'])
         L = _lib.lib()
