@@ -87,6 +87,14 @@ typedef struct y3_conv_desc {
  * y3_conv2d_fwd is allowed and selects the data-parallel schedule; results of the two schedules differ in
  * the last bits (the K sum of a split tile is associated differently), each is deterministic. */
 size_t y3_conv_workspace_bytes(const y3_conv_desc* d);
+/* Test hook (host arithmetic only, no device needed): the stream-K work split the kernels evaluate on the device.
+ * `units` output tiles (kind 0: direct / split kernels) or Winograd blocks (kind 1) of `ksteps` K-steps each are divided,
+ * whole, among 8 workgroup groups (blockIdx %% 8); inside group `group` its workers/8 local workers own equal
+ * contiguous ranges of (unit, K-step) items: [*begin, *end) for `local_worker`.  A unit cut by a range boundary is
+ * finished inside the kernel by the worker owning its K-step 0, from the partial sums the following local workers
+ * publish; tests/test_streamk_partition.py replays that protocol on these ranges. */
+int y3_streamk_range(int kind, int units, int ksteps, int workers, int group, int local_worker, long long* begin,
+                     long long* end);
 int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
                   const float* w, const float* scale, const float* shift, const float* residual,
                   float* y, void* workspace, size_t workspace_bytes);

@@ -26,6 +26,8 @@ PROTOTYPES = {
     "y3_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "y3_conv_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "y3_streamk_range": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(ctypes.c_longlong),
+                                 POINTER(ctypes.c_longlong)]),
     "y3_conv2d_fwd": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_size_t]),
     "y3_conv_wino_eligible": (c_int, [POINTER(ConvDesc)]),

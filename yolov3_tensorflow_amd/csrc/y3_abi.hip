@@ -40,6 +40,11 @@ extern "C" int y3_ctx_destroy(y3_ctx* ctx) {
 
 extern "C" size_t y3_conv_workspace_bytes(const y3_conv_desc* d) { return y3_conv_workspace_bytes_impl(d); }
 
+extern "C" int y3_streamk_range(int kind, int units, int ksteps, int workers, int group, int local_worker,
+                                long long* begin, long long* end) {
+    return y3_streamk_range_impl(kind, units, ksteps, workers, group, local_worker, begin, end);
+}
+
 extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
                              const float* w, const float* scale, const float* shift,
                              const float* residual, float* y, void* workspace, size_t workspace_bytes) {

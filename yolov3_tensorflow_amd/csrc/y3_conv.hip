@@ -374,6 +374,16 @@ int y3_conv_schedule_impl(const y3_conv_desc* d) {
     return use_streamk(a, d->k, true) ? 1 : 0;
 }
 
+int y3_streamk_range_impl(int kind, int units, int ksteps, int workers, int group, int local_worker, long long* begin,
+                          long long* end) {
+    Y3_CHECK_ARG(begin && end && units > 0 && ksteps > 0 && workers >= 8 && workers % 8 == 0 && group >= 0 && group < 8 &&
+                     local_worker >= 0 && local_worker < workers / 8 && (long long)units * ksteps < (1LL << 31),
+                 "y3_streamk_range: bad argument");
+    if (kind == 0) sk_range(units, ksteps, workers, group, local_worker, *begin, *end);
+    else y3_wino_range_impl(units, ksteps, workers, group, local_worker, begin, end);
+    return Y3_OK;
+}
+
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d) {
     if (!d || d->k != 3 || d->cout < 128 || d->c_up > 0) return 0;
     return SK_WORKSPACE_BYTES;

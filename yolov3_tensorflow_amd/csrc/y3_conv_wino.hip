@@ -629,6 +629,10 @@ __global__ void pack_weights_wino_kernel(const float* __restrict__ w_hwio, float
 
 }  // namespace
 
+void y3_wino_range_impl(int units, int ksteps, int workers, int group, int local_worker, long long* begin, long long* end) {
+    wk_range(units, ksteps, workers, group, local_worker, *begin, *end);
+}
+
 int y3_conv_wino_eligible_impl(const y3_conv_desc* d) {
     return d && d->k == 3 && d->stride == 1 && d->c_up == 0 && d->cin % 32 == 0 && d->cout % 32 == 0 &&
            d->n > 0 && d->h > 1 && d->w > 1;
