@@ -341,7 +341,9 @@ class Trainer(object):
         for t, g in zip(fm_ids, st['fm_grads']):
             grads[t] = g
             have.add(t)
-        sk_ws = _scratch(st, 'streamk', 512 * 2 * 128 * 128 * 4, dev)
+        # stream-K scratch of the data-gradient convs: the library's size for any 3x3 conv with Cout >= 128
+        sk_desc = _lib.ConvDesc(1, 8, 8, 128, 0, 128, 3, 1, 0)
+        sk_ws = _scratch(st, 'streamk', int(L.y3_conv_workspace_bytes(ctypes.byref(sk_desc))), dev)
 
         def accumulate_into(t, src, src_channels, offset, c):
             rows = src.numel() // src_channels
