@@ -4,6 +4,9 @@
     Y3_EXTRA_HIPCC_FLAGS=-DY3_WINO_CLOCK python -c "import __graft_entry__ as g; g.build()"
     python tools/wino_clock_probe.py
 
+Knock-out variants for the K-step breakdown of DESIGN.md 4.4: add -DY3_WINO_KO=1 (no loads in the K-loop), =2 (no
+input transform / LDS writes) or =3 (both); they compute garbage, only the cycle counts mean anything.
+
 The probe build makes workgroup 0 write its s_memtime deltas (whole kernel, K-loops only, K-steps inside those loops)
 over the first 24 bytes of the output tensor; hipEvents give the kernel's wall time, the ratio is the shader clock
 the kernel actually ran at.
@@ -40,7 +43,7 @@ def main():
         us = e0.elapsed_time(e1) / iters * 1e3
         c = y.view(-1)[:18].view(torch.int64).cpu().numpy()
         total, loop, steps = int(c[0]), int(c[1]), int(c[2])
-        print('H=%3d %4d->%4d: launch %.1f us (kernel + fix-up), workgroup 0: %d cycles -> >= %.2f GHz; '
+        print('H=%3d %4d->%4d: launch %.1f us, workgroup 0: %d cycles -> >= %.2f GHz; '
               'K-loops %d cycles / %d K-steps = %.0f cycles per K-step; outside the K-loops %d cycles'
               % (h, cin, cout, us, total, total / us / 1e3, loop, steps, loop / max(steps, 1), total - loop),
               flush=True)

@@ -405,12 +405,18 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 #endif
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
             // One basic block per K-step: loads(ks+1) | 64 MFMAs of K-step ks | input transform + LDS writes (ks+1)
-            // into the other LDS stage, all interleaved by the hints below so that only the barrier is serial:
-            //   group 0: 16 x (MFMA, activation load)        group 1: 8 x (MFMA, weight load), 8 MFMAs
-            //   group 2: 8 MFMAs, 8 x (MFMA, weight write)   group 3: 16 x (MFMA, activation write)
-            // (a VMEM issue costs the wave 20-70 cycles, an LDS write ~16, a 32x32x2 fp32 MFMA holds the matrix pipe
-            // for 64; the transform's 32 packed adds float between the MFMAs of groups 2-3).  The loaded registers
-            // are first read ~2000 cycles after the last load issues.
+            // into the other LDS stage, all interleaved by the hints below so that only the barrier is serial
+            // (position group g = 16 MFMAs; its fragments are read half a group ahead):
+            //   group 0: 16 x (MFMA, activation load), fragments of group 1 behind the last 8
+            //   group 1:  8 x (MFMA, weight load), 8 x (MFMA, fragment read of group 2)
+            //   group 2:  8 x (MFMA, LDS write), 8 x (MFMA, fragment read of group 3)
+            //   group 3:  8 x (MFMA, LDS write) | barrier | group-0 fragments of K-step ks+1, last 8 MFMAs
+            // hipcc fills the 16 write slots with the 8 transformed-activation writes (ds_write2st64_b64) first and the
+            // 8 weight writes after them; the transform's 32 packed adds float between the MFMAs of groups 1-2.
+            // (A VMEM issue costs the wave 20-70 cycles, an LDS write ~16, a 32x32x2 fp32 MFMA holds the matrix pipe
+            // for 64.)  The loaded registers are first read ~1500-2000 cycles after the last load issues.
+            // Y3_WINO_KO (bit 0: no loads, bit 1: no transform / LDS writes) are the knock-out builds of
+            // tools/wino_clock_probe.py; they compute garbage.
             const int cur = (ks - ks0) & 1;
             f32x4 a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
 #if !(defined(Y3_WINO_KO) && (Y3_WINO_KO & 1))
