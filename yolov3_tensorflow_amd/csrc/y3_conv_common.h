@@ -165,11 +165,6 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
 }
 
 // ---- stream-K schedule ---------------------------------------------------------------------------------------
-// Balanced contiguous partition of `items` over `workers`: worker w owns [begin(w), begin(w+1)).
-__device__ __host__ __forceinline__ long long sk_begin(long long items, int workers, int w) {
-    const long long q = items / workers, r = items % workers;
-    return (long long)w * q + (w < r ? w : r);
-}
 // The output tiles are first divided, whole, among the 8 XCD groups (group x = workgroups with blockIdx % 8 == x:
 // one L2; a group's tiles are neighbours, so they share A halos / B panels); inside a group its G = workers/8
 // workers own equal contiguous ranges of (tile, K-step) items.  A tile cut by a range boundary is finished INSIDE
@@ -181,6 +176,7 @@ __device__ __host__ __forceinline__ long long sk_begin(long long items, int work
 // than `workers` workgroups are resident.  (workers % 8 == 0, items of a group >= G.)
 // (32-bit arithmetic: the launchers keep tiles * S below 2^31; the 64-bit division expansion costs ~40 registers
 // where this runs, next to live accumulators)
+// balanced contiguous partition of `items` over `workers`: worker w owns [begin(w), begin(w+1))
 __device__ __host__ __forceinline__ int sk_begin32(int items, int workers, int w) {
     const int q = items / workers, r = items - q * workers;
     return w * q + (w < r ? w : r);

@@ -47,11 +47,6 @@ __device__ __host__ __forceinline__ long long wk_begin(long long items, int work
     const long long q = items / workers, r = items % workers;
     return (long long)w * q + (w < r ? w : r);
 }
-__device__ __host__ __forceinline__ int wk_owner(long long items, int workers, long long item) {
-    const long long q = items / workers, r = items % workers;
-    if (item < r * (q + 1)) return (int)(item / (q + 1));
-    return (int)(r + (item - r * (q + 1)) / q);
-}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
