@@ -1,31 +1,43 @@
 #!/usr/bin/env python
 """bench.py — the YOLOv3 hot path on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): Darknet-53 + 3-scale head forward (75 fused conv launches) on a
-batch of 32 synthetic 416x416 fp32 images per GPU, random weights, input resident in HBM.  One "step" = one
-forward over one batch.  Inference shards by image with no data-path collective: every rank
-runs an independent replica on its own stream; torch.distributed (RCCL) is used only for the two barriers
-and the max-over-ranks of the elapsed time.  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself under torch.distributed.run
+(one rank per GPU, rendezvous on 127.0.0.1).
 
-roofline: the dominant kernel is conv_mfma_f32_kernel<128,128,2,2,3,false,true> — the 3x3 implicit-GEMM MFMA
-conv in its stream-K schedule (32 of the 75 conv layers, ~84 % of the FLOPs, ~70 % of the time).  It is
-matrix-pipe bound in fp32: achieved = algorithmic FLOPs of those 32 launches / the sum of
-their durations, measured with hipEvents recorded on the launch stream inside the timed region (one event per
-layer boundary), peak = 157.3 TFLOP/s (fp32 MFMA).  In the default precision the dominant kernel is the Winograd
-kernel conv_wino_f32_kernel<2,2> and `achieved` counts the algorithmic (direct) FLOPs.
-fast_path: after the timed region the same steps are repeated with compute_dtype='f32_bf16x6' (fp32 tensors, every
-product rebuilt from six bf16 matrix-pipe products, fp32 accumulation) and reported next to the
-exact-fp32 `value` together with the max deviation between the two sets of feature maps.  It is never `value`.
-cpu_baseline: the CPU oracle's torch-fp32 restatement of the same graph ("port"; the literal TF-CPU
-reference cannot run here: no TensorFlow), same weights, a bounded sample, rank 0 and N=1 only.
+Workloads
+  c2 (default; BASELINE.json configs[1], the metric): Darknet-53 + 3-scale head forward (75 fused conv launches) on a
+     batch of 32 synthetic 416x416 fp32 images per GPU, random weights, input resident in HBM.  One "step" = one forward
+     over one batch.  Inference shards by image with no data-path collective: every rank runs an
+     independent replica on its own stream; torch.distributed (RCCL) carries only the two barriers and the max-over-ranks
+     of the elapsed time.
+  c4 (configs[3]): one TRAIN step — forward(is_training) -> compute_loss -> backward -> bucketed RCCL all-reduce of the
+     gradients (overlapped with backward) -> clip -> SGD update of the whole model — at 416x416, bs=64 per GPU.
+  c5 (configs[4]): the c2 forward with bf16 storage at 608x608, bs=16 per GPU.
+Prints ONE JSON line on rank 0.
+
+roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the
+Winograd F(2x2,3x3) kernel conv_wino_f32_kernel (the stride-1 3x3 convs: 32 launches, ~65 % of the step).
+`achieved` = the MFMA work those launches ISSUE (16/36 of the direct-convolution FLOPs) / the sum of their durations,
+measured with hipEvents recorded on the launch stream inside the timed region; `peak` = 157.3 TFLOP/s (fp32 MFMA);
+`frac` = achieved / peak.  `achieved_algorithmic` counts the direct-convolution FLOPs (it may exceed `peak`: Winograd
+needs 2.25x fewer multiplies).  `whole_forward_frac` = sum over the 75 layers of max(bytes / 8 TB/s, issued FLOPs /
+157.3 TF/s), divided by the measured ms_per_step.
+fast_path / direct_path: after the timed region the same steps are repeated with other compute_dtypes and reported next
+to `value` with the max deviation between the feature maps.  Never `value`.
+cpu_baseline: the CPU oracle's torch-fp32 restatement of the same graph ("port"; the literal TF-CPU reference cannot run
+here: no TensorFlow), same weights, a bounded sample, rank 0 and N=1 only.
+box_delta_vs_oracle: outside the timed region, the decoded boxes/confs/probs of one image of the bench batch against the
+CPU oracle on that image (BASELINE metric: "box delta vs ref").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,6 +51,8 @@ BATCH = 32
 SIZE = 416
 CLASS_NUM = 80
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip-level table
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_HBM_TBPS = 8.0
 ANCHORS = np.array([10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326],
                    np.float32).reshape(9, 2)
 
@@ -82,49 +96,87 @@ def random_init(seed):
         v.assign(t)
 
 
-def conv_flops(table, n, h, w):
-    """Algorithmic FLOPs per layer for one forward (2*k^2*Cin*Cout*Hout*Wout*N), following the graph."""
-    # spatial divisor of each layer's OUTPUT: replay the strides in creation order
-    flops = []
-    div = 1
-    sdiv_of = []
-    # body: divisors follow the stride-2 convs; head: 13-grid block, then 26, then 52 (SURVEY App. A)
+def layer_divisors(table):
+    """Spatial divisor of each layer's OUTPUT relative to the network input."""
     head_divs = [32] * 8 + [16] * 8 + [8] * 7
+    out, div = [], 1
     for i, (k, s, cin, cout, bn) in enumerate(table):
         if i < 52:
             div *= s
-            d = div
+            out.append(div)
         else:
-            d = head_divs[i - 52]
-        sdiv_of.append(d)
-        flops.append(2.0 * k * k * cin * cout * (h // d) * (w // d) * n)
-    return np.array(flops)
+            out.append(head_divs[i - 52])
+    return out
 
 
-def traffic_from_profile(name='r01_pmc_traffic.json'):
-    """HBM-side bytes per launch of the dominant kernel: rocprofv3 cannot run inside this process, so the
-    number comes from the committed PMC passes (profiles/r01_pmc_traffic*.json: FETCH_SIZE x2 + WRITE_SIZE,
-    collected over this same command); None if the file is absent."""
-    path = os.path.join(ROOT, 'profiles', name)
-    try:
-        with open(path) as f:
-            return int(json.load(f)['traffic_bytes_per_launch'])
-    except (OSError, KeyError, ValueError):
-        return None
+def conv_flops(table, n, h, w):
+    """Algorithmic (direct-convolution) FLOPs per layer for one forward: 2*k^2*Cin*Cout*Hout*Wout*N."""
+    return np.array([2.0 * k * k * cin * cout * (h // d) * (w // d) * n
+                     for (k, s, cin, cout, bn), d in zip(table, layer_divisors(table))])
+
+
+def conv_bytes(table, n, h, w, esize=4):
+    """Algorithmic HBM bytes per layer: input + packed kernel + output (+ the residual the 3x3 of a
+    res_block adds).  The upsampled/concatenated input of the two head convs is counted at its stored size."""
+    out = []
+    resid = set()
+    idx = 2
+    for blocks in (1, 2, 8, 8, 4):
+        for _ in range(blocks):
+            resid.add(idx + 1)
+            idx += 2
+        idx += 1
+    for i, ((k, s, cin, cout, bn), d) in enumerate(zip(table, layer_divisors(table))):
+        ho, wo = h // d, w // d
+        hi, wi = ho * s, wo * s
+        b = n * hi * wi * cin * esize + k * k * cin * cout * 4 + n * ho * wo * cout * esize
+        if i in resid:
+            b += n * ho * wo * cout * esize
+        out.append(float(b))
+    return np.array(out)
+
+
+def traffic_from_profile(names):
+    """HBM-side bytes per launch of the dominant kernel from a committed PMC pass (profiles/*.json: FETCH_SIZE x2 +
+    WRITE_SIZE collected with rocprofv3 --pmc over this same command; rocprofv3 cannot run inside this process, so
+    this is a static figure and is labelled as such).  Returns (bytes or None, source)."""
+    for name in names:
+        path = os.path.join(ROOT, 'profiles', name)
+        try:
+            with open(path) as f:
+                return int(json.load(f)['traffic_bytes_per_launch']), 'profiles/%s (static: separate rocprofv3 --pmc pass)' % name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(model_vars, budget_s=20.0):
-    """Time the oracle's torch-CPU fp32 forward on a bounded sample (checker code, never the product)."""
+    """Time the oracle's torch-CPU fp32 forward on a bounded sample (checker code, never the product): the bench batch
+    size (32) on all cores, and a 2-image batch on the best of {64,32,16} threads; the better rate is reported."""
     import torch
     from oracle import yolo_ref
     params = {v.op_name: v.numpy() for v in model_vars}
-    x = np.random.RandomState(123).rand(2, SIZE, SIZE, 3).astype(np.float32)
     ncpu = os.cpu_count() or 1
-    # oneDNN does not scale to every core of a big host on a 2-image batch: pick the best thread count
+    rng = np.random.RandomState(123)
+    results = []
+    t_start = time.time()
+    # (a) bs=32, every core
+    try:
+        x32 = rng.rand(BATCH, SIZE, SIZE, 3).astype(np.float32)
+        torch.set_num_threads(ncpu)
+        yolo_ref.forward(params, x32[:2])                 # warm-up (thread pool, oneDNN primitives)
+        t0 = time.time()
+        yolo_ref.forward(params, x32)
+        dt = time.time() - t0
+        results.append((BATCH / dt, ncpu, '1 x batch of %d images, %d threads' % (BATCH, ncpu)))
+    except Exception as e:    # a baseline must never cost the line
+        results.append((0.0, ncpu, 'bs=%d failed: %s' % (BATCH, e)))
+    # (b) bs=2, best thread count
+    x = x32[:2]
     best = None
     for nt in sorted({min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
         torch.set_num_threads(nt)
-        yolo_ref.forward(params, x[:1])                   # warm-up (thread pool, oneDNN primitives)
+        yolo_ref.forward(params, x[:1])
         t0 = time.time()
         yolo_ref.forward(params, x)
         dt = time.time() - t0
@@ -132,15 +184,38 @@ def cpu_baseline(model_vars, budget_s=20.0):
             best = (nt, dt)
     threads, per_batch = best
     torch.set_num_threads(threads)
-    reps = int(max(1, min(10, budget_s / max(per_batch, 1e-3))))
+    left = max(2.0, budget_s - (time.time() - t_start))
+    reps = int(max(1, min(10, left / max(per_batch, 1e-3))))
     t0 = time.time()
     for _ in range(reps):
         yolo_ref.forward(params, x)
     dt = time.time() - t0
-    return {"value": round(2 * reps / dt, 3), "unit": "images/s", "cores": int(threads), "kind": "port",
-            "sample": "oracle.yolo_ref.forward (torch-CPU fp32 restatement of the reference graph; "
-                      "TF-CPU itself is not installable here), %d x batch of 2 images %dx%d, same weights, "
-                      "best of {64,32,16} threads on a %d-core host" % (reps, SIZE, SIZE, ncpu)}
+    results.append((2 * reps / dt, threads, '%d x batch of 2 images, best of {64,32,16} threads = %d' % (reps, threads)))
+    rate, cores, what = max(results, key=lambda r: r[0])
+    return {"value": round(rate, 3), "unit": "images/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle.yolo_ref.forward (torch-CPU fp32 restatement of the reference graph; TF-CPU itself is "
+                      "not installable here), %dx%d, same weights, %d-core host; reported: %s; all samples: %s"
+                      % (SIZE, SIZE, ncpu, what, '; '.join('%.2f img/s (%s)' % (r[0], r[2]) for r in results))}
+
+
+def box_delta_vs_oracle(model, y3, x, fms, n_check=1):
+    """Decoded boxes / confs / probs of the first image(s) of the bench batch (taken from the batch's own feature
+    maps) against the CPU oracle's forward + predict on those images (checker; outside the timed region)."""
+    import torch
+    from oracle import yolo_ref
+    params = {v.op_name: v.numpy() for v in y3.global_variables(scope='yolov3')}
+    xs = x[:n_check].cpu().numpy()
+    boxes, confs, probs = model.predict([f[:n_check].contiguous() for f in fms])
+    ref = yolo_ref.forward(params, xs)
+    rb, rc, rp = yolo_ref.predict(ref, ANCHORS, [SIZE, SIZE], CLASS_NUM)
+    gb, gc, gp = boxes.cpu().numpy(), confs.cpu().numpy(), probs.cpu().numpy()
+    scale = np.maximum(np.abs(rb).max(axis=-1, keepdims=True), 1.0)
+    inside = (np.abs(rb).max(axis=-1) <= 2.0 * SIZE)
+    fm_err = max(float(np.abs(f[:n_check].cpu().numpy() - r).max()) for f, r in zip(fms, ref))
+    return {"images": int(n_check), "boxes_max_rel_to_box_scale": float((np.abs(gb - rb) / scale).max()),
+            "boxes_max_abs_px_within_2x_image": float(np.abs(gb - rb)[inside].max()) if inside.any() else None,
+            "confs_max_abs": float(np.abs(gc - rc).max()), "probs_max_abs": float(np.abs(gp - rp).max()),
+            "feature_maps_max_abs": fm_err, "tolerance": "1e-3 (north star)", "oracle": "oracle.yolo_ref (torch-CPU fp32)"}
 
 
 PRECISION_TEXT = {
@@ -179,39 +254,101 @@ def measure_other_precision(model, dtype, primary, y3, x, fms, args, barrier, di
             "max_abs_feature": float(max(a.abs().max().item() for a in ref))}
 
 
-def main():
+def synthetic_y_true(n, size, class_num, anchors, seed, device):
+    """Device-side stand-in for process_box output (utils/data_utils.py:51-115 layout): three object cells per image
+    and scale, class uniform, box = the cell centre with the anchor's size, mix weight 1."""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    out = []
+    for s, a0 in ((32, 6), (16, 3), (8, 0)):
+        gsz = size // s
+        y = torch.zeros((n, gsz, gsz, 3, 6 + class_num))
+        y[..., -1] = 1.0
+        cy = torch.randint(0, gsz, (n, 3), generator=g)
+        cx = torch.randint(0, gsz, (n, 3), generator=g)
+        ka = torch.randint(0, 3, (n, 3), generator=g)
+        cl = torch.randint(0, class_num, (n, 3), generator=g)
+        for i in range(n):
+            for j in range(3):
+                k = int(ka[i, j])
+                yy, xx = int(cy[i, j]), int(cx[i, j])
+                y[i, yy, xx, k, 0:4] = torch.tensor([(xx + 0.5) * s, (yy + 0.5) * s, float(anchors[a0 + k][0]),
+                                                     float(anchors[a0 + k][1])])
+                y[i, yy, xx, k, 4] = 1.0
+                y[i, yy, xx, k, 5 + int(cl[i, j])] = 1.0
+        out.append(y.to(device))
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: run N ranks of this script under torch.distributed.run."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % args.gpus,
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    print('bench.py: launching %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL (see the environment notes)
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['c2', 'c5'], default='c2',
-                    help="c2 (default, the BASELINE metric): fp32 416x416 bs=32; c5: bf16-storage 608x608 bs=16")
+    ap.add_argument('--workload', choices=['c2', 'c4', 'c5'], default='c2',
+                    help="c2 (default, the BASELINE metric): fp32 forward 416x416 bs=32; c4: train step 416x416 bs=64 "
+                         "per GPU, SGD, RCCL gradient all-reduce; c5: bf16-storage forward 608x608 bs=16")
     ap.add_argument('--precision', choices=['f32_wino', 'f32', 'f32_bf16x6', 'f32_bf16x3'], default='f32_wino',
-                    help="c2 only. f32_wino (default): exact fp32 MFMA arithmetic, Winograd F(2x2,3x3) kernel for the "
+                    help="c2/c4. f32_wino (default): exact fp32 MFMA arithmetic, Winograd F(2x2,3x3) kernel for the "
                          "stride-1 3x3 convs, direct kernel elsewhere; f32: direct kernels only; f32_bf16x6 / "
                          "f32_bf16x3: fp32 tensors, every product rebuilt from 6 / 3 bf16 plane products with fp32 "
                          "accumulation")
-    args = ap.parse_args()
+    ap.add_argument('--batch', type=int, default=None, help="per-GPU batch (default: the workload's BASELINE value)")
+    ap.add_argument('--head-only', action='store_true', help="c4: update only yolov3/yolov3_head (the reference's "
+                                                             "default update_part) instead of the whole model")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 5 if args.workload == 'c4' else 20
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == 'c4' else 5
+    return args
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args, argv))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if os.environ.get('Y3_BENCH_DRY_RUN') == '1':      # CPU-side check of the launch plumbing (tests)
+        print('bench.py: dry-run rank %d/%d (local %d), workload %s' % (rank, world, local_rank, args.workload), flush=True)
+        return
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running with WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
     global BATCH, SIZE
-    bf16 = args.workload == 'c5'
-    if bf16:
+    if args.workload == 'c5':
         BATCH, SIZE = 16, 608
+    elif args.workload == 'c4':
+        BATCH = 64
+    if args.batch:
+        BATCH = args.batch
 
     import torch
     import torch.distributed as dist
     import yolov3_tensorflow_amd as y3
-    from yolov3_tensorflow_amd import engine
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     torch.cuda.set_device(local_rank)
     y3.set_default_device('cuda:%d' % local_rank)
     distributed = world > 1 or 'RANK' in os.environ      # under torch.distributed.run even at N=1
@@ -225,13 +362,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if not distributed:
+            return seconds
+        t = torch.tensor([seconds], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.workload == 'c4':
+        out = run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks)
+    else:
+        out = run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# c4: the train step
+# ------------------------------------------------------------------------------------------------------------
+def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks):
+    from yolov3_tensorflow_amd import training, framework as fw
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    model = y3.yolov3(CLASS_NUM, ANCHORS, batch_norm_decay=0.99, weight_decay=5e-4)
+    model.compute_dtype = args.precision
+    x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda', generator=torch.Generator(device='cuda').manual_seed(100 + rank))
+    yt = synthetic_y_true(BATCH, SIZE, CLASS_NUM, ANCHORS, rank, 'cuda')
+    with y3.variable_scope('yolov3'):
+        model.forward(torch.zeros((1, 64, 64, 3), device='cuda'))
+        random_init(seed=1)                              # same weights on every rank
+        upd = None
+        if args.head_only:
+            upd = [v for v in y3.global_variables(scope='yolov3') if v.op_name.startswith('yolov3/yolov3_head')]
+        trainer = training.Trainer(model, config_optimizer('sgd', 1e-4), update_vars=upd,
+                                   process_group=dist.group.WORLD if distributed and world > 1 else None)
+        for _ in range(args.warmup):
+            loss = trainer.step(x, yt)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = trainer.step(x, yt)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        fw.check_context()
+    loss0 = float(loss[0])
+    assert np.isfinite(loss0), "non-finite loss"
+    if rank != 0:
+        return None
+    table = [(l['k'], l['stride'], l['cin'], l['cout'], l['bn']) for l in model._train['topo'].layers]
+    fwd_flops = float(conv_flops(table, BATCH, SIZE, SIZE).sum())
+    ms = elapsed / args.steps * 1e3
+    tflops = 3.0 * fwd_flops / (ms * 1e-3) / 1e12
+    grad_bytes = int(trainer.flat.numel() * 4)
+    return {
+        "metric": "images/sec, train step at 416x416 bs=%d per GPU (forward + loss + backward + gradient all-reduce + clip + SGD)" % BATCH,
+        "value": round(world * BATCH * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "precision": PRECISION_TEXT[args.precision],
+        "data": "synthetic",
+        "config": {"workload": "configs[3]: train step, synthetic COCO-80 batches, 416x416 bs=%d per GPU, SGD, %s, "
+                               "RCCL gradient all-reduce (bucketed, overlapped with backward)" %
+                               (BATCH, "update_part = yolov3_head" if args.head_only else "whole model"),
+                   "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE, "class_num": CLASS_NUM,
+                   "parallelism": "dp%d (one all-reduce of %d bytes of fp32 gradients per step, %d buckets)" %
+                                  (world, grad_bytes, len(trainer.exchange.edges))},
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": "whole train step, counted as 3x the forward's direct-convolution FLOPs (forward + data "
+                               "gradient + weight gradient); a Winograd forward issues fewer"},
+        "loss": round(loss0, 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------
+# c2 / c5: the forward
+# ------------------------------------------------------------------------------------------------------------
+def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks):
+    from yolov3_tensorflow_amd import engine, framework as fw
+    bf16 = args.workload == 'c5'
     model = y3.yolov3(CLASS_NUM, ANCHORS)
-    if bf16:
-        model.compute_dtype = 'bf16'
+    model.compute_dtype = 'bf16' if bf16 else args.precision
     split = (not bf16) and args.precision in ('f32_bf16x6', 'f32_bf16x3')
     wino = (not bf16) and args.precision == 'f32_wino'
-    if not bf16:
-        model.compute_dtype = args.precision
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda',
                    generator=torch.Generator(device='cuda').manual_seed(100 + rank))
     with y3.variable_scope('yolov3'):
@@ -258,6 +472,7 @@ def main():
             fms = model.forward(x, False)
         barrier()
         elapsed = time.perf_counter() - t0
+        fw.check_context()      # a stream-K hand-off that timed out inside the timed region would raise here
         layer_ms, table, main_ms, is_sk = model.read_layer_ms(with_main=True, shape=(BATCH, SIZE, SIZE))
         model.set_layer_profiling(False)
         # p50 of single-step latency (separate short loop; each step synchronised)
@@ -270,8 +485,7 @@ def main():
             lat.append(time.perf_counter() - t1)
     assert all(torch.isfinite(f).all().item() for f in fms), "non-finite feature maps"
 
-    # Secondary measurement (c2, default precision only; outside the timed region above and never `value`): the same
-    # workload with the products on the bf16 matrix pipe, and its deviation from the exact-fp32 feature maps.
+    # Secondary measurements (c2, default precision only; outside the timed region above and never `value`)
     fast, direct = None, None
     if not bf16 and not split:
         primary = model.compute_dtype
@@ -287,93 +501,94 @@ def main():
                 fast = res
             else:
                 direct = res
+    elapsed = max_over_ranks(elapsed)
+    if rank != 0:
+        return None
 
-    if distributed:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * BATCH * args.steps / elapsed
-        flops = conv_flops(table, BATCH, SIZE, SIZE)
-        is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
-        sk_all = np.array(is_sk, bool)
-        if wino:   # dominant family: the Winograd kernel (every stride-1 3x3 conv but the stem)
-            is_sk = np.array([engine.wino_eligible(k, s, cin, cout)
-                              for (k, s, cin, cout, bn) in table])
-            main_ms = np.where(is_sk, layer_ms, main_ms)
-        if bf16:   # dominant family: the 3x3 convs on 128x128 tiles (conv_mfma_bf16_kernel<128,128,2,2,3,false>)
-            is_sk = np.array([k == 3 and cin != 3 and cout > 64 for (k, s, cin, cout, bn) in table])
-        dom_ms = float(main_ms[is_sk].sum())          # the stream-K kernel alone (fix-up excluded)
-        dom_flops = float(flops[is_sk].sum())
-        n_dom = int(is_sk.sum())
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        # split precisions: fp32-equivalent peak = dense bf16 MFMA peak / products per fp32 multiply-add
-        peak = 2500.0 if bf16 else {'f32': PEAK_FP32_MFMA_TFLOPS, 'f32_wino': PEAK_FP32_MFMA_TFLOPS,
-                                    'f32_bf16x6': 2500.0 / 6,
-                                    'f32_bf16x3': 2500.0 / 3}[args.precision]
-        whole = float(flops.sum()) / (float(layer_ms.sum()) * 1e-3) / 1e12
-        out = {
-            "metric": ("images/sec at 608x608 bs=16 bf16 (Darknet-53 + 3-scale head forward)" if bf16 else
-                       "images/sec at 416x416 bs=32 (Darknet-53 + 3-scale head forward)"),
-            "value": round(value, 2),
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "ms_per_image_p50": round(float(np.median(lat)) * 1e3 / BATCH, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "f32",
-            "precision": ("bf16 storage, fp32 accumulate" if bf16 else PRECISION_TEXT[args.precision]),
-            "data": "synthetic",
-            "config": {"workload": ("configs[4]: Darknet-53 + 3-scale head forward, random weights, 608x608 bs=16 "
-                                    "per GPU, bf16 storage / fp32 accumulate, input resident in HBM" if bf16 else
-                                    "configs[1]: Darknet-53 + 3-scale head forward, random weights, "
-                                    "416x416 bs=32 fp32 per GPU, input resident in HBM"),
-                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE,
-                       "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": (None if (bf16 or split) else
-                                     traffic_from_profile('r01_pmc_traffic_wino.json' if wino else 'r01_pmc_traffic.json')),
-                         "kernel": ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; "
-                                    "staging-bound, see DESIGN.md)" if bf16 else
-                                    "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM "
-                                    "conv on the bf16 matrix pipe, stream-K schedule; peak = 2500/%d fp32-equivalent)"
-                                    % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3)) if split else
-                                    "conv_wino_f32_kernel<2,2> (Winograd F(2x2,3x3) conv, fp32 MFMA; `achieved` counts the "
-                                    "ALGORITHMIC (direct-convolution) FLOPs, so frac can exceed 1: the kernel issues "
-                                    "1/2.25 of them as MFMA work, see mfma_work_frac)" if wino else
-                                    "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, "
-                                    "stream-K schedule)"),
-                         "launches_per_step": n_dom,
-                         "avg_launch_ms": round(dom_ms / n_dom, 4),
-                         "algorithmic_gflop_per_launch": round(dom_flops / n_dom / 1e9, 3),
-                         "fixup_ms_per_step": round(float((layer_ms - main_ms)[sk_all].sum()), 4),
-                         "all_3x3_tflops": round(float(flops[is3].sum()) / (float(layer_ms[is3].sum()) * 1e-3) / 1e12, 2),
-                         "whole_forward_tflops": round(whole, 2),
-                         "sum_layer_ms": round(float(layer_ms.sum()), 4)},
-        }
-        if bf16:
-            # algorithmic HBM traffic of the whole bf16 forward: 6.565 GB per bs=16 batch at 608
-            out["roofline"]["whole_forward_hbm_tbps"] = round(6.565e9 / (ms_per_step * 1e-3) / 1e12, 3)
-        if wino:
-            out["roofline"]["mfma_work_tflops"] = round(achieved / 2.25, 2)
-            out["roofline"]["mfma_work_frac"] = round(achieved / 2.25 / peak, 4)
-        if direct is not None:
-            out["direct_path"] = direct
-        if fast is not None:
-            out["fast_path"] = fast
-        if world == 1 and not args.no_cpu_baseline and not bf16:
-            out["cpu_baseline"] = cpu_baseline(y3.global_variables(scope='yolov3'))
-        print(json.dumps(out), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH * args.steps / elapsed
+    flops = conv_flops(table, BATCH, SIZE, SIZE)
+    nbytes = conv_bytes(table, BATCH, SIZE, SIZE, 2 if bf16 else 4)
+    is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
+    is_wino = np.array([wino and engine.wino_eligible(k, s, cin, cout) for (k, s, cin, cout, bn) in table])
+    issued = np.where(is_wino, flops * (16.0 / 36.0), flops)       # MFMA work the kernels actually issue
+    if wino:        # dominant family: the Winograd kernel (every stride-1 3x3 conv but the stem)
+        dom = is_wino
+    elif bf16:      # the 3x3 convs on 128x128 tiles (conv_mfma_bf16_kernel<128,128,2,2,3,false>)
+        dom = np.array([k == 3 and cin != 3 and cout > 64 for (k, s, cin, cout, bn) in table])
+    else:           # the stream-K 3x3 kernel
+        dom = np.array(is_sk, bool)
+    dom_ms = float(layer_ms[dom].sum())
+    n_dom = int(dom.sum())
+    achieved = float(issued[dom].sum()) / (dom_ms * 1e-3) / 1e12
+    achieved_alg = float(flops[dom].sum()) / (dom_ms * 1e-3) / 1e12
+    # split precisions: fp32-equivalent peak = dense bf16 MFMA peak / products per fp32 multiply-add
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else {'f32': PEAK_FP32_MFMA_TFLOPS, 'f32_wino': PEAK_FP32_MFMA_TFLOPS,
+                                                'f32_bf16x6': PEAK_BF16_MFMA_TFLOPS / 6,
+                                                'f32_bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
+    bound_ms = np.maximum(nbytes / (PEAK_HBM_TBPS * 1e12), issued / (peak * 1e12)) * 1e3      # per layer
+    traffic, traffic_src = (None, None) if (bf16 or split) else traffic_from_profile(
+        ['r02_pmc_traffic_wino.json', 'r01_pmc_traffic_wino.json'] if wino else ['r02_pmc_traffic.json', 'r01_pmc_traffic.json'])
+    kernel = ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; staging-bound, see "
+              "DESIGN.md)" if bf16 else
+              "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
+              "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
+              if split else
+              "conv_wino_f32_kernel (Winograd F(2x2,3x3) conv, fp32 MFMA): `achieved` = MFMA work ISSUED (16/36 of the "
+              "direct-convolution FLOPs) per second; `achieved_algorithmic` counts the direct-convolution FLOPs" if wino else
+              "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, stream-K schedule)")
+    out = {
+        "metric": ("images/sec at 608x608 bs=16 bf16 (Darknet-53 + 3-scale head forward)" if bf16 else
+                   "images/sec at 416x416 bs=32 (Darknet-53 + 3-scale head forward)"),
+        "value": round(value, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "ms_per_image_p50": round(float(np.median(lat)) * 1e3 / BATCH, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16" if bf16 else "f32",
+        "precision": ("bf16 storage, fp32 accumulate" if bf16 else PRECISION_TEXT[args.precision]),
+        "data": "synthetic",
+        "config": {"workload": ("configs[4]: Darknet-53 + 3-scale head forward, random weights, 608x608 bs=16 "
+                                "per GPU, bf16 storage / fp32 accumulate, input resident in HBM" if bf16 else
+                                "configs[1]: Darknet-53 + 3-scale head forward, random weights, "
+                                "416x416 bs=32 fp32 per GPU, input resident in HBM"),
+                   "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE,
+                   "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 2),
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kernel,
+                     "launches_per_step": n_dom,
+                     "avg_launch_ms": round(dom_ms / n_dom, 4),
+                     "issued_gflop_per_launch": round(float(issued[dom].sum()) / n_dom / 1e9, 3),
+                     "algorithmic_gflop_per_launch": round(float(flops[dom].sum()) / n_dom / 1e9, 3),
+                     "algorithmic_mb_per_launch": round(float(nbytes[dom].sum()) / n_dom / 1e6, 2),
+                     "achieved_algorithmic": round(achieved_alg, 2),
+                     "all_3x3_tflops": round(float(flops[is3].sum()) / (float(layer_ms[is3].sum()) * 1e-3) / 1e12, 2),
+                     "whole_forward_tflops": round(float(flops.sum()) / (ms_per_step * 1e-3) / 1e12, 2),
+                     "whole_forward_issued_tflops": round(float(issued.sum()) / (ms_per_step * 1e-3) / 1e12, 2),
+                     "whole_forward_bound_ms": round(float(bound_ms.sum()), 4),
+                     "whole_forward_frac": round(float(bound_ms.sum()) / ms_per_step, 4),
+                     "whole_forward_hbm_tbps": round(float(nbytes.sum()) / (ms_per_step * 1e-3) / 1e12, 3),
+                     "sum_layer_ms": round(float(layer_ms.sum()), 4)},
+    }
+    if direct is not None:
+        out["direct_path"] = direct
+    if fast is not None:
+        out["fast_path"] = fast
+    if not bf16:
+        try:
+            out["box_delta_vs_oracle"] = box_delta_vs_oracle(model, y3, x, fms)
+        except Exception as e:      # a checker must never cost the line
+            out["box_delta_vs_oracle"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world == 1 and not args.no_cpu_baseline and not bf16:
+        out["cpu_baseline"] = cpu_baseline(y3.global_variables(scope='yolov3'))
+    return out
 
 
 if __name__ == '__main__':

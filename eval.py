@@ -6,9 +6,9 @@ predictions to the host and feeds them back for a second `sess.run` of the NMS o
 images goes forward -> decode -> per-class NMS on the device in one launch set (`yolov3.detect` building blocks),
 the loss of the batch is computed on the device from `process_box_batch` targets, and only the surviving detections
 cross to the host.  Weights: a darknet `.weights` file (`--restore_path`; the reference restores a TF checkpoint
-converted from the same file).  Images are read with PIL; `--letterbox_resize true` uses the cv2-INTER_NEAREST-exact
-letterbox of utils.data_utils, otherwise PIL bilinear (cv2.INTER_LINEAR in the reference: same geometry, pixel values
-may differ in the last bit).
+converted from the same file) or a native `.npz` checkpoint written by train.py / convert_weight.py.  Images are read
+with PIL and resized like the reference's validation path (cv2.INTER_LINEAR, plain or letterboxed) by the OpenCV-free
+restatement in utils.data_utils.
 """
 from __future__ import division, print_function
 
@@ -24,7 +24,7 @@ def build_parser():
     parser.add_argument("--eval_file", type=str, default="./data/my_data/val.txt",
                         help="The path of the validation or test txt file.")
     parser.add_argument("--restore_path", type=str, default="./data/darknet_weights/yolov3.weights",
-                        help="The path of the darknet weights to restore.")
+                        help="The path of the darknet .weights file (or native .npz checkpoint) to restore.")
     parser.add_argument("--anchor_path", type=str, default="./data/yolo_anchors.txt",
                         help="The path of the anchor txt file.")
     parser.add_argument("--class_name_path", type=str, default="./data/coco.names",
@@ -50,21 +50,13 @@ def build_parser():
 
 
 def load_image(path, line_boxes, img_size, letterbox):
-    """PIL read + resize to img_size [w, h]; returns (float32 RGB image in [0,1], boxes mapped to the new frame)."""
+    """PIL read + the reference's non-train preprocessing (utils/data_utils.py:163-173): resize_with_bbox(interp=1 =
+    cv2.INTER_LINEAR, restated in utils.data_utils.resize_bilinear_cv2), plain or letterboxed, to img_size [w, h];
+    returns (float32 RGB image in [0,1], boxes mapped to the new frame)."""
     from PIL import Image
-    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize
+    from yolov3_tensorflow_amd.utils.data_utils import resize_with_bbox
     img = np.asarray(Image.open(path).convert('RGB'))
-    h0, w0 = img.shape[:2]
-    boxes = np.array(line_boxes, np.float32).reshape(-1, 4)
-    if letterbox:
-        img, ratio, dw, dh = letterbox_resize(img, img_size[0], img_size[1])
-        boxes = boxes * ratio
-        boxes[:, [0, 2]] += dw
-        boxes[:, [1, 3]] += dh
-    else:
-        img = np.asarray(Image.fromarray(img).resize((img_size[0], img_size[1]), Image.BILINEAR))
-        boxes[:, [0, 2]] *= img_size[0] / float(w0)
-        boxes[:, [1, 3]] *= img_size[1] / float(h0)
+    img, boxes = resize_with_bbox(img, line_boxes, img_size[0], img_size[1], interp=1, letterbox=letterbox)
     return np.asarray(img, np.float32) / 255., boxes
 
 
@@ -76,7 +68,7 @@ def main(argv=None):
     from yolov3_tensorflow_amd.utils.eval_utils import get_preds_batch, voc_eval, parse_gt_rec
     from yolov3_tensorflow_amd.utils import eval_utils
     from yolov3_tensorflow_amd.utils.misc_utils import (parse_anchors, read_class_names, AverageMeter, load_weights,
-                                                        run_ops)
+                                                        run_ops, Saver)
     from yolov3_tensorflow_amd.utils.nms_utils import gpu_nms_batched
 
     args.anchors = parse_anchors(args.anchor_path)
@@ -89,7 +81,10 @@ def main(argv=None):
     yolo_model.compute_dtype = args.compute_dtype
     with y3.variable_scope('yolov3'):
         yolo_model.forward(torch.zeros((1, 64, 64, 3)), False)            # create the variables
-        run_ops(load_weights(y3.global_variables(scope='yolov3'), args.restore_path))
+        if args.restore_path.endswith('.npz'):       # native checkpoint (train.py best_model_*.npz, convert_weight.py)
+            Saver(y3.global_variables(scope='yolov3')).restore(args.restore_path)
+        else:
+            run_ops(load_weights(y3.global_variables(scope='yolov3'), args.restore_path))
 
     print('\n----------- start to eval -----------\n')
     meters = [AverageMeter() for _ in range(5)]      # total, xy, wh, conf, class

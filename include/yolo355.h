@@ -35,7 +35,7 @@ extern "C" {
 #define Y3_EHIP (-2)     /* a HIP runtime call failed */
 #define Y3_ESTATE (-3)   /* object used before it was fully configured */
 
-#define Y3_ABI_VERSION 1
+#define Y3_ABI_VERSION 2
 
 typedef struct y3_ctx y3_ctx; /* one per (device, stream) */
 typedef struct y3_net y3_net; /* the 75-conv YOLOv3 graph bound to caller-owned parameters */
@@ -44,9 +44,25 @@ typedef struct y3_net y3_net; /* the 75-conv YOLOv3 graph bound to caller-owned 
 const char* y3_last_error(void);
 int y3_abi_version(void);
 
-/* stream: a hipStream_t (0 = the null stream).  The library never creates streams. */
+/* stream: a hipStream_t (0 = the null stream).  The library never creates streams.  A context owns one 64-byte block of
+ * pinned, device-visible host memory: its error word (below). */
 int y3_ctx_create(int device, void* stream, y3_ctx** out);
 int y3_ctx_destroy(y3_ctx* ctx);
+/* Device-side failures are LOUD.  The stream-K conv schedules (y3_conv2d_fwd*, y3_conv2d_dgrad*, y3_net_forward) finish
+ * tiles that were cut between two persistent workgroups inside the kernel: the consumer workgroup polls a flag the
+ * producer raises.  The poll is bounded so that a launch can never hang; if it expires the tile's sum
+ * is incomplete, and the kernel ORs a code into the context's error word.  From then on every conv / net entry point
+ * called on that context returns Y3_EHIP ("a stream-K hand-off timed out ...") WITHOUT launching, until
+ * y3_ctx_check — which synchronises the stream, reports the condition once more and clears it — has been called.
+ * A caller that wants the guarantee for a specific batch calls y3_ctx_check after it (the Python mirror does so
+ * wherever it synchronises anyway: NMS read-back, train.py's loss read-out, bench.py after the timed region).
+ * Assumption the protocol rests on, stated here because HIP does not promise it: workgroups of one launch are
+ * dispatched in increasing blockIdx order.  A consumer only ever waits for workgroups with SMALLER ids of its own
+ * XCD group, so under that order it cannot wait for a workgroup that has not been dispatched; if a future dispatcher
+ * broke the order, the bounded poll would expire and the failure would surface here, never as a silent wrong tensor.
+ * Test hook: with Y3_STREAMK_FAULT=1 in the environment producers never raise their flag and consumers give up after
+ * 2^10 polls (tests/test_conv_gpu.py::test_streamk_timeout_is_loud). */
+int y3_ctx_check(y3_ctx* ctx);
 
 /* ---- parameter preparation (one-off, utils/misc_utils.py:114-124 produces HWIO) ---------------
  * w_hwio [k][k][cin][cout]  ->  w_packed [k*k][cout][cin]   (cin contiguous: 16-B loads along K).
@@ -83,7 +99,8 @@ typedef struct y3_conv_desc {
 
 /* Scratch the stream-K schedule of this conv may use (0 if it never does): one accumulator slot per persistent
  * workgroup + one flag word each; uninitialised memory is fine (the library zeroes the words it polls ahead of every
- * launch) and it must not be shared by launches on different streams.  Passing workspace = NULL to
+ * launch; y3_net_forward gives each of its layers its own flag words and zeroes them all with one memset per forward)
+ * and it must not be shared by launches on different streams.  Passing workspace = NULL to
  * y3_conv2d_fwd is allowed and selects the data-parallel schedule; results of the two schedules differ in
  * the last bits (the K sum of a split tile is associated differently), each is deterministic. */
 size_t y3_conv_workspace_bytes(const y3_conv_desc* d);
@@ -203,9 +220,7 @@ int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* works
  * 256) records one event per layer boundary; y3_net_get_layer_ms synchronises on the last event, writes
  * the per-layer elapsed ms averaged over the forwards recorded since the previous call, and resets. */
 int y3_net_set_profiling(y3_net* net, int enabled);
-int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int count);
-/* ms_tail (nullable): the part of ms[i] spent after the layer's kernel (kept for ABI stability: every layer is one
- * kernel now, so it is ~0 for stream-K layers and equals ms[i] for the others, whose mark precedes the launch). */
+int y3_net_get_layer_ms(y3_net* net, float* ms, int count);
 int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w);
 
 /* graph topology of y3_net (tensor ids: 0 = network input, 1.. = conv outputs in creation order; -1 = none) */

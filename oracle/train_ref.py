@@ -23,8 +23,15 @@ LEAKY = 0.1
 class TrainGraph(object):
     """Holds the parameters as torch leaves and replays the reference graph in training mode."""
 
-    def __init__(self, params, class_num=80, dtype=torch.float64, prefix='yolov3'):
+    def __init__(self, params, class_num=80, dtype=torch.float64, prefix='yolov3', masks=None):
         self.class_num, self.dtype, self.prefix = class_num, dtype, prefix
+        # masks: optional {conv name: bool NCHW tensor} = the LeakyReLU branch (pre-activation > 0) to take per element
+        # instead of this graph's own sign test.  LeakyReLU makes the gradient a discontinuous function of the forward
+        # values: an element whose pre-activation changes sign between two implementations (|u| ~ 1e-6 in fp32) flips a
+        # 1 / 0.1 factor, and a fraction p of flipped elements moves a gradient tensor by ~sqrt(p) relative — measured
+        # here: the CPU fp32 graph is 4e-2 (worst tensor) from the fp64 one with its own branches, 2e-5 with a smooth
+        # activation.  Handing both sides the SAME branches compares the same piecewise-linear function.
+        self.masks = masks
         self.p = OrderedDict()
         for k, v in params.items():
             t = torch.tensor(np.asarray(v), dtype=dtype)
@@ -55,7 +62,8 @@ class TrainGraph(object):
         else:
             z = z + self.p[name + '/biases'].view(1, -1, 1, 1)
         if act:
-            z = torch.where(z > 0, z, LEAKY * z)
+            pos = (z > 0) if self.masks is None or name not in self.masks else self.masks[name]
+            z = torch.where(pos, z, LEAKY * z)
         self.trace[name] = z
         return z
 
@@ -206,9 +214,10 @@ def apply_update(kind, w, g, slots, lr, step, momentum=0.9, decay=0.9, beta1=0.9
 
 def train_step(params, x, y_trues, anchors, class_num=80, optimizer='sgd', lr=1e-4, weight_decay=5e-4,
                bn_decay=0.99, clip=100.0, update_scopes=None, use_label_smooth=False, use_focal_loss=False,
-               dtype=torch.float64, slots=None, step=1):
-    """One reference train step.  Returns dict(loss=[5 floats], l2, grads, new_params, batch_stats)."""
-    g = TrainGraph(params, class_num, dtype)
+               dtype=torch.float64, slots=None, step=1, masks=None):
+    """One reference train step.  Returns dict(loss=[5 floats], l2, grads, new_params, batch_stats).
+    masks: see TrainGraph (LeakyReLU branches imposed from outside)."""
+    g = TrainGraph(params, class_num, dtype, masks=masks)
     fms = g.forward(x)
     loss = g.compute_loss(fms, y_trues, anchors, use_label_smooth, use_focal_loss)
     l2 = g.l2_loss(weight_decay)
@@ -232,6 +241,16 @@ def train_step(params, x, y_trues, anchors, class_num=80, optimizer='sgd', lr=1e
     return dict(loss=[float(v) for v in loss], l2=float(l2), grads=out_grads,
                 new_params=OrderedDict((k, v.numpy()) for k, v in new_params.items()),
                 feature_maps=[f.detach().numpy() for f in fms], graph=g, slots=slots)
+
+
+def reapply(params, ref, optimizer, lr, step=1):
+    """new_params of `ref` (a train_step result) under another optimizer, from the same clipped gradients (first step:
+    empty slots)."""
+    new = OrderedDict(ref['new_params'])
+    for k, g in ref['grads'].items():
+        w = torch.tensor(np.asarray(params[k]), dtype=torch.float64)
+        new[k] = apply_update(optimizer, w, torch.tensor(g, dtype=torch.float64), {}, lr, step).numpy()
+    return new
 
 
 def process_box(boxes, labels, img_size, class_num, anchors):

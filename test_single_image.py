@@ -36,7 +36,7 @@ def parse_args(argv):
 
 def to_network_frame(image, size, letterbox):
     """uint8 RGB image -> ([1,h,w,3] float32 in [0,1], function mapping network-frame boxes back to the image)."""
-    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize
+    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize, resize_bilinear_cv2
     h0, w0 = image.shape[:2]
     if letterbox:
         resized, ratio, dw, dh = letterbox_resize(image, size[0], size[1])
@@ -46,10 +46,8 @@ def to_network_frame(image, size, letterbox):
             boxes[:, [1, 3]] = (boxes[:, [1, 3]] - dh) / ratio
             return boxes
     else:
-        # plain resize with cv2's nearest-neighbour sampling rule: src = min(floor(dst * src/dst_size), src - 1)
-        cols = np.minimum(np.floor(np.arange(size[0]) * (w0 / size[0])).astype(int), w0 - 1)
-        rows = np.minimum(np.floor(np.arange(size[1]) * (h0 / size[1])).astype(int), h0 - 1)
-        resized = image[rows][:, cols]
+        # cv2.resize(img_ori, tuple(new_size)): OpenCV's default interpolation, INTER_LINEAR (test_single_image.py:43)
+        resized = resize_bilinear_cv2(image, size[0], size[1])
 
         def back(boxes):
             boxes[:, [0, 2]] *= w0 / float(size[0])

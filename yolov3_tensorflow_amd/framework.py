@@ -201,6 +201,13 @@ def context(device=None):
     return ctx
 
 
+def check_context(device=None):
+    """y3_ctx_check for the current (device, stream): synchronises the stream and raises Y3Error if a kernel of an
+    earlier launch reported a failure (a stream-K hand-off that timed out: include/yolo355.h).  Cheap to call wherever
+    the host synchronises anyway."""
+    _lib.check(_lib.lib().y3_ctx_check(context(device)))
+
+
 def ptr(t):
     """Raw device pointer of a contiguous fp32/int32 tensor (None -> NULL)."""
     if t is None:

@@ -177,22 +177,20 @@ class yolov3(object):
 
     def read_layer_ms(self, device=None, with_main=False, shape=None):
         """Per-layer ms averaged over the forwards recorded since the last read (synchronises), plus the
-        layer table [(k, stride, cin, cout, has_bn)].  with_main=True also returns, per layer, the duration
-        of the layer's kernel alone (y3_net_get_layer_ms's ms_tail; the same as the total now that a stream-K
-        layer is one kernel) and the stream-K flags; needs shape=(n, h, w)."""
+        layer table [(k, stride, cin, cout, has_bn)].  with_main=True also returns the same per-layer times once
+        more (every layer is ONE kernel; kept for callers written when a stream-K layer had a fix-up launch) and the
+        stream-K flags; needs shape=(n, h, w)."""
         ent = self._get_net(device if device is not None else fw.default_device())
         nl = len(ent['table'])
         L = _lib.lib()
         buf = (ctypes.c_float * nl)()
-        tail = (ctypes.c_float * nl)()
-        _lib.check(L.y3_net_get_layer_ms(ent['handle'], buf, tail, nl))
+        _lib.check(L.y3_net_get_layer_ms(ent['handle'], buf, nl))
         ms = np.array(buf[:], dtype=np.float64)
         if not with_main:
             return ms, ent['table']
         n, h, w = shape
         sk = np.array([L.y3_net_layer_is_streamk(ent['handle'], i, n, h, w) for i in range(nl)], bool)
-        main = np.where(sk, ms - np.array(tail[:], dtype=np.float64), ms)
-        return ms, ent['table'], main, sk
+        return ms, ent['table'], ms.copy(), sk
 
     def layer_times_ms(self, inputs, iters=5):
         """Per-layer hipEvent timing of the fused plan (for profiles/ and DESIGN.md tables)."""

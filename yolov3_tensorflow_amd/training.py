@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import distributed
 from . import engine
 from . import framework as fw
 
@@ -276,20 +277,49 @@ def box_iou(pred_boxes, valid_true_boxes):
 # --------------------------------------------------------------------------------------------------------
 # backward + update
 # --------------------------------------------------------------------------------------------------------
+def gradient_layout(layer_vars, trainable=lambda v: v.trainable):
+    """Layout of the flat gradient buffer: the variables in the order backward PRODUCES their gradients (last layer
+    first; inside a layer gamma, beta / bias, then the kernel), every view 16-byte aligned.  Pure host arithmetic over
+    objects with .op_name / .shape (no device needed).
+    Returns (order, offsets {op_name: element offset}, layer_ends {layer index: element offset just after that layer's
+    gradients} (layers with a trainable variable only; increasing as the layer index decreases), total elements)."""
+    order, offs, ends, total = [], {}, {}, 0
+    layer_vars = list(layer_vars)
+    for li in range(len(layer_vars) - 1, -1, -1):
+        wvar, bnv, bias = layer_vars[li]
+        vs = (list(bnv[:2]) if bnv is not None else [bias]) + [wvar]
+        vs = [v for v in vs if trainable(v)]
+        for v in vs:
+            numel = 1
+            for d in v.shape:
+                numel *= int(d)
+            offs[v.op_name] = total
+            total += (numel + 3) // 4 * 4
+            order.append(v)
+        if vs:
+            ends[li] = total
+    return order, offs, ends, total
+
+
 class Trainer(object):
     """One object = the train op of train.py:105-115: gradients of loss[0] + l2_loss w.r.t. update_vars,
     per-tensor clip_by_norm(100), optimizer.apply_gradients; with torch.distributed initialised, gradients
-    are summed over ranks (RCCL all-reduce of ONE flat buffer) and averaged before clipping."""
+    are summed over ranks — RCCL all-reduce of the flat gradient buffer in buckets, issued in the order backward
+    produces them and overlapped with the rest of backward (distributed.GradientExchange) — and averaged (the 1/world
+    factor is folded into the clip/update kernel) before clipping."""
 
     def __init__(self, model, optimizer, update_vars=None, clip_norm=CLIP_NORM, process_group=None,
-                 global_step=0.0):
+                 global_step=0.0, bucket_bytes=distributed.DEFAULT_BUCKET_BYTES):
         self.model, self.opt = model, optimizer
         self.update_names = None if update_vars is None else set(v.op_name for v in update_vars)
         self.clip_norm = float(clip_norm)
         self.pg = process_group
+        self.bucket_bytes = int(bucket_bytes)
         self.global_step = float(global_step)
         self.flat = None
         self.views = None
+        self.exchange = None
+        self.capture = None      # test hook: a list that backward() fills with each BN layer's (z, stats)
 
     def _trainable(self, var):
         return var.trainable and (self.update_names is None or var.op_name in self.update_names)
@@ -297,22 +327,15 @@ class Trainer(object):
     def _alloc_grads(self, layer_vars, dev):
         if self.flat is not None:
             return
-        order = []
-        for wvar, bnv, bias in layer_vars:
-            order.append(wvar)
-            if bnv is not None:
-                order.extend(bnv[:2])
-            else:
-                order.append(bias)
-        order = [v for v in order if self._trainable(v)]
-        offs, total = {}, 0
-        for v in order:
-            offs[v.op_name] = total
-            total += (v.tensor.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        order, offs, ends, total = gradient_layout(layer_vars, self._trainable)
         self.flat = torch.zeros(max(total, 4), dtype=torch.float32, device=dev)
         self.views = {v.op_name: self.flat[offs[v.op_name]:offs[v.op_name] + v.tensor.numel()].view(v.tensor.shape)
                       for v in order}
         self.order = order
+        self.offsets = offs
+        self.layer_ends = ends
+        self.exchange = distributed.GradientExchange(self.flat, sorted(ends.values()) or [total], self.pg,
+                                                     self.bucket_bytes)
 
     def backward(self):
         model = self.model
@@ -334,6 +357,8 @@ class Trainer(object):
                 break
         if first is None:
             return
+        self.exchange.begin()
+        cap = self.capture
         needs = lambda t: t > 0 and (t - 1) >= first         # tensor t is produced by layer t-1
         grads, have = {}, set()
         fm_ids = sorted([t for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0],
@@ -363,6 +388,8 @@ class Trainer(object):
             dy = grads[dst]
             cout = l['cout']
             xin = rec['xin']
+            if cap is not None:      # test hook: the tensors that fix this layer's LeakyReLU branch (z, folded scale/shift)
+                cap.append(dict(layer=i, z=rec.get('z'), stats=rec.get('stats')))
             if l['bn']:
                 rows = dy.numel() // cout
                 if l['resid'] >= 0 and needs(l['resid']):
@@ -398,6 +425,8 @@ class Trainer(object):
                 sc = _scratch(st, 'wgrad', wsb, dev)
                 _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
                                            fw.ptr(self.views[wvar.op_name]), fw.ptr(sc), ctypes.c_size_t(sc.numel())))
+            if i in self.layer_ends:      # this layer's gradients are complete: reduce every bucket below its edge
+                self.exchange.ready(self.layer_ends[i])
             src, up = l['src'], l['up']
             need_src = needs(src)
             need_up = up >= 0 and needs(up)
@@ -448,11 +477,8 @@ class Trainer(object):
         L = _lib.lib()
         dev = self.flat.device
         ctx = fw.context(dev)
-        world = 1
-        if self.pg is not None or torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(self.pg)
-            if world > 1:
-                torch.distributed.all_reduce(self.flat, group=self.pg)
+        self.exchange.finish()      # buckets not yet issued by backward + join the asynchronous ones
+        world = self.exchange.world
         self.opt.step += 1
         lr = self.opt.lr_at(self.global_step)
         kind = Optimizer.KINDS.index(self.opt.kind)

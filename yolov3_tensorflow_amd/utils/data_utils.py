@@ -80,25 +80,107 @@ def process_box_batch(boxes, labels, counts, img_size, class_num, anchors):
     return ys
 
 
+def resize_nearest_cv2(img, new_width, new_height):
+    """cv2.resize(img, (new_width, new_height), interpolation=cv2.INTER_NEAREST) restated: src = min(floor(dst *
+    src_size / dst_size), src_size - 1) (no half-pixel centre)."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    sx = np.minimum(np.floor(np.arange(new_width) * (w / new_width)).astype(np.int64), w - 1)
+    sy = np.minimum(np.floor(np.arange(new_height) * (h / new_height)).astype(np.int64), h - 1)
+    return img[sy][:, sx]
+
+
+_COEF_BITS = 11      # OpenCV's INTER_RESIZE_COEF_BITS: uint8 bilinear runs in 2^11 fixed point
+
+
+def _linear_taps(src, dst):
+    """Per destination index: left source index, and the two 11-bit fixed-point weights, as OpenCV's resize computes
+    them for INTER_LINEAR: fx = (dx + 0.5) * scale - 0.5 in float32 (half-pixel centres, no antialiasing), clamped at both
+    borders; weights cvRound(w * 2048) as int16 (round-half-even)."""
+    scale = 1.0 / (dst / float(src))                    # OpenCV: scale_x = 1. / inv_scale_x
+    f = ((np.arange(dst) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo = s < 0
+    s[lo], f[lo] = 0, 0.0
+    hi = s >= src - 1
+    s[hi], f[hi] = src - 1, 0.0
+    a1 = np.rint(f.astype(np.float32) * np.float32(1 << _COEF_BITS)).astype(np.int32)
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(1 << _COEF_BITS)).astype(np.int32)
+    return s, np.minimum(s + 1, src - 1), a0, a1
+
+
+def resize_bilinear_cv2(img, new_width, new_height):
+    """cv2.resize(img, (new_width, new_height)) / interpolation=cv2.INTER_LINEAR for uint8 images, restated without
+    OpenCV (the reference's eval / validation / plain-resize preprocessing: utils/data_utils.py:167,
+    test_single_image.py:43).  Follows OpenCV's fixed-point path: horizontal pass with 11-bit weights into int32, vertical
+    pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16), +2, >>2; an exact 2x2 downscale is OpenCV's INTER_AREA fast path
+    ((a+b+c+d+2)>>2).  Half-pixel centres and NO antialiasing on downscale (PIL's BILINEAR antialiases: not the same
+    function).  Parity unpinned: no OpenCV is installable here; the arithmetic is restated from OpenCV's resize.cpp."""
+    img = np.asarray(img)
+    if img.dtype != np.uint8:
+        raise ValueError("resize_bilinear_cv2 expects a uint8 image")
+    squeeze = img.ndim == 2
+    if squeeze:
+        img = img[:, :, None]
+    h, w = img.shape[:2]
+    if (new_width, new_height) == (w, h):
+        return (img[:, :, 0] if squeeze else img).copy()
+    if w == 2 * new_width and h == 2 * new_height:
+        v = img.astype(np.int32)
+        out = ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        return out[:, :, 0] if squeeze else out
+    x0, x1, ax0, ax1 = _linear_taps(w, new_width)
+    y0, y1, ay0, ay1 = _linear_taps(h, new_height)
+    v = img.astype(np.int32)
+    rows = v[:, x0] * ax0[None, :, None] + v[:, x1] * ax1[None, :, None]          # [h, new_w, c] int32, scaled 2^11
+    s0, s1 = rows[y0], rows[y1]
+    out = (((ay0[:, None, None] * (s0 >> 4)) >> 16) + ((ay1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
+
+
+def _resize(img, new_width, new_height, interp):
+    if interp == 0:
+        return resize_nearest_cv2(img, new_width, new_height)
+    if interp == 1:
+        return resize_bilinear_cv2(img, new_width, new_height)
+    raise ValueError("interp must be 0 (cv2.INTER_NEAREST) or 1 (cv2.INTER_LINEAR); the other OpenCV interpolations "
+                     "are only used by the training augmentation, which is out of scope")
+
+
 def letterbox_resize(img, new_width, new_height, interp=0):
     '''
     Letterbox resize keeping the aspect ratio (reference utils/data_aug.py:274-293), without OpenCV.
-    img: HxWx3 uint8.  interp 0 = cv2.INTER_NEAREST semantics: src = min(floor(dst * src_size / dst_size),
-    src_size - 1) (no half-pixel centre); other interpolations are not provided.
+    img: HxWx3 uint8.  interp 0 = cv2.INTER_NEAREST (the demo call site, test_single_image.py:40), 1 =
+    cv2.INTER_LINEAR (the eval / validation call sites, utils/data_utils.py:167).
     returns image_padded, resize_ratio, dw, dh
     '''
-    if interp != 0:
-        raise ValueError("only interp=0 (nearest, the value the demo/eval call sites use) is implemented")
     img = np.asarray(img)
     ori_height, ori_width = img.shape[:2]
     resize_ratio = min(new_width / ori_width, new_height / ori_height)
     resize_w = int(resize_ratio * ori_width)
     resize_h = int(resize_ratio * ori_height)
-    sx = np.minimum(np.floor(np.arange(resize_w) * (ori_width / resize_w)).astype(np.int64), ori_width - 1)
-    sy = np.minimum(np.floor(np.arange(resize_h) * (ori_height / resize_h)).astype(np.int64), ori_height - 1)
-    resized = img[sy][:, sx]
+    resized = _resize(img, resize_w, resize_h, interp)
     image_padded = np.full((new_height, new_width, 3), 128, np.uint8)
     dw = int((new_width - resize_w) / 2)
     dh = int((new_height - resize_h) / 2)
     image_padded[dh: resize_h + dh, dw: resize_w + dw, :] = resized
     return image_padded, resize_ratio, dw, dh
+
+
+def resize_with_bbox(img, bbox, new_width, new_height, interp=0, letterbox=False):
+    '''
+    Resize the image and correct the bbox accordingly (reference utils/data_aug.py:296-320).
+    '''
+    bbox = np.array(bbox, np.float32).reshape(-1, 4)
+    if letterbox:
+        image_padded, resize_ratio, dw, dh = letterbox_resize(img, new_width, new_height, interp)
+        bbox[:, [0, 2]] = bbox[:, [0, 2]] * resize_ratio + dw
+        bbox[:, [1, 3]] = bbox[:, [1, 3]] * resize_ratio + dh
+        return image_padded, bbox
+    ori_height, ori_width = np.asarray(img).shape[:2]
+    img = _resize(img, new_width, new_height, interp)
+    bbox[:, [0, 2]] = bbox[:, [0, 2]] / ori_width * new_width
+    bbox[:, [1, 3]] = bbox[:, [1, 3]] / ori_height * new_height
+    return img, bbox

@@ -94,12 +94,41 @@ def load_weights(var_list, weights_file):
       BN'd : beta, gamma, moving_mean, moving_variance (FILE order; the variable order is gamma first)
       else : bias
       then the kernel as (Cout, Cin, kh, kw), transposed here to HWIO.
-    Like the reference, the stream length is not checked against the variables.
     Returns a list of AssignOp; execute with run_ops(ops).
+
+    The stream is read with the FILE's layer sizes, not blindly with the model's: a darknet file does not name its
+    class count, but the stream length does (the only layers whose size depends on it are the bias'd detection convs,
+    Cout = 3*(5+C)).  When the length does not fit the model's class count but fits another one, the detection layers
+    are cut with the file's Cout so that every later layer is read from the right offset; their AssignOps then carry
+    file-shaped arrays and raise ValueError when run (tf.assign(validate_shape=True)) — unless the caller drops them,
+    which is exactly what train.py's default restore_exclude does when fine-tuning a COCO file on another class count.
+    (The reference restores by NAME from a converted TF checkpoint, so its exclude works the same way.)  A length that
+    fits no class count raises ValueError (a truncated / over-long file, or not a darknet file at all).
     """
     with open(weights_file, "rb") as fp:
         np.fromfile(fp, dtype=np.int32, count=5)
         stream = np.fromfile(fp, dtype=np.float32)
+
+    groups = list(_conv_groups(var_list))
+
+    def layer_count(kernel, bn, bias, det_cout=None):
+        kh, kw, cin, cout = kernel.shape.as_list()
+        if det_cout is not None and bn is None and bias is not None:
+            cout = det_cout
+        return kh * kw * cin * cout + (4 * cout if bn is not None else cout if bias is not None else 0)
+
+    expected = sum(layer_count(*g) for g in groups)
+    det_cout = None
+    if expected != stream.size:
+        dets = [g for g in groups if g[1] is None and g[2] is not None]
+        couts = set(g[0].shape.as_list()[3] for g in dets)
+        per_cout = sum(g[0].shape.as_list()[0] * g[0].shape.as_list()[1] * g[0].shape.as_list()[2] + 1 for g in dets)
+        rest = expected - (per_cout * couts.pop() if len(couts) == 1 else 0)
+        cand = (stream.size - rest) // per_cout if (dets and not couts and per_cout) else 0
+        if not dets or couts or cand <= 0 or rest + per_cout * cand != stream.size or cand % 3 or cand // 3 <= 5:
+            raise ValueError("%s holds %d float32 values, the variables need %d: truncated / over-long file, or not a "
+                             "darknet file of this architecture" % (weights_file, stream.size, expected))
+        det_cout = int(cand)        # the file was written for (det_cout / 3 - 5) classes
 
     pos = [0]
 
@@ -116,8 +145,11 @@ def load_weights(var_list, weights_file):
             for v in (beta, gamma, mean, variance):
                 ops.append(AssignOp(v, take(v.shape.as_list()).reshape(v.shape.as_list())))
         elif bias is not None:
-            ops.append(AssignOp(bias, take(bias.shape.as_list()).reshape(bias.shape.as_list())))
+            bshape = bias.shape.as_list() if det_cout is None else [det_cout]
+            ops.append(AssignOp(bias, take(bshape).reshape(bshape)))
         kh, kw, cin, cout = kernel.shape.as_list()
+        if det_cout is not None and bn is None and bias is not None:
+            cout = det_cout
         oihw = take((cout, cin, kh, kw)).reshape(cout, cin, kh, kw)
         ops.append(AssignOp(kernel, np.transpose(oihw, (2, 3, 1, 0))))
     return ops
@@ -187,18 +219,21 @@ class Saver(object):
             np.savez(f, **out)
         return path
 
-    def restore(self, save_path, optimizer=None):
-        """Returns the stored global_step (or None)."""
+    def restore(self, save_path, optimizer=None, variables=True):
+        """Returns the stored global_step (or None).  variables=False leaves the variables alone and loads only the
+        optimizer slots (of the variables in var_list whose stored slots match the variable's shape) and its step —
+        what resuming needs AFTER a filtered variable restore (train.py: restore_exclude must stay excluded)."""
         import torch
         ckpt = np.load(self._path(save_path))
-        for v in self.var_list:
-            if v.op_name not in ckpt.files:
-                raise KeyError('Key %s not found in checkpoint %s' % (v.op_name, save_path))
-            v.assign(ckpt[v.op_name], validate_shape=True)
+        if variables:
+            for v in self.var_list:
+                if v.op_name not in ckpt.files:
+                    raise KeyError('Key %s not found in checkpoint %s' % (v.op_name, save_path))
+                v.assign(ckpt[v.op_name], validate_shape=True)
         if optimizer is not None:
             for v in self.var_list:
                 keys = [v.op_name + '/' + s for s in _SLOT_NAMES[optimizer.kind]]
-                if keys and all(k in ckpt.files for k in keys):
+                if keys and all(k in ckpt.files and tuple(ckpt[k].shape) == tuple(v.shape) for k in keys):
                     slots = [torch.as_tensor(ckpt[k]).to(v.tensor.device) for k in keys]
                     optimizer.slots[v.op_name] = tuple(slots + [None] * (2 - len(slots)))
             if 'optimizer/step' in ckpt.files:

@@ -60,6 +60,7 @@ def gpu_nms(boxes, scores, num_classes, max_boxes=50, score_thresh=0.5, nms_thre
     s = fw.as_device_f32(scores).reshape(1, -1, num_classes)
     ob, osc, ol, _, cnt = _run_nms(_lib.Y3_NMS_TF, b, s, num_classes, max_boxes, score_thresh, nms_thresh)
     k = int(cnt[0].item())
+    fw.check_context(b.device)      # the stream is idle here: surface a device-side failure of the forward, if any
     return ob[0, :k], osc[0, :k], ol[0, :k]
 
 
@@ -70,6 +71,7 @@ def gpu_nms_batched(boxes, scores, num_classes, max_boxes=50, score_thresh=0.5, 
     s = fw.as_device_f32(scores)
     ob, osc, ol, oi, cnt = _run_nms(_lib.Y3_NMS_TF, b, s, num_classes, max_boxes, score_thresh, nms_thresh)
     cnt_h = cnt.cpu().tolist()
+    fw.check_context(b.device)      # the stream is idle here: surface a device-side failure of the forward, if any
     out = []
     for i, k in enumerate(cnt_h):
         item = (ob[i, :k], osc[i, :k], ol[i, :k])
