@@ -268,6 +268,14 @@ int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int c
 int y3_conv2d_dgrad_split(y3_ctx* ctx, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
                           const void* w_split_d, const float* ones, const float* zeros, int accumulate, float* dx,
                           void* workspace, size_t workspace_bytes);
+/* The same data gradient in Winograd F(2x2,3x3) form (stride-1 3x3 convs with Cin %% 32 == 0 and dz_stride %% 32 == 0;
+ * the gradient of a SAME stride-1 conv is a SAME stride-1 conv with the flipped, channel-swapped kernel, so the forward
+ * Winograd kernel runs it): w_wino_d = 16 * dz_stride * cin floats from y3_pack_conv_weights_wino_dgrad(w_d = the
+ * [k*k][cin][dz_stride] kernel above); workspace as y3_conv_wino_workspace_bytes of the [n,h,w,dz_stride]->[..,cin] conv. */
+int y3_pack_conv_weights_wino_dgrad(y3_ctx* ctx, const float* w_d, int cin, int dz_stride, float* w_wino_d);
+int y3_conv2d_dgrad_wino(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride, const float* w_wino_d,
+                         const float* ones, const float* zeros, int accumulate, float* dx, void* workspace,
+                         size_t workspace_bytes);
 size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* fwd);
 int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,
                   float* dw_hwio, void* scratch, size_t scratch_bytes);
@@ -310,6 +318,25 @@ size_t y3_optimizer_scratch_bytes(void);
 int y3_clip_update(y3_ctx* ctx, int kind, float* w, float* g, float* slot0, float* slot1, long long n,
                    float weight_decay, float grad_scale, float clip_norm, float lr, float momentum, float decay,
                    float beta2, float eps, float* scratch);
+
+/* The same K11 for ALL trainable tensors of a step in three launches (train.py:112-115 applies clip_by_norm and the
+ * update to every (gradient, variable) pair): per-tensor norms come from a segmented, fixed-order reduction, so the
+ * result is deterministic.  `params` is a HOST array (device pointers inside); it is copied to the scratch with an
+ * asynchronous copy on the context's stream.  scratch: y3_clip_update_multi_scratch_bytes(params, count), 16-byte
+ * aligned.  w and g of a tensor with n %% 4 == 0 must be 16-byte aligned. */
+typedef struct y3_param_desc {
+    float* w;            /* the variable */
+    float* g;            /* its gradient (updated in place to the clipped gradient) */
+    float* slot0;        /* optimizer slots as in y3_clip_update (NULL where the rule has none) */
+    float* slot1;
+    long long n;         /* elements */
+    float weight_decay;  /* l2 coefficient (0 for BN parameters and biases) */
+    int reserved;
+} y3_param_desc;
+size_t y3_clip_update_multi_scratch_bytes(const y3_param_desc* params, int count);
+int y3_clip_update_multi(y3_ctx* ctx, int kind, const y3_param_desc* params, int count, float grad_scale,
+                         float clip_norm, float lr, float momentum, float decay, float beta2, float eps,
+                         void* scratch, size_t scratch_bytes);
 
 #ifdef __cplusplus
 }

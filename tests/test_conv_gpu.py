@@ -273,16 +273,24 @@ def test_streamk_timeout_is_loud(monkeypatch):
     runs = {'direct': lambda: engine.conv2d_fwd(x, wp, ones, zeros, 3, 1, cout, True),
             'wino': lambda: engine.conv2d_fwd_wino(x, wu, ones, zeros, cout, True)}
     fw.check_context()
-    for name, run in runs.items():
-        good = run()
-        fw.check_context()
-        monkeypatch.setenv('Y3_STREAMK_FAULT', '1')
-        run()                                          # launches; its result is garbage and says so:
-        with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
-            run()                                      # ... the next call on the context refuses to launch
-        with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
-            fw.check_context()                         # ... and the explicit check reports it (and clears it)
-        monkeypatch.delenv('Y3_STREAMK_FAULT')
-        fw.check_context()
-        assert torch.equal(run(), good), name
-        fw.check_context()
+    try:
+        for name, run in runs.items():
+            good = run()
+            fw.check_context()
+            monkeypatch.setenv('Y3_STREAMK_FAULT', '1')
+            run()                                      # launches; its result is garbage and says so:
+            torch.cuda.synchronize()                   # (the kernel has to have run for the word to be set)
+            with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
+                run()                                  # ... the next call on the context refuses to launch
+            with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
+                fw.check_context()                     # ... and the explicit check reports it (and clears it)
+            monkeypatch.delenv('Y3_STREAMK_FAULT')
+            fw.check_context()
+            assert torch.equal(run(), good), name
+            fw.check_context()
+    finally:
+        monkeypatch.delenv('Y3_STREAMK_FAULT', raising=False)
+        try:
+            fw.check_context()                         # never leave the session's context poisoned for later tests
+        except _lib.Y3Error:
+            pass

@@ -2,7 +2,7 @@
 conv weight/data gradients, batch-norm train forward/backward, the YOLO loss and its gradient, and one
 whole train step (loss 5-tuple, clipped gradients, updated variables, BN moving statistics) for each of
 the four optimizers.  Tolerances (stated): per-op 2e-4 relative to the tensor's max magnitude; whole-step
-gradients 1e-3 relative to the tensor's max |grad| for EVERY tensor (256 px, bs=4, fp64 oracle evaluated on the
+gradients 2e-4 relative to the tensor's max |grad| for EVERY tensor (256 px, bs=4, fp64 oracle evaluated on the
 LeakyReLU branches the GPU took — see test_one_train_step_matches_oracle); loss values 1e-4 relative."""
 import ctypes
 
@@ -84,6 +84,20 @@ def test_conv_wgrad_and_dgrad_match_autograd(n, h, w, k, stride, cin, cout):
             _lib.check(L.y3_conv2d_dgrad_split(ctx, ctypes.byref(d), 3, fw.ptr(dzg), stride_c, fw.ptr(w_d),
                                                fw.ptr(ones), fw.ptr(zeros), 0, fw.ptr(dx), fw.ptr(ws),
                                                ctypes.c_size_t(ws.numel())))
+    # the same data gradient in Winograd form (stride-1 3x3 convs): the gradient conv is itself a 3x3 SAME conv
+    if k == 3 and stride == 1 and cin % 32 == 0:
+        wwd = torch.empty(16 * cin * stride_c, device=dev)
+        _lib.check(L.y3_pack_conv_weights_wino_dgrad(ctx, fw.ptr(w_d), cin, stride_c, fw.ptr(wwd)))
+        for use_ws in (True, False):
+            for acc, mult in ((0, 1.0), (1, 2.0)):
+                _lib.check(L.y3_conv2d_dgrad_wino(ctx, ctypes.byref(d), fw.ptr(dzg), stride_c, fw.ptr(wwd), fw.ptr(ones),
+                                                  fw.ptr(zeros), acc, fw.ptr(dx), fw.ptr(ws) if use_ws else None,
+                                                  ctypes.c_size_t(ws.numel() if use_ws else 0)))
+                assert rel_err(dx.cpu().numpy(), mult * x.grad.numpy()) < 2e-4, 'wino accumulate=%d ws=%s' % (acc, use_ws)
+    elif stride == 2:
+        with pytest.raises(ValueError):
+            _lib.check(L.y3_conv2d_dgrad_wino(ctx, ctypes.byref(d), fw.ptr(dzg), stride_c, fw.ptr(w_d), fw.ptr(ones),
+                                              fw.ptr(zeros), 0, fw.ptr(dx), None, ctypes.c_size_t(0)))
 
 
 @pytest.mark.parametrize('rows,c', [(2 * 13 * 13, 1024), (3 * 20 * 28, 64), (5000, 32), (64, 256)])
@@ -158,6 +172,53 @@ def test_loss_and_its_gradient_match_oracle(smooth, focal):
         model.compute_loss(fms, [yts[0], yts[0], yts[2]])
 
 
+@pytest.mark.parametrize('kind', [0, 1, 2, 3])
+def test_multi_tensor_clip_update_equals_the_per_tensor_form(kind):
+    """y3_clip_update_multi (3 launches for all tensors; ref: train.py:112-115) against y3_clip_update tensor by tensor:
+    same arithmetic, only the association of the norm's partial sums differs (-> 1e-6 relative), deterministic."""
+    fw, _lib, L, ctx = _ctx()
+    dev = fw.default_device()
+    rng = np.random.RandomState(kind)
+    sizes = [255, 32, 3 * 3 * 64 * 128, 1024, 18, 8192, 8193, 3 * 3 * 256 * 512, 7]
+    def make():
+        out = []
+        r = np.random.RandomState(100 + kind)
+        for i, n in enumerate(sizes):
+            big = 50.0 if i % 3 == 0 else 0.01          # some tensors get clipped (norm > 100), some do not
+            t = lambda a: torch.tensor(a.astype(np.float32), device=dev)
+            out.append(dict(w=t(r.standard_normal(n)), g=t(r.standard_normal(n) * big), s0=t(np.abs(r.standard_normal(n))),
+                            s1=t(np.abs(r.standard_normal(n))), wd=5e-4 if n > 1000 else 0.0))
+        return out
+    hp = dict(gs=0.5, clip=100.0, lr=1e-2, mom=0.9, decay=0.9, b2=0.999, eps=1e-8)
+    def run_multi(ts):
+        arr = (_lib.ParamDesc * len(ts))()
+        for i, t in enumerate(ts):
+            arr[i] = _lib.ParamDesc(t['w'].data_ptr(), t['g'].data_ptr(), t['s0'].data_ptr(), t['s1'].data_ptr(),
+                                    t['w'].numel(), t['wd'], 0)
+        sc = torch.empty(L.y3_clip_update_multi_scratch_bytes(arr, len(ts)), dtype=torch.uint8, device=dev)
+        _lib.check(L.y3_clip_update_multi(ctx, kind, arr, len(ts), ctypes.c_float(hp['gs']), ctypes.c_float(hp['clip']),
+                                          ctypes.c_float(hp['lr']), ctypes.c_float(hp['mom']), ctypes.c_float(hp['decay']),
+                                          ctypes.c_float(hp['b2']), ctypes.c_float(hp['eps']), fw.ptr(sc),
+                                          ctypes.c_size_t(sc.numel())))
+    a, b, c = make(), make(), make()
+    run_multi(a)
+    run_multi(c)
+    sc = torch.empty(L.y3_optimizer_scratch_bytes(), dtype=torch.uint8, device=dev)
+    for t in b:
+        _lib.check(L.y3_clip_update(ctx, kind, fw.ptr(t['w']), fw.ptr(t['g']), fw.ptr(t['s0']), fw.ptr(t['s1']),
+                                    t['w'].numel(), ctypes.c_float(t['wd']), ctypes.c_float(hp['gs']),
+                                    ctypes.c_float(hp['clip']), ctypes.c_float(hp['lr']), ctypes.c_float(hp['mom']),
+                                    ctypes.c_float(hp['decay']), ctypes.c_float(hp['b2']), ctypes.c_float(hp['eps']),
+                                    fw.ptr(sc)))
+    for ta, tb, tc in zip(a, b, c):
+        for key in ('w', 'g', 's0', 's1'):
+            assert torch.equal(ta[key], tc[key]), 'multi-tensor update is not deterministic'
+            np.testing.assert_allclose(ta[key].cpu().numpy(), tb[key].cpu().numpy(), rtol=2e-6, atol=1e-7,
+                                       err_msg='%s of a %d-element tensor' % (key, ta['w'].numel()))
+    # clipping happened where it should: ||g|| == 100 for the large-gradient tensors
+    assert abs(float(a[0]['g'].norm()) - 100.0) < 1e-2 and float(a[1]['g'].norm()) < 100.0
+
+
 def _fresh_model(params, **kw):
     import yolov3_tensorflow_amd as y3
     y3.reset_default_graph()
@@ -186,7 +247,7 @@ def _conv_name(i):
     ('sgd', None, 'f32_wino')])
 def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated_graph):
     """One whole train step (ref: train.py:105-115) at 256 px, bs=4 (every BN layer reduces over >= 256 samples) against
-    the fp64 autograd oracle: loss 5-tuple 1e-4, EVERY clipped gradient tensor within 1e-3 of its max magnitude,
+    the fp64 autograd oracle: loss 5-tuple 1e-4, EVERY clipped gradient tensor within 2e-4 of its max magnitude,
     updated variables and BN moving statistics.
 
     Conditioning: LeakyReLU makes the gradient discontinuous in the forward values — an element whose pre-activation
@@ -194,7 +255,7 @@ def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated
     gradient tensor by ~sqrt(p).  Measured on this very configuration: the CPU fp32 oracle with its OWN branches is
     4.4e-2 (worst tensor; median 3e-3) from the fp64 oracle, and 2.2e-5 when the activation is smooth.  So the oracle
     is run with the branches the GPU took (mask = z*scale+shift > 0 from the tensors the GPU kept for its backward):
-    both sides then differentiate the same piecewise-linear function and every tensor is held to 1e-3.  The
+    both sides then differentiate the same piecewise-linear function and every tensor is held to 2e-4.  The
     comparison against the oracle's own branches is printed for scale."""
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd import training
@@ -233,7 +294,7 @@ def test_one_train_step_matches_oracle(optimizer, update_scopes, dtype, isolated
         assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-6, ([float(v) for v in loss], ref['loss'])
     # clipped gradients (incl. the L2 term), every trainable variable
     assert set(trainer.views) == set(ref['grads'])
-    GRAD_TOL = 1e-3
+    GRAD_TOL = 2e-4      # measured: worst 2.0e-5 over all tensors, modes and optimizers (vs 1.1e-1 on the oracle's own branches)
     errs = {name: rel_err(trainer.views[name].cpu().numpy(), g) for name, g in ref['grads'].items()}
     worst = max(errs, key=errs.get)
     msg = '%s/%s: gradient rel err vs fp64 oracle on the GPU\'s branches: worst %.2e (%s), median %.2e over %d tensors' % (

@@ -17,6 +17,11 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("n", "h", "w", "cin", "c_up", "cout", "k", "stride", "act")]
 
 
+class ParamDesc(ctypes.Structure):      # y3_param_desc
+    _fields_ = [("w", c_void_p), ("g", c_void_p), ("slot0", c_void_p), ("slot1", c_void_p), ("n", c_longlong),
+                ("weight_decay", c_float), ("reserved", c_int)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
 PROTOTYPES = {
     "y3_last_error": (c_char_p, []),
@@ -78,6 +83,9 @@ PROTOTYPES = {
     "y3_bias_grad": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
     "y3_conv2d_dgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                 c_void_p, c_void_p, c_size_t]),
+    "y3_pack_conv_weights_wino_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "y3_conv2d_dgrad_wino": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_size_t]),
     "y3_conv_wgrad_scratch_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv_wgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
     "y3_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -92,6 +100,9 @@ PROTOTYPES = {
     "y3_optimizer_scratch_bytes": (c_size_t, []),
     "y3_clip_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
                                c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
+    "y3_clip_update_multi_scratch_bytes": (c_size_t, [c_void_p, c_int]),
+    "y3_clip_update_multi": (c_int, [c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
+                                     c_float, c_float, c_void_p, c_size_t]),
     "y3_net_set_profiling": (c_int, [c_void_p, c_int]),
     "y3_net_get_layer_ms": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "y3_net_layer_is_streamk": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),

@@ -134,6 +134,39 @@ extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const floa
     return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
+// Data gradient of a stride-1 3x3 conv in its Winograd form: dx (+)= conv_same(dz, flipped / channel-swapped kernel) is
+// itself a stride-1 3x3 SAME conv [n,h,w,dz_stride] -> [n,h,w,cin], so the forward Winograd kernel runs it unchanged.
+static int wino_dgrad_desc(const y3_conv_desc* fwd, int dz_stride, y3_conv_desc* g) {
+    Y3_CHECK_ARG(fwd && fwd->k == 3 && fwd->stride == 1 && fwd->c_up == 0, "y3_conv2d_dgrad_wino: needs a 3x3 stride-1 conv");
+    Y3_CHECK_ARG(dz_stride >= fwd->cout && dz_stride % 32 == 0 && fwd->cin % 32 == 0,
+                 "y3_conv2d_dgrad_wino: dz stride and Cin must be multiples of 32");
+    *g = *fwd;
+    g->cin = dz_stride; g->cout = fwd->cin; g->act = 0;
+    Y3_CHECK_ARG(y3_conv_wino_eligible_impl(g), "y3_conv2d_dgrad_wino: shape not eligible for the Winograd kernel");
+    return Y3_OK;
+}
+
+extern "C" int y3_pack_conv_weights_wino_dgrad(y3_ctx* ctx, const float* w_d, int cin, int dz_stride, float* w_wino_d) {
+    Y3_CHECK_ARG(ctx && w_d && w_wino_d, "y3_pack_conv_weights_wino_dgrad: null argument");
+    Y3_CHECK_ARG(cin > 0 && dz_stride > 0 && dz_stride % 8 == 0,
+                 "y3_pack_conv_weights_wino_dgrad: dz_stride must be a positive multiple of 8");
+    return y3_launch_pack_wino(ctx->stream, w_d, dz_stride, cin, w_wino_d, 1);
+}
+
+extern "C" int y3_conv2d_dgrad_wino(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
+                                    const float* w_wino_d, const float* ones, const float* zeros, int accumulate,
+                                    float* dx, void* workspace, size_t workspace_bytes) {
+    Y3_CHECK_CTX(ctx, "y3_conv2d_dgrad_wino");
+    Y3_CHECK_ARG(dz && w_wino_d && ones && zeros && dx, "y3_conv2d_dgrad_wino: null pointer argument");
+    y3_conv_desc g;
+    if (int rc = wino_dgrad_desc(fwd, dz_stride, &g)) return rc;
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    // accumulate: dx is read as the residual and written by the same thread of the same tile (no cross-thread hazard)
+    return y3_launch_conv_wino(ctx->stream, &g, dz, w_wino_d, ones, zeros, accumulate ? dx : nullptr, dx, workspace,
+                               workspace_bytes, &o);
+}
+
 extern "C" int y3_pack_conv_weights_split_dgrad(y3_ctx* ctx, const float* w_d, int k, int cin, int dz_stride,
                                                 int planes, void* w_split) {
     Y3_CHECK_ARG(ctx && w_d && w_split, "y3_pack_conv_weights_split_dgrad: null argument");

@@ -607,7 +607,11 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 }
 
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
-__global__ void pack_weights_wino_kernel(const float* __restrict__ w_hwio, float* __restrict__ out, int cin, int cout) {
+// dgrad != 0: (cin, cout) are those of the GRADIENT conv (cin = dz channels, cout = the forward layer's Cin) and w is
+// the forward kernel stored [3*3][cout][cin] (= [tap][fwd Cin][dz_stride]); the gradient conv's kernel is the forward
+// one with its taps flipped and its channel axes swapped: g'[a][b](ci, co) = w[(2-a, 2-b)][co][ci].
+__global__ void pack_weights_wino_kernel(const float* __restrict__ w_hwio, float* __restrict__ out, int cin, int cout,
+                                         int dgrad) {
     const size_t total = (size_t)cin * cout;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(i / cout), co = (int)(i % cout);
@@ -615,7 +619,9 @@ __global__ void pack_weights_wino_kernel(const float* __restrict__ w_hwio, float
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = dgrad ? w_hwio[((size_t)((2 - a) * 3 + (2 - b)) * cout + co) * cin + ci]
+                                : w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
         float t[4][3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -646,10 +652,10 @@ int y3_conv_wino_eligible_impl(const y3_conv_desc* d) {
            d->n > 0 && d->h > 1 && d->w > 1;
 }
 
-int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {
+int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out, int dgrad) {
     const size_t total = (size_t)cin * cout;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout);
+    hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout, dgrad);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

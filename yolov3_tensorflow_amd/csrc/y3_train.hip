@@ -5,6 +5,7 @@
 // All are HBM-bound streaming/reduction kernels: 16-byte-per-lane accesses along the channel axis,
 // per-workgroup partial sums written to a scratch array and combined by a finalize kernel in a FIXED order
 // (fp64 accumulation) so that every statistic and gradient is run-to-run deterministic (no float atomics).
+#include <vector>
 #include "y3_internal.h"
 
 namespace {
@@ -455,6 +456,109 @@ __global__ void __launch_bounds__(256) optimizer_update_kernel(float* __restrict
     }
 }
 
+// ---- multi-tensor form: every trainable tensor of the step in THREE launches (prepare / norms / update) --------------
+// A tensor is cut into chunks of MT_CHUNK elements; workgroup b owns global chunk b and finds its tensor by a binary
+// search over the tensors' first-chunk indices.  Per-tensor norms are segmented sums of the per-chunk partials in a
+// fixed order (deterministic; no float atomics).
+constexpr int MT_CHUNK = 8192;          // elements per workgroup: 256 threads x 8 float4
+struct MtDesc {                         // device copy of y3_param_desc + its first global chunk
+    float* w; float* g; float* s0; float* s1;
+    long long n;
+    float wd;
+    int chunk_begin;
+};
+static_assert(sizeof(MtDesc) == 48, "MtDesc layout");
+
+__device__ __forceinline__ int mt_find(const MtDesc* __restrict__ d, int count, int chunk) {
+    int lo = 0, hi = count - 1;         // last tensor whose chunk_begin <= chunk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].chunk_begin <= chunk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// g <- g*gscale + wd*w ; partial[chunk] = sum of g^2 over the chunk
+__global__ void __launch_bounds__(256) mt_prepare_kernel(const MtDesc* __restrict__ descs, int count, float gscale,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int t = mt_find(descs, count, blockIdx.x);
+    const MtDesc d = descs[t];
+    const long long base = (long long)(blockIdx.x - d.chunk_begin) * MT_CHUNK;
+    const long long end = base + MT_CHUNK < d.n ? base + MT_CHUNK : d.n;
+    float s = 0.f;
+    if ((d.n & 3) == 0) {               // every view is 16-byte aligned and (n % 4 == 0) a whole number of float4
+        for (long long i = base + 4 * threadIdx.x; i < end; i += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(d.g + i) * gscale;
+            if (d.wd != 0.f) v += d.wd * *reinterpret_cast<const f32x4*>(d.w + i);
+            *reinterpret_cast<f32x4*>(d.g + i) = v;
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    } else {
+        for (long long i = base + threadIdx.x; i < end; i += 256) {
+            float v = d.g[i] * gscale;
+            if (d.wd != 0.f) v += d.wd * d.w[i];
+            d.g[i] = v;
+            s += v * v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// norm[t] = sqrt(sum of tensor t's chunk partials) — one workgroup per tensor, fixed order, fp64
+__global__ void __launch_bounds__(256) mt_norms_kernel(const MtDesc* __restrict__ descs, int count, int total_chunks,
+                                                       const float* __restrict__ partial, float* __restrict__ norm) {
+    __shared__ double sh[256];
+    const int t = blockIdx.x;
+    const int b = descs[t].chunk_begin, e = t + 1 < count ? descs[t + 1].chunk_begin : total_chunks;
+    const double s = block_sum_fixed(partial + b, e - b, (size_t)1, (size_t)0, sh);
+    if (threadIdx.x == 0) norm[t] = (float)sqrt(s);
+}
+
+__device__ __forceinline__ void mt_update_one(int kind, float& wi, float& gi, float* s0, float* s1, long long i,
+                                              float factor, float lr, float momentum, float decay, float beta2,
+                                              float eps) {
+    gi *= factor;
+    if (kind == 0) {
+        wi -= lr * gi;
+    } else if (kind == 1) {
+        const float acc = s0[i] * momentum + gi;
+        s0[i] = acc;
+        wi -= lr * acc;
+    } else if (kind == 2) {
+        const float m = s0[i] * decay + (1.f - decay) * gi;          // decay = beta1
+        const float v = s1[i] * beta2 + (1.f - beta2) * gi * gi;
+        s0[i] = m; s1[i] = v;
+        wi -= lr * m / (sqrtf(v) + eps);                              // lr = lr_t
+    } else {
+        const float ms = s0[i] * decay + (1.f - decay) * gi * gi;
+        const float mom = s1[i] * momentum + lr * gi / sqrtf(ms + eps);
+        s0[i] = ms; s1[i] = mom;
+        wi -= mom;
+    }
+}
+
+// tf.clip_by_norm per tensor, then the TF1 update rule — the same arithmetic as optimizer_update_kernel
+__global__ void __launch_bounds__(256) mt_update_kernel(const MtDesc* __restrict__ descs, int count,
+                                                        const float* __restrict__ norm, float clip, int kind, float lr,
+                                                        float momentum, float decay, float beta2, float eps) {
+    const int t = mt_find(descs, count, blockIdx.x);
+    const MtDesc d = descs[t];
+    const float factor = clip / fmaxf(norm[t], clip);
+    const long long base = (long long)(blockIdx.x - d.chunk_begin) * MT_CHUNK;
+    const long long end = base + MT_CHUNK < d.n ? base + MT_CHUNK : d.n;
+    for (long long i = base + threadIdx.x; i < end; i += 256) {
+        float gi = d.g[i], wi = d.w[i];
+        mt_update_one(kind, wi, gi, d.s0, d.s1, i, factor, lr, momentum, decay, beta2, eps);
+        d.g[i] = gi;                                  // the clipped gradient stays observable
+        d.w[i] = wi;
+    }
+}
+
 // sum over rows of an [M][C] matrix with arbitrary C (bias gradient of the detection convs, C = 3*(5+classes))
 __global__ void __launch_bounds__(256) col_sum_scalar_kernel(const float* __restrict__ x, long long M, int C,
                                                              float* __restrict__ partial /*[grid][C]*/) {
@@ -728,6 +832,57 @@ extern "C" int y3_clip_update(y3_ctx* ctx, int kind, float* w, float* g, float* 
     Y3_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(optimizer_update_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, w, g, slot0, slot1,
                        norm, clip_norm, kind, lr, momentum, decay, beta2, eps, n);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+static long long mt_chunks(long long n) { return (n + MT_CHUNK - 1) / MT_CHUNK; }
+
+extern "C" size_t y3_clip_update_multi_scratch_bytes(const y3_param_desc* params, int count) {
+    if (!params || count <= 0) return 0;
+    long long chunks = 0;
+    for (int i = 0; i < count; ++i) chunks += params[i].n > 0 ? mt_chunks(params[i].n) : 0;
+    // [descs][partial per chunk][norm per tensor]
+    return (((size_t)count * sizeof(MtDesc) + 255) & ~(size_t)255) + (((size_t)chunks * 4 + 255) & ~(size_t)255) +
+           (size_t)count * 4 + 256;
+}
+
+extern "C" int y3_clip_update_multi(y3_ctx* ctx, int kind, const y3_param_desc* params, int count, float grad_scale,
+                                    float clip_norm, float lr, float momentum, float decay, float beta2, float eps,
+                                    void* scratch, size_t scratch_bytes) {
+    Y3_CHECK_ARG(ctx && params && scratch, "y3_clip_update_multi: null argument");
+    Y3_CHECK_ARG(count > 0 && count <= 65536, "y3_clip_update_multi: bad tensor count %d", count);
+    Y3_CHECK_ARG(kind >= 0 && kind <= 3, "y3_clip_update_multi: unknown optimizer kind %d", kind);
+    Y3_CHECK_ARG(scratch_bytes >= y3_clip_update_multi_scratch_bytes(params, count) && ((uintptr_t)scratch & 15) == 0,
+                 "y3_clip_update_multi: scratch too small or misaligned");
+    // host staging of the device descriptors: thread-local so that the asynchronous copy below never reads a buffer
+    // another call is rewriting (the copy is enqueued before this call returns; HIP stages pageable memory itself)
+    static thread_local std::vector<MtDesc> host;
+    host.resize(count);
+    long long chunks = 0;
+    for (int i = 0; i < count; ++i) {
+        const y3_param_desc& q = params[i];
+        Y3_CHECK_ARG(q.w && q.g && q.n > 0, "y3_clip_update_multi: tensor %d has a null pointer or no elements", i);
+        Y3_CHECK_ARG(kind == 0 || q.slot0, "y3_clip_update_multi: tensor %d: optimizer slot missing", i);
+        Y3_CHECK_ARG(kind < 2 || q.slot1, "y3_clip_update_multi: tensor %d: second optimizer slot missing", i);
+        Y3_CHECK_ARG((((uintptr_t)q.w | (uintptr_t)q.g) & 15) == 0 || (q.n & 3) != 0,
+                     "y3_clip_update_multi: tensor %d: w and g must be 16-byte aligned", i);
+        host[i] = MtDesc{q.w, q.g, q.slot0, q.slot1, q.n, q.weight_decay, (int)chunks};
+        chunks += mt_chunks(q.n);
+        Y3_CHECK_ARG(chunks < (1LL << 30), "y3_clip_update_multi: too many elements");
+    }
+    char* base = static_cast<char*>(scratch);
+    MtDesc* descs = reinterpret_cast<MtDesc*>(base);
+    float* partial = reinterpret_cast<float*>(base + (((size_t)count * sizeof(MtDesc) + 255) & ~(size_t)255));
+    float* norm = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + (((size_t)chunks * 4 + 255) & ~(size_t)255));
+    hipStream_t st = ctx->stream;
+    Y3_CHECK_HIP(hipMemcpyAsync(descs, host.data(), (size_t)count * sizeof(MtDesc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mt_prepare_kernel, dim3((unsigned)chunks), dim3(256), 0, st, descs, count, grad_scale, partial);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mt_norms_kernel, dim3(count), dim3(256), 0, st, descs, count, (int)chunks, partial, norm);
+    Y3_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(mt_update_kernel, dim3((unsigned)chunks), dim3(256), 0, st, descs, count, norm, clip_norm, kind,
+                       lr, momentum, decay, beta2, eps);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

@@ -435,6 +435,15 @@ class Trainer(object):
             cin = int(xin.shape[3])
             ones, zeros = _consts(st, cin, dev)
             planes = _planes(model) if (l['stride'] == 1 and cin % 4 == 0 and dz_stride % 32 == 0) else 0
+            # compute_dtype 'f32_wino': the data gradient of a stride-1 3x3 conv is itself a stride-1 3x3 SAME conv
+            # (flipped, channel-swapped kernel), so it runs on the Winograd kernel too
+            wino_d = (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and up < 0 and
+                      engine.wino_eligible(l['k'], l['stride'], dz_stride, cin))
+            if wino_d:
+                w_dw = _scratch(st, 'wwino_d', 16 * cin * dz_stride * 4, dev)
+                _lib.check(L.y3_pack_conv_weights_wino_dgrad(ctx, fw.ptr(w_d), cin, dz_stride, fw.ptr(w_dw)))
+                gdesc = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), dz_stride, 0, cin, 3, 1, 0)
+                wk_ws = _scratch(st, 'streamk_wino', int(L.y3_conv_wino_workspace_bytes(ctypes.byref(gdesc))), dev)
             if planes:
                 k = l['k']
                 w_ds = _scratch(st, 'wsplit_d', planes * k * k * cin * dz_stride * 2, dev)
@@ -442,7 +451,11 @@ class Trainer(object):
                                                               fw.ptr(w_ds)))
 
             def dgrad(accumulate, dx):
-                if planes:
+                if wino_d:
+                    _lib.check(L.y3_conv2d_dgrad_wino(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_dw),
+                                                      fw.ptr(ones), fw.ptr(zeros), accumulate, fw.ptr(dx),
+                                                      fw.ptr(wk_ws), ctypes.c_size_t(wk_ws.numel())))
+                elif planes:
                     _lib.check(L.y3_conv2d_dgrad_split(ctx, ctypes.byref(d), planes, fw.ptr(dz), dz_stride,
                                                        fw.ptr(w_ds), fw.ptr(ones), fw.ptr(zeros), accumulate,
                                                        fw.ptr(dx), fw.ptr(sk_ws), ctypes.c_size_t(sk_ws.numel())))
@@ -472,6 +485,23 @@ class Trainer(object):
         st['saved'] = None
         st['fm_grads'] = None
 
+    def _param_descs(self):
+        """Host array of y3_param_desc for self.order (rebuilt when a variable's storage or a slot changed)."""
+        sig = tuple((v.tensor.data_ptr(),) + tuple(0 if s is None else s.data_ptr() for s in self.opt._slots_for(v))
+                    for v in self.order)
+        if getattr(self, '_descs_sig', None) != sig:
+            arr = (_lib.ParamDesc * len(self.order))()
+            keep = []
+            for i, v in enumerate(self.order):
+                g = self.views[v.op_name]
+                s0, s1 = self.opt._slots_for(v)
+                wd = float(self.model.weight_decay) if v.op_name.endswith('/weights') else 0.0
+                arr[i] = _lib.ParamDesc(v.tensor.data_ptr(), g.data_ptr(), 0 if s0 is None else s0.data_ptr(),
+                                        0 if s1 is None else s1.data_ptr(), v.tensor.numel(), wd, 0)
+                keep.append((v.tensor, s0, s1))
+            self._descs, self._descs_keep, self._descs_sig = arr, keep, sig
+        return self._descs, self._descs_keep
+
     def apply_gradients(self):
         """all-reduce (mean over ranks) -> + weight_decay*w on conv kernels -> clip_by_norm -> update."""
         L = _lib.lib()
@@ -487,16 +517,16 @@ class Trainer(object):
             lr = lr * np.sqrt(1.0 - self.opt.beta2 ** t) / (1.0 - self.opt.beta1 ** t)
         decay = self.opt.beta1 if self.opt.kind == 'adam' else self.opt.decay
         st = _train_state(self.model)
-        sc = _scratch(st, 'opt', L.y3_optimizer_scratch_bytes(), dev)
+        # ONE multi-tensor call (three launches) for every (gradient, variable) pair of train.py:112-115
+        descs, keep = self._param_descs()
+        nbytes = L.y3_clip_update_multi_scratch_bytes(descs, len(self.order))
+        sc = _scratch(st, 'opt_multi', nbytes, dev)
+        _lib.check(L.y3_clip_update_multi(ctx, kind, descs, len(self.order), ctypes.c_float(1.0 / world),
+                                          ctypes.c_float(self.clip_norm), ctypes.c_float(lr),
+                                          ctypes.c_float(self.opt.momentum), ctypes.c_float(decay),
+                                          ctypes.c_float(self.opt.beta2), ctypes.c_float(self.opt.epsilon),
+                                          fw.ptr(sc), ctypes.c_size_t(sc.numel())))
         for v in self.order:
-            g = self.views[v.op_name]
-            s0, s1 = self.opt._slots_for(v)
-            wd = float(self.model.weight_decay) if v.op_name.endswith('/weights') else 0.0
-            _lib.check(L.y3_clip_update(ctx, kind, fw.ptr(v.tensor), fw.ptr(g), fw.ptr(s0), fw.ptr(s1),
-                                        v.tensor.numel(), ctypes.c_float(wd), ctypes.c_float(1.0 / world),
-                                        ctypes.c_float(self.clip_norm), ctypes.c_float(lr),
-                                        ctypes.c_float(self.opt.momentum), ctypes.c_float(decay),
-                                        ctypes.c_float(self.opt.beta2), ctypes.c_float(self.opt.epsilon), fw.ptr(sc)))
             v.touch()
         self.global_step += 1.0
 
