@@ -48,9 +48,14 @@ def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys, isolated
         '--progress_log_path', str(tmp_path / 'progress.log'), '--anchor_path', os.path.join(ROOT, 'data', 'yolo_anchors.txt'),
         '--class_name_path', names, '--batch_size', '8', '--img_size', '160', '160', '--letterbox_resize', 'false',
         '--total_epoches', '201', '--train_evaluation_step', '50', '--val_evaluation_epoch', '200', '--batch_norm_decay', '0.9', '--save_epoch', '1000',
-        '--optimizer_name', 'adam', '--learning_rate_init', '1e-3', '--lr_type', 'fixed', '--update_part', 'None',
+        '--optimizer_name', 'adam', '--learning_rate_init', '1e-3', '--lr_type', 'piecewise', '--pw_boundaries', '140',
+        '--pw_values', '1e-3', '1e-4', '--update_part', 'None',
         '--multi_scale_train', 'false', '--use_warm_up', 'false', '--warm_up_epoch', '0', '--use_label_smooth', 'false',
         '--use_focal_loss', 'false', '--score_threshold', '0.3', '--nms_topk', '20', '--weight_decay', '0'])
+    # (learning rate 1e-3 for 140 steps, then 1e-4: at a constant 1e-3 Adam on this 8-image set throws loss spikes
+    # in the last 50 steps whose position depends on the last bit of every kernel — tools/train_converge_probe.py
+    # shows five numerically equivalent builds agreeing to 1e-5 for the first steps and ending anywhere between
+    # loss 0.88 and 2.6; with the drop every one of them settles: loss 1.35, recall 1.0, mAP 1.0)
     out = capsys.readouterr().out
     loss = np.array(hist['loss'])
     print('loss: first %.2f, min %.2f, last %.2f; recalls %s; mAP %s' % (loss[0], loss.min(), loss[-1], hist['recall'],
@@ -59,7 +64,7 @@ def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys, isolated
     assert loss[-10:].mean() < 0.5 * loss[:3].mean()
     assert 'Last batch: rec:' in out and 'EVAL: Recall:' in out
     assert len(hist['mAP']) == 2 and all(0.0 <= m <= 1.0 for m in hist['mAP'])
-    # measured: recall on the training batch 1.0 and mAP 1.0 on the (memorised) set after 201 Adam steps
+    # measured: recall on the training batch 1.0 and mAP 1.0 on the (memorised) set after 201 Adam steps (lr drop at 140)
     assert hist['recall'][-1] > 0.8 and hist['mAP'][-1] > 0.8
     files = os.listdir(str(tmp_path / 'ckpt'))
     assert any(f.startswith('best_model_Epoch_') and f.endswith('.weights') for f in files)

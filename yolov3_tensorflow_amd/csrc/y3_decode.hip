@@ -2,9 +2,11 @@
 //
 // y3_decode replaces the ~60 small TensorFlow ops of yolov3.reorg_layer (model.py:82-137),
 // yolov3.predict (model.py:140-190) and the conf*prob product (test_single_image.py:55) with ONE
-// HBM-bound elementwise pass over the three feature maps: each feature map is a flat array of
-// (N*g*g*3) boxes x (5+C) fields, read once with coalesced 4-byte-per-lane loads (the (5+C)=85
-// record length defeats wider vectors) and written once.
+// HBM-bound pass over the three feature maps: each feature map is a flat array of (N*g*g*3) records x (5+C)
+// fields.  A workgroup stages 64 consecutive records of one (image, scale) in the LDS with 16-byte coalesced loads
+// (the 85-float record is not 16-byte periodic, so the span is read from the enclosing aligned window), then writes
+// boxes / confs / probs / scores with 16-byte stores: the outputs of consecutive records are contiguous, and
+// 16-byte aligned when C % 4 == 0 (decode_staged_kernel; other class counts use the 4-byte-per-lane kernel).
 #include "y3_internal.h"
 
 namespace {
@@ -88,6 +90,91 @@ __global__ void __launch_bounds__(256) decode_kernel(const DecodeArgs a) {
     }
 }
 
+// ---- staged form (C % 4 == 0) --------------------------------------------------------------------------------------
+constexpr int DRPB = 64;                 // records per workgroup
+struct StagedArgs {
+    DecodeArgs d;
+    int chunks_per_img[3];               // ceil(g*g*3 / DRPB)
+    int chunk_end[3];                    // cumulative chunk counts over the scales (all images)
+};
+
+__global__ void __launch_bounds__(256) decode_staged_kernel(const StagedArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [DRPB*F + 8] staged fields, then [DRPB] confs
+    const DecodeArgs& a = sa.d;
+    const int tid = threadIdx.x;
+    int s = 0, ch = blockIdx.x;
+    if (ch >= sa.chunk_end[1]) { s = 2; ch -= sa.chunk_end[1]; }
+    else if (ch >= sa.chunk_end[0]) { s = 1; ch -= sa.chunk_end[0]; }
+    const int cpi = sa.chunks_per_img[s];
+    const int n = ch / cpi, j = ch - n * cpi;
+    const int per_img = a.g_h[s] * a.g_w[s] * 3;
+    const int rec0 = j * DRPB;
+    const int nrec = min(DRPB, per_img - rec0);
+    const int F = a.F, C = a.C;
+    float* conf_s = lds + DRPB * F + 8;
+    // stage: the aligned window around elements [e0, e0 + nrec*F) of fm[s]
+    const long long e0 = ((long long)n * per_img + rec0) * F;
+    const long long a0 = e0 & ~3LL;
+    const int lead = (int)(e0 - a0);
+    const int nf4 = (lead + nrec * F + 3) >> 2;
+    const long long fm_elems = (long long)a.n * per_img * F;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.fm[s] + a0);
+    for (int i = tid; i < nf4; i += 256) {
+        f32x4 v;
+        if (a0 + 4LL * i + 4 <= fm_elems) {
+            v = src[i];
+        } else {                          // the last window of the tensor may end inside a float4
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (a0 + 4LL * i + q < fm_elems) ? a.fm[s][a0 + 4LL * i + q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(lds + 4 * i) = v;
+    }
+    __syncthreads();
+    const float* rec = lds + lead;
+    const size_t ob0 = (size_t)n * a.B + a.box_off[s] + rec0;      // first output box slot of the chunk
+    if (tid < nrec) {
+        const float* r = rec + tid * F;
+        const float conf = sigmoidf_(r[4]);
+        conf_s[tid] = conf;
+        a.confs[ob0 + tid] = conf;
+        const int lb = rec0 + tid;
+        const int anc = lb % 3, cell = lb / 3;
+        const int gy = cell / a.g_w[s], gx = cell - gy * a.g_w[s];
+        // model.py:105-126: (sigmoid + offset) * ratio ; (exp * rescaled_anchor) * ratio
+        const float cx = (sigmoidf_(r[0]) + (float)gx) * a.ratio_w[s];
+        const float cy = (sigmoidf_(r[1]) + (float)gy) * a.ratio_h[s];
+        const float bw = (expf(r[2]) * a.ra_w[s][anc]) * a.ratio_w[s];
+        const float bh = (expf(r[3]) * a.ra_h[s][anc]) * a.ratio_h[s];
+        f32x4 o;                                                    // model.py:182-188
+        o[0] = cx - bw / 2.f;
+        o[1] = cy - bh / 2.f;
+        o[2] = cx + bw / 2.f;
+        o[3] = cy + bh / 2.f;
+        *reinterpret_cast<f32x4*>(a.boxes + (ob0 + tid) * 4) = o;
+    }
+    __syncthreads();
+    // class probabilities (and scores): the chunk's outputs are nrec*C contiguous floats, 16-byte aligned
+    const int nq = nrec * C / 4;
+    f32x4* pout = reinterpret_cast<f32x4*>(a.probs + ob0 * C);
+    f32x4* sout = a.scores ? reinterpret_cast<f32x4*>(a.scores + ob0 * C) : nullptr;
+    for (int q = tid; q < nq; q += 256) {
+        const int e = 4 * q;
+        const int r = e / C, c = e - r * C;
+        const float* f = rec + r * F + 5 + c;
+        f32x4 pr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pr[k] = sigmoidf_(f[k]);
+        pout[q] = pr;
+        if (sout) {
+            const float conf = conf_s[r];
+            f32x4 sc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sc[k] = conf * pr[k];
+            sout[q] = sc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int y3_pack_conv_weights(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout,
@@ -145,6 +232,23 @@ extern "C" int y3_decode(y3_ctx* ctx, const float* fm1, const float* fm2, const 
     }
     a.B = off;
     a.boxes = boxes; a.confs = confs; a.probs = probs; a.scores = scores;
+    const bool aligned = (((uintptr_t)fm1 | (uintptr_t)fm2 | (uintptr_t)fm3 | (uintptr_t)boxes | (uintptr_t)probs |
+                           (uintptr_t)scores) & 15) == 0;
+    if (class_num % 4 == 0 && aligned && class_num <= 1024) {
+        StagedArgs sa;
+        sa.d = a;
+        long long chunks = 0;
+        for (int s = 0; s < 3; ++s) {
+            sa.chunks_per_img[s] = (a.g_h[s] * a.g_w[s] * 3 + DRPB - 1) / DRPB;
+            chunks += (long long)n * sa.chunks_per_img[s];
+            Y3_CHECK_ARG(chunks < (1LL << 31), "y3_decode: too many boxes");
+            sa.chunk_end[s] = (int)chunks;
+        }
+        const size_t lds = (size_t)(DRPB * a.F + 8 + DRPB) * sizeof(float);
+        hipLaunchKernelGGL(decode_staged_kernel, dim3((unsigned)chunks), dim3(256), lds, ctx->stream, sa);
+        Y3_CHECK_HIP(hipGetLastError());
+        return Y3_OK;
+    }
     long long nb = (cum + 255) / 256;
     if (nb > 256 * 16) nb = 256 * 16;
     hipLaunchKernelGGL(decode_kernel, dim3((int)nb), dim3(256), 0, ctx->stream, a);

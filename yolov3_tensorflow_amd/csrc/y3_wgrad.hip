@@ -11,6 +11,8 @@
 // fixed order (deterministic, no float atomics).
 // Tile: 128 (j) x 128 (co), 32 pixels per K-step, 4 waves x (2x2) 32x32 fp32 MFMA tiles — the same
 // matrix-pipe-bound regime as the forward conv (K = M is long, so the prologue/epilogue are negligible).
+#include <cstdlib>
+#include <cmath>
 #include "y3_internal.h"
 
 namespace {
@@ -194,12 +196,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// dw[i] = sum over the splits, in a FIXED order: four lanes per element each add every fourth split (four independent
+// accumulators in flight per lane), then (q0 + q1) + (q2 + q3).  64 elements per workgroup.
 __global__ void __launch_bounds__(256) wgrad_sum_splits_kernel(const float* __restrict__ scratch, int nsplit,
                                                                long long n, float* __restrict__ dw) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+        const long long i = base + e;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += scratch[(size_t)k * n + i];
-        dw[i] = s;
+        if (i < n)
+            for (int k = q; k < nsplit; k += 4) s += scratch[(size_t)k * n + i];
+        part[q][e] = s;
+        __syncthreads();
+        if (q == 0 && i < n) dw[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        __syncthreads();
     }
 }
 
@@ -273,20 +284,43 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
 
 static int wgrad_co_tile(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
 
-// split heuristic: aim at ~1024 workgroups (2 per CU x 2 rounds), at most 512 splits
+// Split choice: the number of pixel-range splits per output tile that minimises a small cost model
+//   rounds(tiles * nsplit over the 512 co-resident workgroups: 256 CUs x 2) x (K-steps per split x t_K + t_fixed)
+//   + the write + read of the nsplit partial tiles.
+// What matters is the FIRST term's quantisation: the previous rule ("about 1024 workgroups") produced e.g. 18 tiles x 57
+// = 1026 workgroups = 2.004 rounds, i.e. three rounds of which the last runs two workgroups.
 static void wgrad_split(const y3_conv_desc* d, int* nsplit_out, int* chunk_out) {
     const long long M = (long long)d->n * (d->h / d->stride) * (d->w / d->stride);
     const int J = d->k * d->k * d->cin;
     const int bnt = wgrad_co_tile(d->cout);
     const int tiles = ((J + 127) / 128) * ((d->cout + bnt - 1) / bnt);
     const int ksteps = (int)((M + WBK - 1) / WBK);
-    int nsplit = (1024 + tiles - 1) / tiles;
-    if (nsplit > 512) nsplit = 512;
-    if (nsplit > ksteps) nsplit = ksteps;
-    if (nsplit < 1) nsplit = 1;
-    const int chunk = ((ksteps + nsplit - 1) / nsplit) * WBK;
-    *chunk_out = chunk;
-    *nsplit_out = (int)((M + chunk - 1) / chunk);
+    constexpr double SLOTS = 512.0;            // co-resident workgroups
+    constexpr double T_K = 3.9, T_FIX = 6.0;   // us per K-step with two workgroups per CU; prologue + epilogue
+    const double partial_us = 2.0 * (double)J * d->cout * 4.0 / 3.0e6;   // one partial tile set written + read at ~3 TB/s
+    if (const char* e = getenv("Y3_WGRAD_OLD_SPLIT"); e && e[0] == '1') {   // experiment hook: the round-1 rule
+        int nsplit = (1024 + tiles - 1) / tiles;
+        if (nsplit > 512) nsplit = 512;
+        if (nsplit > ksteps) nsplit = ksteps;
+        if (nsplit < 1) nsplit = 1;
+        const int chunk = ((ksteps + nsplit - 1) / nsplit) * WBK;
+        *chunk_out = chunk;
+        *nsplit_out = (int)((M + chunk - 1) / chunk);
+        return;
+    }
+    int best_ns = 1, best_chunk = ksteps;
+    double best = 1e300;
+    const int ns_max = ksteps < 512 ? ksteps : 512;
+    for (int ns = 1; ns <= ns_max; ++ns) {
+        const int chunk = (ksteps + ns - 1) / ns;
+        const int real = (ksteps + chunk - 1) / chunk;          // splits that actually get pixels
+        if (real != ns) continue;
+        const double rounds = ceil((double)tiles * real / SLOTS);
+        const double t = rounds * (chunk * T_K + T_FIX) + (real > 1 ? real * partial_us : 0.0);
+        if (t < best) { best = t; best_ns = real; best_chunk = chunk; }
+    }
+    *chunk_out = best_chunk * WBK;
+    *nsplit_out = best_ns;
 }
 
 extern "C" size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* d) {
@@ -353,8 +387,8 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     Y3_CHECK_HIP(hipGetLastError());
     if (nsplit > 1) {
         const long long n = (long long)a.J * a.Cout;
-        long long nb = (n + 255) / 256;
-        if (nb > 4096) nb = 4096;
+        long long nb = (n + 63) / 64;
+        if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3((int)nb), dim3(256), 0, st, static_cast<float*>(scratch),
                            nsplit, n, dw_hwio);
         Y3_CHECK_HIP(hipGetLastError());

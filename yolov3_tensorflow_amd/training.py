@@ -5,6 +5,7 @@ Python here only sequences C-ABI calls over caller-owned device buffers (torch =
 every number is produced by a HIP kernel of csrc/y3_train.hip, y3_wgrad.hip or y3_conv.hip.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -517,6 +518,19 @@ class Trainer(object):
             lr = lr * np.sqrt(1.0 - self.opt.beta2 ** t) / (1.0 - self.opt.beta1 ** t)
         decay = self.opt.beta1 if self.opt.kind == 'adam' else self.opt.decay
         st = _train_state(self.model)
+        if os.environ.get('Y3_TRAIN_PER_TENSOR_UPDATE') == '1':     # experiment hook: one y3_clip_update per variable
+            sc = _scratch(st, 'opt', L.y3_optimizer_scratch_bytes(), dev)
+            for v in self.order:
+                s0, s1 = self.opt._slots_for(v)
+                wd = float(self.model.weight_decay) if v.op_name.endswith('/weights') else 0.0
+                _lib.check(L.y3_clip_update(ctx, kind, fw.ptr(v.tensor), fw.ptr(self.views[v.op_name]), fw.ptr(s0),
+                                            fw.ptr(s1), v.tensor.numel(), ctypes.c_float(wd), ctypes.c_float(1.0 / world),
+                                            ctypes.c_float(self.clip_norm), ctypes.c_float(lr),
+                                            ctypes.c_float(self.opt.momentum), ctypes.c_float(decay),
+                                            ctypes.c_float(self.opt.beta2), ctypes.c_float(self.opt.epsilon), fw.ptr(sc)))
+                v.touch()
+            self.global_step += 1.0
+            return
         # ONE multi-tensor call (three launches) for every (gradient, variable) pair of train.py:112-115
         descs, keep = self._param_descs()
         nbytes = L.y3_clip_update_multi_scratch_bytes(descs, len(self.order))
