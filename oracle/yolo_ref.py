@@ -293,7 +293,7 @@ _RESIDUAL_CLOSERS = _residual_closers()
 
 def synthetic_params(class_num=80, seed=1, prefix='yolov3'):
     """SURVEY.md §8(d) C2 synthetic weights: He-normal kernels, BN gamma~U(.8,1.2), beta~N(0,.05),
-    mean~N(0,.05), var~U(.8,1.2); detection biases: conf channel -9.0 (logit std is ~2.7), others N(0,.1).
+    mean~N(0,.05), var~U(.8,1.2); detection biases: conf channel -4.0, others N(0,.1).
     Two dampings keep activations and logits O(1) (documented in DESIGN.md): residual-branch gamma x0.25,
     detection kernels x0.25."""
     rng = np.random.RandomState(seed)

@@ -610,34 +610,48 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 // dgrad != 0: (cin, cout) are those of the GRADIENT conv (cin = dz channels, cout = the forward layer's Cin) and w is
 // the forward kernel stored [3*3][cout][cin] (= [tap][fwd Cin][dz_stride]); the gradient conv's kernel is the forward
 // one with its taps flipped and its channel axes swapped: g'[a][b](ci, co) = w[(2-a, 2-b)][co][ci].
-__global__ void pack_weights_wino_kernel(const float* __restrict__ w_hwio, float* __restrict__ out, int cin, int cout,
-                                         int dgrad) {
-    const size_t total = (size_t)cin * cout;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i / cout), co = (int)(i % cout);
-        float g[3][3];
+// A workgroup owns one K-step slab (8 input channels) x 32 output channels: the nine taps go through the LDS so that
+// both the reads (runs along the source's contiguous axis) and the writes (1 KB contiguous per transform position:
+// [co][8]) are coalesced — the training step re-packs the forward and the data-gradient kernels of 32 layers every step.
+__global__ void __launch_bounds__(256) pack_weights_wino_kernel(const float* __restrict__ w_hwio, float* __restrict__ out,
+                                                                int cin, int cout, int dgrad) {
+    __shared__ float g[9][WKC][33];
+    const int tid = threadIdx.x;
+    const int ncb = (cout + 31) / 32;
+    const int kb = blockIdx.x / ncb, cb = blockIdx.x - kb * ncb;      // K-step slab, 32-channel column block
+    const int ci0 = kb * WKC, co0 = cb * 32;
+    if (!dgrad) {            // source [tap][cin][cout]: 32 consecutive co per (tap, ci)
+        const int col = tid & 31, cil = tid >> 5;
+        const bool ok = co0 + col < cout && ci0 + cil < cin;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int t = 0; t < 9; ++t)
+            g[t][cil][col] = ok ? w_hwio[((size_t)t * cin + ci0 + cil) * cout + co0 + col] : 0.f;
+    } else {                 // source [tap][cout][cin], taps flipped: 8 consecutive ci per (tap, co)
+        const int cil = tid & 7, col = tid >> 3;
+        const bool ok = co0 + col < cout && ci0 + cil < cin;
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-                g[a][b] = dgrad ? w_hwio[((size_t)((2 - a) * 3 + (2 - b)) * cout + co) * cin + ci]
-                                : w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
-        float t[4][3];
+        for (int t = 0; t < 9; ++t)
+            g[t][cil][col] = ok ? w_hwio[((size_t)(8 - t) * cout + co0 + col) * cin + ci0 + cil] : 0.f;
+    }
+    __syncthreads();
+    const int cil = tid & 7, col = tid >> 3;           // writer: (channel-in-slab fastest, then co) = the packed order
+    if (co0 + col >= cout || ci0 + cil >= cin) return;
+    float t[4][3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            t[0][b] = g[0][b];
-            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-            t[3][b] = g[2][b];
-        }
+    for (int b = 0; b < 3; ++b) {
+        const float g0 = g[0 * 3 + b][cil][col], g1 = g[1 * 3 + b][cil][col], g2 = g[2 * 3 + b][cil][col];
+        t[0][b] = g0;
+        t[1][b] = 0.5f * (g0 + g1 + g2);
+        t[2][b] = 0.5f * (g0 - g1 + g2);
+        t[3][b] = g2;
+    }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]),
-                                t[a][2]};
+    for (int a = 0; a < 4; ++a) {
+        const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                            t[a][2]};
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                out[(((size_t)(a * 4 + b) * (cin / WKC) + ci / WKC) * cout + co) * WKC + (ci % WKC)] = u[b];
-        }
+        for (int b = 0; b < 4; ++b)
+            out[(((size_t)(a * 4 + b) * (cin / WKC) + kb) * cout + co0 + col) * WKC + cil] = u[b];
     }
 }
 
@@ -653,8 +667,7 @@ int y3_conv_wino_eligible_impl(const y3_conv_desc* d) {
 }
 
 int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out, int dgrad) {
-    const size_t total = (size_t)cin * cout;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int blocks = (cin / WKC) * ((cout + 31) / 32);       // cin % 8 == 0 (checked by the callers)
     hipLaunchKernelGGL(pack_weights_wino_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout, dgrad);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;

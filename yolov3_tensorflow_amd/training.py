@@ -393,8 +393,17 @@ class Trainer(object):
                 cap.append(dict(layer=i, z=rec.get('z'), stats=rec.get('stats')))
             if l['bn']:
                 rows = dy.numel() // cout
+                dz_out = dy                       # BN backward runs in place ...
                 if l['resid'] >= 0 and needs(l['resid']):
-                    accumulate_into(l['resid'], dy, cout, 0, cout)
+                    if l['resid'] in have:
+                        accumulate_into(l['resid'], dy, cout, 0, cout)
+                    else:
+                        # ... unless dy is also the first contribution to the shortcut's gradient (res_block: net +
+                        # shortcut, utils/layer_utils.py:30): then dy itself becomes that gradient (no copy) and the
+                        # BN backward writes dz elsewhere
+                        grads[l['resid']] = dy
+                        have.add(l['resid'])
+                        dz_out = torch.empty_like(dy)
                 gamma, beta = bnv[0], bnv[1]
                 stats = rec['stats']
                 tmp = torch.empty((2, cout), dtype=torch.float32, device=dev)
@@ -404,8 +413,8 @@ class Trainer(object):
                 _lib.check(L.y3_bn_train_bwd(ctx, fw.ptr(rec['z']), fw.ptr(dy), fw.ptr(gamma.tensor),
                                              fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(stats[0]), fw.ptr(stats[1]),
                                              rows, cout, fw.ptr(dgam if dgam is not None else tmp[0]),
-                                             fw.ptr(dbet if dbet is not None else tmp[1]), fw.ptr(dy), fw.ptr(sc)))
-                dz, dz_stride, w_d = dy, cout, wvar.tensor
+                                             fw.ptr(dbet if dbet is not None else tmp[1]), fw.ptr(dz_out), fw.ptr(sc)))
+                dz, dz_stride, w_d = dz_out, cout, wvar.tensor
             else:
                 dz_stride = int(dy.shape[-1])
                 rows = dy.numel() // dz_stride
