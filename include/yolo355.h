@@ -279,6 +279,15 @@ int y3_conv2d_dgrad_wino(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, 
 size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* fwd);
 int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,
                   float* dw_hwio, void* scratch, size_t scratch_bytes);
+/* The weight gradient of a stride-1 3x3 conv in Winograd F(2x2,3x3) form (Cin %% 64 == 0, Cout %% 64 == 0):
+ *   dw = G^T [ sum over 2x2 output tiles of (B^T d B) .* (A dY A^T) ] G,
+ * exact fp32 arithmetic with 16/36 of the multiplies of y3_conv_wgrad; results differ from it by a few fp32 roundings
+ * per term; deterministic (the tile range is split over workgroups, partial kernels are added in a fixed order).
+ * scratch: y3_conv_wgrad_wino_scratch_bytes(fwd). */
+int y3_conv_wgrad_wino_eligible(const y3_conv_desc* fwd);
+size_t y3_conv_wgrad_wino_scratch_bytes(const y3_conv_desc* fwd);
+int y3_conv_wgrad_wino(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,
+                       float* dw_hwio, void* scratch, size_t scratch_bytes);
 /* backward routing: 2x2 sum of the gradient of a nearest-upsampled tensor (g has g_channels per pixel, the
  * first c belong to the upsampled part), channel-slice (accumulate), zero-extension of the channel axis */
 int y3_upsample2x_bwd(y3_ctx* ctx, const float* g, int g_channels, int n, int h, int w, int c, int accumulate,

@@ -100,6 +100,63 @@ def test_conv_wgrad_and_dgrad_match_autograd(n, h, w, k, stride, cin, cout):
                                               fw.ptr(zeros), 0, fw.ptr(dx), None, ctypes.c_size_t(0)))
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout', [
+    (2, 20, 28, 64, 128),      # even map, several K-steps, two column blocks
+    (1, 13, 13, 128, 64),      # odd map: the last tile row / column has outputs that do not exist
+    (3, 7, 5, 64, 64),         # tiny odd map, T = 36 tiles: a partial last K-step
+    (2, 26, 26, 256, 128),     # 8 workgroup tiles x 32 splits
+    (1, 2, 2, 64, 64),         # one tile per image
+    (8, 52, 52, 128, 256),     # a real layer shape (52-grid residual stage) at bs=8: 676 K-steps over 32 splits
+])
+def test_winograd_weight_gradient_matches_autograd(n, h, w, cin, cout):
+    """y3_conv_wgrad_wino: dw = G^T [ sum over tiles (B^T d B) .* (A dY A^T) ] G against fp64 autograd (ref: train.py:112,
+    the kernel gradients of utils/layer_utils.py:9-22) at the direct weight-gradient kernel's tolerance (2e-4 of the
+    tensor's max), run-to-run bit-exact, and interchangeable with y3_conv_wgrad."""
+    fw, _lib, L, ctx = _ctx()
+    dev = fw.default_device()
+    rng = np.random.RandomState(cin + cout + h)
+    x = torch.tensor(rng.standard_normal((n, h, w, cin)), dtype=torch.float64)
+    wt = torch.zeros((3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    z = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), padding=1)
+    dz = rng.standard_normal((n, h, w, cout))
+    z.backward(torch.tensor(dz).permute(0, 3, 1, 2))
+    want = wt.grad.numpy()
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 0)
+    assert L.y3_conv_wgrad_wino_eligible(ctypes.byref(d)) == 1
+    xg = torch.tensor(x.numpy(), dtype=torch.float32, device=dev)
+    dzg = torch.tensor(dz, dtype=torch.float32, device=dev)
+    sc = torch.empty(L.y3_conv_wgrad_wino_scratch_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((3, 3, cin, cout), float('nan'), device=dev)
+        _lib.check(L.y3_conv_wgrad_wino(ctx, ctypes.byref(d), fw.ptr(xg), fw.ptr(dzg), cout, fw.ptr(dw), fw.ptr(sc),
+                                        ctypes.c_size_t(sc.numel())))
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]), 'not run-to-run bit-exact'
+    e = rel_err(outs[0].cpu().numpy(), want)
+    assert e < 2e-4, 'Winograd wgrad rel err %.3e' % e
+    # the direct kernel on the same operands: the two must agree to the same tolerance
+    dw2 = torch.empty((3, 3, cin, cout), device=dev)
+    sc2 = torch.empty(L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
+    _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xg), fw.ptr(dzg), cout, fw.ptr(dw2), fw.ptr(sc2),
+                               ctypes.c_size_t(sc2.numel())))
+    assert rel_err(outs[0].cpu().numpy(), dw2.cpu().numpy()) < 2e-4
+    # a padded dz row stride (the detection convs pad 255 -> 256; here 3x3 layers with extra columns)
+    dzp = torch.zeros((n, h, w, cout + 32), dtype=torch.float32, device=dev)
+    dzp[..., :cout] = dzg
+    dw3 = torch.empty((3, 3, cin, cout), device=dev)
+    _lib.check(L.y3_conv_wgrad_wino(ctx, ctypes.byref(d), fw.ptr(xg), fw.ptr(dzp), cout + 32, fw.ptr(dw3), fw.ptr(sc),
+                                    ctypes.c_size_t(sc.numel())))
+    assert torch.equal(dw3, outs[0])
+    # shapes the kernel does not take are refused, not mangled
+    for bad in (_lib.ConvDesc(n, h, w, 32, 0, cout, 3, 1, 0), _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 2, 0),
+                _lib.ConvDesc(n, h, w, cin, 0, cout, 1, 1, 0)):
+        assert L.y3_conv_wgrad_wino_eligible(ctypes.byref(bad)) == 0
+        with pytest.raises(ValueError):
+            _lib.check(L.y3_conv_wgrad_wino(ctx, ctypes.byref(bad), fw.ptr(xg), fw.ptr(dzg), cout, fw.ptr(dw3), fw.ptr(sc),
+                                            ctypes.c_size_t(sc.numel())))
+
+
 @pytest.mark.parametrize('rows,c', [(2 * 13 * 13, 1024), (3 * 20 * 28, 64), (5000, 32), (64, 256)])
 def test_bn_train_forward_backward(rows, c):
     fw, _lib, L, ctx = _ctx()

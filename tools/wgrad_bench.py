@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--wino', action='store_true', help='y3_conv_wgrad_wino for the shapes it takes')
     a = ap.parse_args()
     import torch
     from yolov3_tensorflow_amd import framework as fw, _lib
@@ -34,9 +35,12 @@ def main():
         dz = torch.randn((n, ho, ho, cout), device=dev)
         d = _lib.ConvDesc(n, hw, hw, cin, 0, cout, k, s, 0)
         dw = torch.empty((k, k, cin, cout), device=dev)
-        sc = torch.empty(L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
-        run = lambda: _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(x), fw.ptr(dz), cout, fw.ptr(dw), fw.ptr(sc),
-                                                 ctypes.c_size_t(sc.numel())))
+        wino = a.wino and L.y3_conv_wgrad_wino_eligible(ctypes.byref(d)) == 1
+        nbytes = (L.y3_conv_wgrad_wino_scratch_bytes if wino else L.y3_conv_wgrad_scratch_bytes)(ctypes.byref(d))
+        sc = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        fn = L.y3_conv_wgrad_wino if wino else L.y3_conv_wgrad
+        run = lambda: _lib.check(fn(ctx, ctypes.byref(d), fw.ptr(x), fw.ptr(dz), cout, fw.ptr(dw), fw.ptr(sc),
+                                    ctypes.c_size_t(sc.numel())))
         for _ in range(2):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +51,8 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         flop = 2.0 * k * k * cin * cout * ho * ho * n
-        print('wgrad k%d s%d %4d->%4d @%3d bs%d: %.3f ms  %.1f TF/s  (x%d in the net)' % (k, s, cin, cout, hw, n, ms, flop / ms / 1e9, cnt))
+        print('wgrad k%d s%d %4d->%4d @%3d bs%d: %.3f ms  %.1f TF/s  (x%d in the net)%s' % (
+            k, s, cin, cout, hw, n, ms, flop / ms / 1e9, cnt, '  [Winograd: TF/s counted as direct-algorithm FLOPs]' if wino else ''))
         tot_ms += ms * cnt
         tot_flop += flop * cnt
     print('weighted: %.2f ms for %d layers, %.1f TF/s [old split %s]' % (

@@ -88,6 +88,9 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_size_t]),
     "y3_conv_wgrad_scratch_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv_wgrad": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
+    "y3_conv_wgrad_wino_eligible": (c_int, [POINTER(ConvDesc)]),
+    "y3_conv_wgrad_wino_scratch_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "y3_conv_wgrad_wino": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
     "y3_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_slice_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_int, c_void_p]),
     "y3_pad_channels": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p]),

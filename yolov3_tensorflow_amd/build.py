@@ -25,6 +25,7 @@ SOURCES = [
     ("y3_ops.hip", ["-ffp-contract=off"]),
     ("y3_train.hip", ["-ffp-contract=off"]),
     ("y3_wgrad.hip", []),
+    ("y3_wgrad_wino.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 COMMON += os.environ.get("Y3_EXTRA_HIPCC_FLAGS", "").split()   # experiment hook (e.g. -DY3_EXP=1)

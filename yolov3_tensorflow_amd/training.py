@@ -431,10 +431,19 @@ class Trainer(object):
             d = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), int(xin.shape[3]), 0, cout, l['k'],
                               l['stride'], 0)
             if self._trainable(wvar):
-                wsb = L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d))
-                sc = _scratch(st, 'wgrad', wsb, dev)
-                _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
-                                           fw.ptr(self.views[wvar.op_name]), fw.ptr(sc), ctypes.c_size_t(sc.numel())))
+                # compute_dtype 'f32_wino': the stride-1 3x3 kernels' gradients in Winograd form too (16/36 of the MFMA work)
+                if (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and
+                        L.y3_conv_wgrad_wino_eligible(ctypes.byref(d)) == 1):
+                    sc = _scratch(st, 'wgrad_wino', L.y3_conv_wgrad_wino_scratch_bytes(ctypes.byref(d)), dev)
+                    _lib.check(L.y3_conv_wgrad_wino(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
+                                                    fw.ptr(self.views[wvar.op_name]), fw.ptr(sc),
+                                                    ctypes.c_size_t(sc.numel())))
+                else:
+                    wsb = L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d))
+                    sc = _scratch(st, 'wgrad', wsb, dev)
+                    _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
+                                               fw.ptr(self.views[wvar.op_name]), fw.ptr(sc),
+                                               ctypes.c_size_t(sc.numel())))
             if i in self.layer_ends:      # this layer's gradients are complete: reduce every bucket below its edge
                 self.exchange.ready(self.layer_ends[i])
             src, up = l['src'], l['up']
