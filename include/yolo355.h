@@ -279,7 +279,8 @@ int y3_conv2d_dgrad_wino(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, 
 size_t y3_conv_wgrad_scratch_bytes(const y3_conv_desc* fwd);
 int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,
                   float* dw_hwio, void* scratch, size_t scratch_bytes);
-/* The weight gradient of a stride-1 3x3 conv in Winograd F(2x2,3x3) form (Cin %% 64 == 0, Cout %% 64 == 0):
+/* The weight gradient of a stride-1 3x3 conv in Winograd F(2x2,3x3) form (Cin %% 64 == 0, Cout %% 64 == 0, at least
+ * 8 / ceil(w/2) + 1 rows of 2x2 tiles per image — y3_conv_wgrad_wino_eligible says):
  *   dw = G^T [ sum over 2x2 output tiles of (B^T d B) .* (A dY A^T) ] G,
  * exact fp32 arithmetic with 16/36 of the multiplies of y3_conv_wgrad; results differ from it by a few fp32 roundings
  * per term; deterministic (the tile range is split over workgroups, partial kernels are added in a fixed order).

@@ -105,7 +105,7 @@ def test_conv_wgrad_and_dgrad_match_autograd(n, h, w, k, stride, cin, cout):
     (1, 13, 13, 128, 64),      # odd map: the last tile row / column has outputs that do not exist
     (3, 7, 5, 64, 64),         # tiny odd map, T = 36 tiles: a partial last K-step
     (2, 26, 26, 256, 128),     # 8 workgroup tiles x 32 splits
-    (1, 2, 2, 64, 64),         # one tile per image
+    (2, 16, 4, 64, 64),        # two tile columns: a K-step advances four tile rows
     (8, 52, 52, 128, 256),     # a real layer shape (52-grid residual stage) at bs=8: 676 K-steps over 32 splits
 ])
 def test_winograd_weight_gradient_matches_autograd(n, h, w, cin, cout):
@@ -150,7 +150,7 @@ def test_winograd_weight_gradient_matches_autograd(n, h, w, cin, cout):
     assert torch.equal(dw3, outs[0])
     # shapes the kernel does not take are refused, not mangled
     for bad in (_lib.ConvDesc(n, h, w, 32, 0, cout, 3, 1, 0), _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 2, 0),
-                _lib.ConvDesc(n, h, w, cin, 0, cout, 1, 1, 0)):
+                _lib.ConvDesc(n, h, w, cin, 0, cout, 1, 1, 0), _lib.ConvDesc(n, 2, 2, cin, 0, cout, 3, 1, 0)):
         assert L.y3_conv_wgrad_wino_eligible(ctypes.byref(bad)) == 0
         with pytest.raises(ValueError):
             _lib.check(L.y3_conv_wgrad_wino(ctx, ctypes.byref(bad), fw.ptr(xg), fw.ptr(dzg), cout, fw.ptr(dw3), fw.ptr(sc),

@@ -31,6 +31,7 @@ struct WgWinoArgs {
     float* out;         // nsplit == 1: dW [9][Cin][Cout]; else scratch [nsplit][9][Cin][Cout]
     int N, H, W, Cin, Cout, CoP;
     int TH, TW, T;      // 2x2 tiles per image column / row, and in total
+    int adv_r, adv_c;   // 8 tiles further = adv_r tile rows + adv_c tile columns (8 / TW, 8 % TW); adv_r + 1 <= TH
     int ksteps;         // K-steps (8 tiles) per split
     int nsplit;
 };
@@ -41,14 +42,6 @@ constexpr int WROW = 32;                       // LDS bytes per (position, chann
 constexpr int PLANE = 64 * WROW;               // bytes per transform position (64 channels)
 constexpr int STAGE = 16 * PLANE;              // one operand, one stage
 
-// t / d for 0 <= t < 2^24 and a quotient below 2^20 (as in y3_conv_wino.hip): float reciprocal + correction
-__device__ __forceinline__ int fastdiv(int t, int d) {
-    int q = (int)((float)t * __frcp_rn((float)d));
-    const int r = t - q * d;
-    q += (r >= d) ? 1 : 0;
-    q -= (r < 0) ? 1 : 0;
-    return q;
-}
 // byte offset of tile pair `pair` (0..3) inside row `ch`
 __device__ __forceinline__ int row_off(int ch, int pair) { return ch * WROW + (((pair + (ch >> 2)) & 3) << 3); }
 
@@ -116,18 +109,32 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
     // a uniform `?:` becomes a real branch in hipcc's output and would cut the K-step into dozens of basic blocks.
     const unsigned ci_b = (unsigned)(cb * 64 + lane) * 4u, co_b = (unsigned)(ob * 64 + lane) * 4u;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int thtw = p.TH * p.TW;
+    // tile coordinates of this wave's two tiles: integer divisions once, then advanced by 8 tiles per K-step with
+    // compare + select (no division, no vector ALU, no branch in the K-loop)
+    int tn[2], tty[2], ttx[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int t = ks_begin * 8 + wv * 2 + e;
+        tn[e] = t / (p.TH * p.TW);
+        const int rem = t - tn[e] * p.TH * p.TW;
+        tty[e] = rem / p.TW;
+        ttx[e] = rem - tty[e] * p.TW;
+    }
     float rd[2][16], ry[2][4];
-    auto issue = [&](int ks) {
+    auto issue = [&]() {        // loads of the K-step the tile coordinates point at; then advance them by 8 tiles
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int t = ks * 8 + wv * 2 + e;
-            const bool tok = t < p.T;                             // tiles past the end (last K-step) read zeros
-            const int tq = min(t, p.T - 1);
-            const int n = __builtin_amdgcn_readfirstlane(fastdiv(tq, thtw));
-            const int rem = tq - n * thtw;
-            const int ty = __builtin_amdgcn_readfirstlane(fastdiv(rem, p.TW));
-            const int tx = rem - ty * p.TW;
+            const int n = tn[e], ty = tty[e], tx = ttx[e];
+            const bool tok = n < p.N;                             // tiles past the end (last K-step) read zeros
+            {
+                int x = tx + p.adv_c;
+                const int c1 = (int)(x >= p.TW);
+                x -= p.TW & -c1;
+                int y = ty + p.adv_r + c1;
+                const int c2 = (int)(y >= p.TH);
+                y -= p.TH & -c2;
+                ttx[e] = x; tty[e] = y; tn[e] = n + c2;
+            }
             const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
             // Per patch row / column: its byte offset (scalar) and 0 or OOB (scalar) for "no such pixel".  An invalid
             // pixel sets the top bit of the VGPR offset, which alone fails the buffer's range check (the scalar offset
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
         }
     };
 
-    issue(ks_begin);
+    issue();
     store(0);
     __syncthreads();
     for (int ks = ks_begin; ks + 1 < ks_end; ++ks) {
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
         //   group 3: 16 x (MFMA, LDS write) — the transforms float in front of the writes
         // (the ~170 scalar / vector instructions of the address arithmetic stay ahead of the first MFMA: SALU / VALU
         // groups in this list were tried and made hipcc bunch the MFMAs instead)
-        issue(ks + 1);
+        issue();
         compute(cur);
         store(cur ^ 1);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                 // fragments of group 0
@@ -334,8 +341,12 @@ void wgw_split(const y3_conv_desc* d, int* nsplit, int* ksteps) {
 }  // namespace
 
 int y3_conv_wgrad_wino_eligible_impl(const y3_conv_desc* d) {
-    return d && d->k == 3 && d->stride == 1 && d->c_up == 0 && d->cin % 64 == 0 && d->cout % 64 == 0 && d->n > 0 &&
-           d->h > 1 && d->w > 1;
+    if (!(d && d->k == 3 && d->stride == 1 && d->c_up == 0 && d->cin % 64 == 0 && d->cout % 64 == 0 && d->n > 0 &&
+          d->h > 1 && d->w > 1))
+        return 0;
+    // the K-loop advances its tile coordinates by 8 tiles with one wrap per axis: 8 / TW + 1 tile rows must fit an image
+    const int th = (d->h + 1) / 2, tw = (d->w + 1) / 2;
+    return 8 / tw + 1 <= th;
 }
 
 size_t y3_conv_wgrad_wino_scratch_bytes_impl(const y3_conv_desc* d) {
@@ -349,7 +360,8 @@ int y3_launch_conv_wgrad_wino(hipStream_t stream, const y3_conv_desc* d, const f
                               float* dw_hwio, void* scratch, size_t scratch_bytes) {
     Y3_CHECK_ARG(d && x && dz && dw_hwio && scratch, "y3_conv_wgrad_wino: null argument");
     Y3_CHECK_ARG(y3_conv_wgrad_wino_eligible_impl(d),
-                 "y3_conv_wgrad_wino: needs a 3x3 stride-1 conv with Cin %% 64 == 0 and Cout %% 64 == 0");
+                 "y3_conv_wgrad_wino: needs a 3x3 stride-1 conv with Cin %% 64 == 0, Cout %% 64 == 0 and a map of at least "
+                 "8 / ceil(w/2) + 1 tile rows (y3_conv_wgrad_wino_eligible)");
     Y3_CHECK_ARG(dz_stride >= d->cout, "y3_conv_wgrad_wino: dz row stride must be >= Cout");
     Y3_CHECK_ARG(scratch_bytes >= y3_conv_wgrad_wino_scratch_bytes_impl(d), "y3_conv_wgrad_wino: scratch too small");
     const long long M = (long long)d->n * d->h * d->w;
@@ -359,6 +371,7 @@ int y3_launch_conv_wgrad_wino(hipStream_t stream, const y3_conv_desc* d, const f
     a.x = x; a.dz = dz;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.CoP = dz_stride;
     a.TH = (d->h + 1) / 2; a.TW = (d->w + 1) / 2; a.T = d->n * a.TH * a.TW;
+    a.adv_r = 8 / a.TW; a.adv_c = 8 % a.TW;
     Y3_CHECK_ARG(a.T < (1 << 24), "y3_conv_wgrad_wino: too many tiles");
     wgw_split(d, &a.nsplit, &a.ksteps);
     a.out = a.nsplit == 1 ? dw_hwio : static_cast<float*>(scratch);
