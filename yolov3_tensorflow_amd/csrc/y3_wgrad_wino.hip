@@ -120,12 +120,16 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
         tty[e] = rem / p.TW;
         ttx[e] = rem - tty[e] * p.TW;
     }
-    float rd[2][16], ry[2][4];
-    auto issue = [&]() {        // loads of the K-step the tile coordinates point at; then advance them by 8 tiles
+    const unsigned cin4 = (unsigned)p.Cin * 4u, cop4 = (unsigned)p.CoP * 4u, wcin4 = (unsigned)p.W * cin4,
+                   wcop4 = (unsigned)p.W * cop4;
+    // Two register sets: the loads of K-step s+2 are issued during K-step s and consumed (transform + LDS writes) at the
+    // end of K-step s+1 — a whole K-step (~5k cycles) of latency cover; the accumulators live in AGPRs, so the VGPRs are there.
+    float rdA[2][16], ryA[2][4], rdB[2][16], ryB[2][4];
+    auto issue = [&](float (&rd)[2][16], float (&ry)[2][4]) {   // loads of the K-step the tile coordinates point at; then advance
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int n = tn[e], ty = tty[e], tx = ttx[e];
-            const bool tok = n < p.N;                             // tiles past the end (last K-step) read zeros
+            const bool tok = n < p.N;                             // tiles past the end read zeros
             {
                 int x = tx + p.adv_c;
                 const int c1 = (int)(x >= p.TW);
@@ -135,23 +139,25 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
                 y -= p.TH & -c2;
                 ttx[e] = x; tty[e] = y; tn[e] = n + c2;
             }
-            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+            // (a tile past the end gets a row coordinate no image has: every patch row fails the range test below)
+            const int y0 = (2 * ty - 1) | (0x40000000 & -(int)!tok), x0 = 2 * tx - 1;
             // Per patch row / column: its byte offset (scalar) and 0 or OOB (scalar) for "no such pixel".  An invalid
             // pixel sets the top bit of the VGPR offset, which alone fails the buffer's range check (the scalar offset
             // is not part of that check), so the load returns 0 whatever its scalar offset is.
             // (readfirstlane: hipcc evaluates these uniform compares on the vector ALU and would then wrap every load
             // in a waterfall loop to get its scalar offset.)
             unsigned rowx[4], colx[4], rowz[4], colz[4], rowb[4], colb[4];
+            const unsigned ro = (unsigned)((n * p.H + y0) * p.W), cx = (unsigned)x0;      // may wrap: masked below
+            rowx[0] = ro * cin4; colx[0] = cx * cin4; rowz[0] = ro * cop4; colz[0] = cx * cop4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 rowb[i] = (unsigned)__builtin_amdgcn_readfirstlane(
-                    (int)(OOB & (0u - (unsigned)(!tok | ((unsigned)(y0 + i) >= (unsigned)p.H)))));
+                    (int)(OOB & (0u - (unsigned)((unsigned)(y0 + i) >= (unsigned)p.H))));
                 colb[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)(OOB & (0u - (unsigned)((unsigned)(x0 + i) >= (unsigned)p.W))));
-                const unsigned ro = (unsigned)((n * p.H + y0 + i) * p.W), cx = (unsigned)(x0 + i);
-                rowx[i] = ro * (unsigned)(p.Cin * 4);
-                colx[i] = cx * (unsigned)(p.Cin * 4);
-                rowz[i] = ro * (unsigned)(p.CoP * 4);
-                colz[i] = cx * (unsigned)(p.CoP * 4);
+                if (i > 0) {
+                    rowx[i] = rowx[i - 1] + wcin4; colx[i] = colx[i - 1] + cin4;
+                    rowz[i] = rowz[i - 1] + wcop4; colz[i] = colz[i - 1] + cop4;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
         }
     };
     const int st_off = row_off(lane, wave);       // this thread's 8-byte slot inside a (position, channel) row
-    auto store = [&](int buf) {
+    auto store = [&](int buf, const float (&rd)[2][16], const float (&ry)[2][4]) {
         float va[16], vb[16];
         input_transform(rd[0], va);
         input_transform(rd[1], vb);
@@ -222,23 +228,20 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
         }
     };
 
-    issue();
-    store(0);
-    __syncthreads();
-    for (int ks = ks_begin; ks + 1 < ks_end; ++ks) {
-        const int cur = (ks - ks_begin) & 1;
-        // One basic block per K-step: 64 MFMAs | 40 loads of K-step ks+1 (+ their scalar address arithmetic) | 32 fragment
-        // reads | the four transforms + 16 LDS writes (ks+1) into the other stage.  The hints pin the classes that have a
-        // natural place (position group g = 16 MFMAs):
-        //   group 0: 16 x (MFMA, load), the fragments of group 1 behind the last 8
-        //   group 1: 16 x (MFMA, load), the fragments of group 2 behind the last 8
-        //   group 2:  8 x (MFMA, load), 8 x (MFMA, fragment read of group 3)
-        //   group 3: 16 x (MFMA, LDS write) — the transforms float in front of the writes
-        // (the ~170 scalar / vector instructions of the address arithmetic stay ahead of the first MFMA: SALU / VALU
-        // groups in this list were tried and made hipcc bunch the MFMAs instead)
-        issue();
+    // One K-step = one basic block: 64 MFMAs on stage `cur` | the 40 loads of K-step ks+2 into `ld` (+ their scalar
+    // address arithmetic) | 32 fragment reads | transforms + 16 LDS writes of K-step ks+1 (registers `use`, loaded one
+    // K-step ago) into the other stage.  The hints pin the classes that have a natural place (position group = 16 MFMAs):
+    //   group 0: 16 x (MFMA, load), the fragments of group 1 behind the last 8
+    //   group 1: 16 x (MFMA, load), the fragments of group 2 behind the last 8
+    //   group 2:  8 x (MFMA, load), 8 x (MFMA, fragment read of group 3)
+    //   group 3: 16 x (MFMA, LDS write) — the transforms float in front of the writes
+    // (the ~150 scalar instructions of the address arithmetic stay ahead of the first MFMA: SALU / VALU groups in this list
+    // were tried and made hipcc bunch the MFMAs instead)
+    auto kstep = [&](int cur, float (&ld_d)[2][16], float (&ld_y)[2][4], const float (&use_d)[2][16],
+                     const float (&use_y)[2][4]) {
+        issue(ld_d, ld_y);
         compute(cur);
-        store(cur ^ 1);
+        store(cur ^ 1, use_d, use_y);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                 // fragments of group 0
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -270,8 +273,25 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __syncthreads();
+    };
+
+    issue(rdA, ryA);                  // K-step ks_begin
+    store(0, rdA, ryA);
+    issue(rdB, ryB);                  // K-step ks_begin + 1 (tiles past this split's range are loaded but never staged)
+    __syncthreads();
+    int ks = ks_begin;
+    for (; ks + 1 < ks_end; ++ks) {   // a further K-step remains to be staged
+        // rotate the register sets: B was loaded during the previous K-step (a whole K-step ago: no stall), A is free
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rdA[e][i] = rdB[e][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ryA[e][i] = ryB[e][i];
+        }
+        kstep((ks - ks_begin) & 1, rdB, ryB, rdA, ryA);
     }
-    compute((ks_end - 1 - ks_begin) & 1);
+    compute((ks - ks_begin) & 1);
 
     // G^T dU G per (ci, co) in registers; D layout of the 32x32 MFMA: row (ci) = (r&3) + 8*(r>>2) + 4*(lane>>5),
     // column (co) = lane & 31
