@@ -240,6 +240,21 @@ size_t y3_reduce_scratch_bytes(int c);
 int y3_bn_train_stats(y3_ctx* ctx, const float* z, long long rows, int c, const float* gamma, const float* beta,
                       float eps, float decay, float* mean, float* inv_std, float* scale, float* shift,
                       float* moving_mean, float* moving_var, float* scratch);
+/* The same statistics without the extra pass over z: the conv entry points below also write, per row block of their
+ * output, the column sums of y and y^2 — stats [y3_conv_stats_blocks(d, wino)][2][cout] floats — taken in the conv's
+ * epilogue where the tile is in registers (the training forward calls them with scale = 1, shift = 0, act = 0, so y = z);
+ * y3_bn_train_stats_partials then finishes exactly like y3_bn_train_stats (fixed-order fp64 combination: deterministic).
+ * y3_conv_stats_blocks returns 0 for convs without this support (the Cin = 3 stem, Cout %% 4 != 0, fused upsample
+ * inputs; wino != 0: convs y3_conv_wino_eligible rejects).  Same arguments as y3_conv2d_fwd / y3_conv2d_fwd_wino
+ * otherwise (no x_up, no residual). */
+int y3_conv_stats_blocks(const y3_conv_desc* d, int wino);
+int y3_conv2d_fwd_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w, const float* scale,
+                        const float* shift, float* y, float* stats, void* workspace, size_t workspace_bytes);
+int y3_conv2d_fwd_wino_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino, const float* scale,
+                             const float* shift, float* y, float* stats, void* workspace, size_t workspace_bytes);
+int y3_bn_train_stats_partials(y3_ctx* ctx, const float* partial, int nblocks, long long rows, int c,
+                               const float* gamma, const float* beta, float eps, float decay, float* mean,
+                               float* inv_std, float* scale, float* shift, float* moving_mean, float* moving_var);
 /* y = act(z*scale + shift) + residual   (act: 1 = LeakyReLU(0.1); residual may be NULL) */
 int y3_bn_apply_fwd(y3_ctx* ctx, const float* z, const float* scale, const float* shift, const float* residual,
                     long long rows, int c, int act, float* y);

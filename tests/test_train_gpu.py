@@ -157,6 +157,70 @@ def test_winograd_weight_gradient_matches_autograd(n, h, w, cin, cout):
                                             ctypes.c_size_t(sc.numel())))
 
 
+@pytest.mark.parametrize('n,h,w,k,stride,cin,cout,wino', [
+    (3, 20, 28, 1, 1, 128, 64, 0),      # 128x64 tiles
+    (3, 20, 28, 1, 1, 256, 128, 0),     # 64x64 tiles (1x1, Cout > 64)
+    (2, 26, 26, 3, 2, 64, 128, 0),      # stride 2, data-parallel 128x128
+    (32, 52, 52, 3, 2, 128, 256, 0),    # stride 2 on the stream-K schedule (cut tiles summed in the kernel)
+    (2, 24, 24, 1, 1, 64, 32, 0),       # 128x32 tiles
+    (3, 13, 13, 3, 1, 64, 128, 1),      # Winograd, odd map (outputs that do not exist must not be counted)
+    (16, 52, 52, 3, 1, 128, 256, 1),    # Winograd on the stream-K schedule
+    (2, 26, 26, 3, 1, 64, 64, 0),       # direct 3x3 stride 1
+])
+def test_conv_epilogue_statistics_equal_the_separate_pass(n, h, w, k, stride, cin, cout, wino):
+    """Training forward (ref: model.py:35-41 with is_training=True): the conv writes per-row-block column sums of its
+    output in the epilogue and y3_bn_train_stats_partials finishes them; mean / inv_std / scale / shift / moving statistics
+    must agree with y3_bn_train_stats on the same z (1e-6 relative: only the fp32 partial-sum grouping differs), the conv
+    output must be bit-identical to the plain entry point, and everything is run-to-run bit-exact."""
+    from yolov3_tensorflow_amd import engine
+    fw, _lib, L, ctx = _ctx()
+    dev = fw.default_device()
+    rng = np.random.RandomState(cin + cout + k + stride)
+    x = torch.tensor(rng.standard_normal((n, h, w, cin)).astype(np.float32), device=dev)
+    wt = torch.tensor((rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32), device=dev)
+    ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    gamma = torch.tensor(rng.uniform(0.5, 1.5, cout).astype(np.float32), device=dev)
+    beta = torch.tensor(rng.normal(0, 0.3, cout).astype(np.float32), device=dev)
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, k, stride, 0)
+    nblk = L.y3_conv_stats_blocks(ctypes.byref(d), wino)
+    assert nblk > 0
+    if wino:
+        wp = engine.pack_wino(wt)
+        conv = lambda stats: engine.conv2d_fwd_wino(x, wp, ones, zeros, cout, False, stats=stats)
+    else:
+        wp = torch.empty(k * k * cout * cin, device=dev)
+        _lib.check(L.y3_pack_conv_weights(ctx, fw.ptr(wt), k, cin, cout, fw.ptr(wp)))
+        conv = lambda stats: engine.conv2d_fwd(x, wp, ones, zeros, k, stride, cout, False, stats=stats)
+    z_plain = conv(None)
+    outs = []
+    for _ in range(2):
+        part = torch.full((nblk, 2, cout), float('nan'), device=dev)
+        z = conv(part)
+        assert torch.equal(z, z_plain)
+        st = torch.empty((4, cout), device=dev)
+        mm, mv = torch.full((cout,), 0.25, device=dev), torch.full((cout,), 2.0, device=dev)
+        rows = z.numel() // cout
+        _lib.check(L.y3_bn_train_stats_partials(ctx, fw.ptr(part), nblk, rows, cout, fw.ptr(gamma), fw.ptr(beta),
+                                                ctypes.c_float(1e-5), ctypes.c_float(0.9), fw.ptr(st[0]), fw.ptr(st[1]),
+                                                fw.ptr(st[2]), fw.ptr(st[3]), fw.ptr(mm), fw.ptr(mv)))
+        outs.append((part, st, mm, mv))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), 'not run-to-run bit-exact'
+    st2 = torch.empty((4, cout), device=dev)
+    mm2, mv2 = torch.full((cout,), 0.25, device=dev), torch.full((cout,), 2.0, device=dev)
+    sc = torch.empty(L.y3_reduce_scratch_bytes(cout), dtype=torch.uint8, device=dev)
+    _lib.check(L.y3_bn_train_stats(ctx, fw.ptr(z_plain), z_plain.numel() // cout, cout, fw.ptr(gamma), fw.ptr(beta),
+                                   ctypes.c_float(1e-5), ctypes.c_float(0.9), fw.ptr(st2[0]), fw.ptr(st2[1]),
+                                   fw.ptr(st2[2]), fw.ptr(st2[3]), fw.ptr(mm2), fw.ptr(mv2), fw.ptr(sc)))
+    _, st, mm, mv = outs[0]
+    zz = z_plain.double().reshape(-1, cout)
+    mean64, var64 = zz.mean(0), zz.var(0, unbiased=False)
+    assert float((st[0].double() - mean64).abs().max()) <= 1e-5 * float(zz.abs().max())
+    np.testing.assert_allclose(st[1].cpu().numpy(), (1.0 / torch.sqrt(var64 + 1e-5)).cpu().numpy(), rtol=2e-5)
+    for a, b in ((st, st2), (mm, mm2), (mv, mv2)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize('rows,c', [(2 * 13 * 13, 1024), (3 * 20 * 28, 64), (5000, 32), (64, 256)])
 def test_bn_train_forward_backward(rows, c):
     fw, _lib, L, ctx = _ctx()

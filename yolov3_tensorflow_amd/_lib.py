@@ -76,6 +76,13 @@ PROTOTYPES = {
     "y3_reduce_scratch_bytes": (c_size_t, [c_int]),
     "y3_bn_train_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_float, c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_conv_stats_blocks": (c_int, [POINTER(ConvDesc), c_int]),
+    "y3_conv2d_fwd_stats": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t]),
+    "y3_conv2d_fwd_wino_stats": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_size_t]),
+    "y3_bn_train_stats_partials": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_float,
+                                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "y3_bn_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "y3_bn_bwd_scratch_bytes": (c_size_t, [c_int]),
     "y3_bn_train_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

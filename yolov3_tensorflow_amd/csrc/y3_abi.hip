@@ -96,6 +96,33 @@ extern "C" int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     return y3_launch_conv(ctx->stream, d, x, x_up, w, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
+// ---- training forward: the conv + the batch-norm statistics of its output in one pass ---------------------------------
+extern "C" int y3_conv_stats_blocks(const y3_conv_desc* d, int wino) { return y3_conv_stats_blocks_impl(d, wino); }
+
+extern "C" int y3_conv2d_fwd_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w,
+                                   const float* scale, const float* shift, float* y, float* stats, void* workspace,
+                                   size_t workspace_bytes) {
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_stats");
+    Y3_CHECK_ARG(stats && d && y3_conv_stats_blocks_impl(d, 0) > 0,
+                 "y3_conv2d_fwd_stats: null stats, or a conv without statistics support (y3_conv_stats_blocks == 0)");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    o.stats = stats;
+    return y3_launch_conv(ctx->stream, d, x, nullptr, w, scale, shift, nullptr, y, workspace, workspace_bytes, &o);
+}
+
+extern "C" int y3_conv2d_fwd_wino_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino,
+                                        const float* scale, const float* shift, float* y, float* stats, void* workspace,
+                                        size_t workspace_bytes) {
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_wino_stats");
+    Y3_CHECK_ARG(stats && d && y3_conv_stats_blocks_impl(d, 1) > 0,
+                 "y3_conv2d_fwd_wino_stats: null stats, or a conv the Winograd kernel does not take");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    o.stats = stats;
+    return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, nullptr, y, workspace, workspace_bytes, &o);
+}
+
 extern "C" int y3_pack_conv_weights_split(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, int planes,
                                           void* w_split) {
     Y3_CHECK_ARG(ctx && w_hwio && w_split, "y3_pack_conv_weights_split: null argument");

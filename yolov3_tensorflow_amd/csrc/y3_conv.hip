@@ -33,7 +33,7 @@ using namespace y3conv;
 
 // TMODE (compile time, so that the forward instantiations carry none of its state): data gradient of a stride-2
 // conv, one output parity class per launch (see ConvArgs::tmode)
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, bool TMODE>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, bool TMODE, bool STATS = false>
 __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     constexpr int MI = G::MI, NI = G::NI, WTM = G::WTM, WTN = G::WTN;
@@ -312,17 +312,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             // whole tile, or K-steps [0, k) of a cut tile (this worker's last segment): add what the next workers
             // of the group published for it, then the common epilogue
             if (STREAMK && seg_end < tile_end) sk_consume<BM, BN, WGM, WGN>(p, skw, ntiles, S, tile_end, acc);
-            epilogue<BM, BN, WGM, WGN, TMODE>(p, smem, acc, m0, n0);
+            epilogue<BM, BN, WGM, WGN, TMODE, STATS>(p, smem, acc, m0, n0);
         }
         if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = false>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = false, bool STATS = false>
 int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     using G = Geo<BM, BN, WGM, WGN>;
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, TMODE>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, TMODE, STATS>;
     static bool attr_set = false;  // per instantiation; benign race (idempotent)
     if (!attr_set) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
@@ -335,11 +335,11 @@ int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     return Y3_OK;
 }
 
-template <int KS, bool TMODE = false>
+template <int KS, bool TMODE = false, bool STATS = false>
 int launch_streamk(hipStream_t stream, const ConvArgs& a) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true, TMODE>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true, TMODE, STATS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
@@ -350,15 +350,15 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a) {
     return Y3_OK;
 }
 
-template <int KS, bool UPCAT, bool TMODE = false>
+template <int KS, bool UPCAT, bool TMODE = false, bool STATS = false>
 int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
-    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT, TMODE>(stream, a);
-    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT, TMODE>(stream, a);
+    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT, TMODE, STATS>(stream, a);
+    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT, TMODE, STATS>(stream, a);
     // 1x1 layers have 8-32 K-steps per tile: 64x64 tiles (37 KB of LDS, 72 VGPRs -> 4 workgroups per CU) hide one
     // tile's prologue/epilogue under its neighbours' MFMAs and quantise the 172-1352-tile grids of the network 4x
     // finer (measured, batch 32: 52x52 -10 %, 26x26 -19 %, 13x13 -21 % against the 128x128 tile)
-    if (KS == 1 && !TMODE) return launch_data_parallel<64, 64, 2, 2, KS, UPCAT, TMODE>(stream, a);
-    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT, TMODE>(stream, a);
+    if (KS == 1 && !TMODE) return launch_data_parallel<64, 64, 2, 2, KS, UPCAT, TMODE, STATS>(stream, a);
+    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT, TMODE, STATS>(stream, a);
 }
 
 }  // namespace
@@ -403,7 +403,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
-    a.err = nullptr; a.spin_limit = 0; a.fault = 0;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -411,6 +411,9 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 29) && M * d->cout < (1LL << 29),
                  "y3_conv2d_fwd: tensor exceeds 2^29 elements (32-bit byte offsets)");
     a.M = (int)M;
+    a.stats = sk ? sk->stats : nullptr;
+    Y3_CHECK_ARG(!a.stats || (d->cin != 3 && !x_up && d->cout % 4 == 0),
+                 "y3_conv2d_fwd_stats: statistics need Cin != 3, no fused upsample input and Cout %% 4 == 0");
 
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && !x_up && !residual,
@@ -430,15 +433,29 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     }
     if (d->k == 1) {
         Y3_CHECK_ARG(d->stride == 1, "y3_conv2d_fwd: 1x1 conv must have stride 1");
-        return dispatch_bn<1, false>(stream, a);
+        return a.stats ? dispatch_bn<1, false, false, true>(stream, a) : dispatch_bn<1, false>(stream, a);
     }
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     if (use_streamk(a, d->k, has_ws)) {
         if (int rc = sk_prepare(stream, a, workspace, sk)) return rc;
-        return launch_streamk<3>(stream, a);
+        return a.stats ? launch_streamk<3, false, true>(stream, a) : launch_streamk<3>(stream, a);
     }
-    return dispatch_bn<3, false>(stream, a);
+    return a.stats ? dispatch_bn<3, false, false, true>(stream, a) : dispatch_bn<3, false>(stream, a);
+}
+
+// Row blocks of the `stats` output (= output rows / the BM the dispatch above picks); the Winograd kernel: 64-tile blocks.
+int y3_conv_stats_blocks_impl(const y3_conv_desc* d, int wino) {
+    if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout % 4 != 0 || d->cin == 3 || d->c_up > 0) return 0;
+    if (wino) {
+        if (!y3_conv_wino_eligible_impl(d)) return 0;
+        const long long T = (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2);
+        return (int)((T + 63) / 64);
+    }
+    if (!((d->k == 1 && d->stride == 1) || d->k == 3) || (d->stride != 1 && d->stride != 2)) return 0;
+    const long long M = (long long)d->n * (d->h / d->stride) * (d->w / d->stride);
+    const int bm = (d->k == 1 && d->cout > 64) ? 64 : 128;
+    return (int)((M + bm - 1) / bm);
 }
 
 // Data gradient of a conv layer as a forward conv over dz:
@@ -461,7 +478,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     ConvArgs a;
     a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
     a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.flags = nullptr; a.workers = 0;
-    a.err = nullptr; a.spin_limit = 0; a.fault = 0;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr;
     a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
     a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;

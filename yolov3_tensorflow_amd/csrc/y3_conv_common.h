@@ -20,6 +20,8 @@ struct ConvArgs {
     unsigned* err;       // stream-K: device-visible error word (a consumer whose poll expires ORs a code into it) or null
     unsigned spin_limit; // stream-K: polls per awaited flag before giving up
     int fault;           // stream-K test hook: producers skip raising their flag
+    float* stats;        // nullptr, or [ceil(M/BM)][2][Cout]: per row block of the output, the column sums of y and y^2
+                         // (batch-norm statistics of the training forward, taken where the tile is already in registers)
     int N, H, W, Cin, Cu, Cx;
     int Ho, Wo, Cout;
     int stride, pad, act;
@@ -76,7 +78,9 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[NP]) {
 }
 // ---- epilogue shared by the conv kernels ------------------------------------------------------------
 // D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int BM, int BN, int WGM, int WGN, bool TMODE>
+// STATS (training forward only; a template parameter so that the inference instantiations carry none of it): the column
+// sums of y and y^2 over the tile's rows go to p.stats (ConvArgs).
+template <int BM, int BN, int WGM, int WGN, bool TMODE, bool STATS = false>
 __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                                          f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI],
                                          int m0, int n0) {
@@ -121,6 +125,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                     cs[(wm * G::WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2)) * G::LDC + wn * G::WTN +
                        ni * 32 + col_l] = acc[mi][ni][r];
         __syncthreads();
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};      // column sums of y, y^2 over this thread's rows
         if (cok) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + col);
@@ -137,8 +142,32 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                     }
                     if (p.resid) v += res[i];
                     *reinterpret_cast<f32x4*>(p.y + out_pixel(row) * p.Cout + col) = v;
+                    if (STATS) {
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
             }
+        }
+        if (STATS) {
+            // the RPP row lanes of every column quad are combined through the LDS in a fixed order (deterministic)
+            __syncthreads();                           // every thread is done reading the staged tile
+            float* red = smem;                         // [RPP][2][BN]
+            *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BN + tc) = s1;
+            *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BN + tc) = s2;
+            __syncthreads();
+            if (tid < C4 && cok) {                     // (tid < C4  <=>  tr == 0: tc = 4 * tid)
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < RPP; ++k) {
+                    a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BN + tc);
+                    b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BN + tc);
+                }
+                float* st = p.stats + (size_t)(m0 / BM) * 2 * p.Cout;
+                *reinterpret_cast<f32x4*>(st + col) = a;
+                *reinterpret_cast<f32x4*>(st + p.Cout + col) = b;
+            }
+            __syncthreads();                           // (the LDS goes back to the caller)
         }
         return;
     }

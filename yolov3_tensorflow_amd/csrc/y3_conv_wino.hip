@@ -43,6 +43,7 @@ struct WinoArgs {
     unsigned* err;       // stream-K: device-visible error word (a consumer whose poll expires ORs a code into it) or null
     unsigned spin_limit; // stream-K: polls per awaited flag before giving up
     int fault;           // stream-K test hook: producers skip raising their flag
+    float* stats;        // STATS instantiations: [ceil(T/BT)][2][Cout] column sums of y, y^2 per 64-tile block
 };
 
 // Balanced contiguous partition of `items` over `workers` (same as y3_conv_common.h)
@@ -146,9 +147,12 @@ struct WinoRows {
     // wave store), so independent register work placed there is free (the kernel resets its accumulators)
     // n_extra consecutive published partial-sum slots ([BT*4][BNW] floats each) starting `extra_base` bytes into
     // p.partial are added to the staged sums, in slot order, before scale/shift (the stream-K consumer; 0 elsewhere).
-    template <typename F>
+    // STATS: s1 / s2 receive the sums of y and y^2 over this thread's existing rows (training forward: batch-norm
+    // statistics taken where the outputs are already in registers)
+    template <bool STATS = false, typename F>
     __device__ __forceinline__ void finish(const WinoArgs& p, const float* cs, int n0, F between,
-                                           int n_extra = 0, unsigned extra_base = 0) const {
+                                           int n_extra = 0, unsigned extra_base = 0, f32x4* s1 = nullptr,
+                                           f32x4* s2 = nullptr) const {
         const int tid = threadIdx.x;
         const int tc = (tid % C4) * 4, tr = tid / C4;
         const int co = n0 + tc;
@@ -179,6 +183,11 @@ struct WinoRows {
             v += res[i];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_y,
                                                    ((ok >> i) & 1) ? off[i] * 4u : OOB, 0, 0);
+            if (STATS) {
+                const float m = ((ok >> i) & 1) ? 1.f : 0.f;      // rows that do not exist contribute nothing
+                *s1 += v * m;
+                *s2 += (v * v) * m;
+            }
             between(i);
         }
     }
@@ -214,7 +223,7 @@ __device__ __forceinline__ void wino_tile_info(const WinoArgs& p, int t, int& pi
 // STREAMK: a persistent grid of p.workers workgroups (one per CU), each owning an equal contiguous range of
 // (block, K-step) work items; a block computed by several workers is summed in output space by
 // the consumer worker inside the kernel (fixed worker order: deterministic; wk_range above).
-template <int WGM, int WGN, bool STREAMK>
+template <int WGM, int WGN, bool STREAMK, bool STATS = false>
 __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int BT = WGM * 32, BNW = WGN * 32;
@@ -566,10 +575,33 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             // (2) all threads: float4 rows of the staging tile (+ the partial sums other workers published for this
             // block) -> scale/shift, LeakyReLU, + residual -> global
             static_assert(WinoRows<BT, BNW>::PASSES == 16, "one accumulator set is reset per store pass");
-            rows.finish(p, cs, n0, [&](int i) {
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            rows.template finish<STATS>(p, cs, n0, [&](int i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4));
+            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4), &s1, &s2);
+            if (STATS) {
+                // combine the 16 row lanes of every column quad through the LDS in a fixed order (deterministic)
+                constexpr int C4 = BNW / 4, RPP = 256 / C4;
+                const int tc = (tid % C4) * 4, tr = tid / C4;
+                __syncthreads();                           // every thread is done reading the staged outputs
+                float* red = cs;                           // [RPP][2][BNW]
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BNW + tc) = s1;
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BNW + tc) = s2;
+                __syncthreads();
+                if (tid < C4 && n0 + tc < p.Cout) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < RPP; ++k) {
+                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BNW + tc);
+                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BNW + tc);
+                    }
+                    float* st = p.stats + (size_t)(t0 / BT) * 2 * p.Cout;
+                    *reinterpret_cast<f32x4*>(st + n0 + tc) = a;
+                    *reinterpret_cast<f32x4*>(st + p.Cout + n0 + tc) = b;
+                }
+                if (!STREAMK) __syncthreads();             // (STREAMK: the barrier below)
+            }
         } else {
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos)
@@ -700,17 +732,18 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.TH = (d->h + 1) / 2; a.TW = (d->w + 1) / 2; a.T = d->n * a.TH * a.TW;
     a.partial = nullptr; a.flags = nullptr; a.workers = 0;
     a.err = nullptr; a.spin_limit = 0; a.fault = 0;
+    a.stats = sk ? sk->stats : nullptr;
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
-    auto kern = conv_wino_f32_kernel<2, 2, false>;
-    auto kern_sk = conv_wino_f32_kernel<2, 2, true>;
-    static bool attr_set = false;   // benign race (idempotent)
-    if (!attr_set) {
+    auto kern = a.stats ? conv_wino_f32_kernel<2, 2, false, true> : conv_wino_f32_kernel<2, 2, false>;
+    auto kern_sk = a.stats ? conv_wino_f32_kernel<2, 2, true, true> : conv_wino_f32_kernel<2, 2, true>;
+    static bool attr_set[2] = {false, false};   // per (STATS) pair of instantiations; benign race (idempotent)
+    if (!attr_set[a.stats ? 1 : 0]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[a.stats ? 1 : 0] = true;
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = (a.Cout + BNW - 1) / BNW;
     const int blocks = nbt * nbn;

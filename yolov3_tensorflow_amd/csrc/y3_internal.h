@@ -18,7 +18,10 @@ struct y3_sk_opts {
                                 // regions of all its layers with one memset); nullptr: the launcher uses the words
                                 // inside the workspace and zeroes them itself ahead of the launch
     unsigned* err = nullptr;    // device-visible error word (y3_ctx::err_host) or nullptr
+    float* stats = nullptr;     // [y3_conv_stats_blocks][2][cout] column sums of y / y^2 per output row block, or nullptr
 };
+// rows of the `stats` output of the exact-fp32 conv launchers for this conv (0: not available); wino != 0: the Winograd kernel
+int y3_conv_stats_blocks_impl(const y3_conv_desc* d, int wino);
 #define Y3_ERR_STREAMK_TIMEOUT 1u
 // Test hook: with Y3_STREAMK_FAULT=1 in the environment the producers of a stream-K launch never raise their flag and
 // the consumers give up after 2^10 polls, so the time-out path (error word -> Y3_EHIP) can be exercised.

@@ -698,6 +698,21 @@ extern "C" int y3_bn_train_stats(y3_ctx* ctx, const float* z, long long rows, in
     return Y3_OK;
 }
 
+extern "C" int y3_bn_train_stats_partials(y3_ctx* ctx, const float* partial, int nblocks, long long rows, int c,
+                                          const float* gamma, const float* beta, float eps, float decay, float* mean,
+                                          float* inv_std, float* scale, float* shift, float* moving_mean,
+                                          float* moving_var) {
+    Y3_CHECK_ARG(ctx && partial && gamma && beta && mean && inv_std && scale && shift,
+                 "y3_bn_train_stats_partials: null argument");
+    Y3_CHECK_ARG(nblocks > 0 && rows > 0 && c > 0, "y3_bn_train_stats_partials: bad shape");
+    Y3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr),
+                 "y3_bn_train_stats_partials: moving stats must come in pairs");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(c), dim3(256), 0, ctx->stream, partial, nblocks, c, (double)rows,
+                       gamma, beta, eps, decay, mean, inv_std, scale, shift, moving_mean, moving_var);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
 extern "C" int y3_bn_apply_fwd(y3_ctx* ctx, const float* z, const float* scale, const float* shift,
                                const float* residual, long long rows, int c, int act, float* y) {
     Y3_CHECK_ARG(ctx && z && scale && shift && y, "y3_bn_apply_fwd: null argument");

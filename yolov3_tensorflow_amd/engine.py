@@ -121,7 +121,7 @@ def _conv_scratch(device, nbytes):
 
 
 def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up=None, use_workspace=True,
-               planes=0):
+               planes=0, stats=None):
     """y = act(conv(x) * scale + shift) + residual on NHWC fp32 device tensors (y3_conv2d_fwd).
     use_workspace=False forces the data-parallel schedule (no scratch).  planes=2/3: w_dev is the split-plane
     packing and the products are rebuilt on the bf16 matrix pipe (y3_conv2d_fwd_split)."""
@@ -143,13 +143,19 @@ def conv2d_fwd(x, w_dev, scale, shift, k, stride, cout, act, residual=None, x_up
                                          fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
                                          fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
         return y
+    if stats is not None:       # also: per row block of y, the column sums of y and y^2 (y3_conv_stats_blocks rows)
+        if residual is not None or x_up is not None:
+            raise ValueError("conv2d_fwd(stats=...) takes no residual and no fused upsample input")
+        _lib.check(L.y3_conv2d_fwd_stats(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_dev), fw.ptr(scale),
+                                         fw.ptr(shift), fw.ptr(y), fw.ptr(stats), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
+        return y
     _lib.check(L.y3_conv2d_fwd(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(x_up),
                                fw.ptr(w_dev), fw.ptr(scale), fw.ptr(shift), fw.ptr(residual),
                                fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y
 
 
-def conv2d_fwd_wino(x, w_wino, scale, shift, cout, act, residual=None, use_workspace=True):
+def conv2d_fwd_wino(x, w_wino, scale, shift, cout, act, residual=None, use_workspace=True, stats=None):
     """3x3 stride-1 conv in its Winograd F(2x2,3x3) form (y3_conv2d_fwd_wino); w_wino from pack_wino.
     use_workspace=False forces the one-workgroup-per-block schedule (no stream-K scratch)."""
     n, h, w, cin = x.shape
@@ -160,6 +166,13 @@ def conv2d_fwd_wino(x, w_wino, scale, shift, cout, act, residual=None, use_works
     if use_workspace:
         ws_bytes = L.y3_conv_wino_workspace_bytes(ctypes.byref(d))
         ws = _conv_scratch(x.device, ws_bytes) if ws_bytes else None
+    if stats is not None:
+        if residual is not None:
+            raise ValueError("conv2d_fwd_wino(stats=...) takes no residual")
+        _lib.check(L.y3_conv2d_fwd_wino_stats(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino),
+                                              fw.ptr(scale), fw.ptr(shift), fw.ptr(y), fw.ptr(stats), fw.ptr(ws),
+                                              ctypes.c_size_t(ws_bytes)))
+        return y
     _lib.check(L.y3_conv2d_fwd_wino(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino), fw.ptr(scale),
                                     fw.ptr(shift), fw.ptr(residual), fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y

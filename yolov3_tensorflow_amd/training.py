@@ -166,27 +166,38 @@ def forward_train(model, x):
         wino = (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and
                 engine.wino_eligible(l['k'], l['stride'], int(xin.shape[3]), cout))
         rec = dict(xin=xin)
-        if wino:        # Winograd forward for the stride-1 3x3 convs (the backward kernels are unchanged)
+        # exact-fp32 BN layers: the conv also returns the column sums of z and z^2 per row block of its output (taken in
+        # its epilogue), which saves the statistics' own pass over z; the stem and the split-precision kernels keep it
+        desc = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), int(xin.shape[3]), 0, cout, l['k'], l['stride'], 0)
+        nblk = L.y3_conv_stats_blocks(ctypes.byref(desc), 1 if wino else 0) if (l['bn'] and not planes) else 0
+        part = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev) if nblk else None
+        if wino:        # Winograd forward for the stride-1 3x3 convs
             key = wvar.op_name + '#wino'
             hit = st['packed'].get(key)
             if hit is None or hit[0] != wvar.version:
                 hit = (wvar.version, engine.pack_wino(wvar.tensor))
                 st['packed'][key] = hit
-            z = engine.conv2d_fwd_wino(xin, hit[1], ones, zeros, cout, False)
+            z = engine.conv2d_fwd_wino(xin, hit[1], ones, zeros, cout, False, stats=part)
             wp = None
         else:
             wp = _packed_weights(st, wvar, planes)
         if l['bn']:
             if not wino:
-                z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False, planes=planes)
+                z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False, planes=planes, stats=part)
             rows = z.numel() // cout
             stats = torch.empty((4, cout), dtype=torch.float32, device=dev)   # mean, inv_std, scale, shift
-            sc = _scratch(st, 'reduce', L.y3_reduce_scratch_bytes(cout), dev)
             gamma, beta, mmean, mvar = bnv
-            _lib.check(L.y3_bn_train_stats(ctx, fw.ptr(z), rows, cout, fw.ptr(gamma.tensor), fw.ptr(beta.tensor),
-                                           ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay),
-                                           fw.ptr(stats[0]), fw.ptr(stats[1]), fw.ptr(stats[2]), fw.ptr(stats[3]),
-                                           fw.ptr(mmean.tensor), fw.ptr(mvar.tensor), fw.ptr(sc)))
+            if part is not None:
+                _lib.check(L.y3_bn_train_stats_partials(
+                    ctx, fw.ptr(part), nblk, rows, cout, fw.ptr(gamma.tensor), fw.ptr(beta.tensor),
+                    ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay), fw.ptr(stats[0]), fw.ptr(stats[1]),
+                    fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(mmean.tensor), fw.ptr(mvar.tensor)))
+            else:
+                sc = _scratch(st, 'reduce', L.y3_reduce_scratch_bytes(cout), dev)
+                _lib.check(L.y3_bn_train_stats(ctx, fw.ptr(z), rows, cout, fw.ptr(gamma.tensor), fw.ptr(beta.tensor),
+                                               ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay),
+                                               fw.ptr(stats[0]), fw.ptr(stats[1]), fw.ptr(stats[2]), fw.ptr(stats[3]),
+                                               fw.ptr(mmean.tensor), fw.ptr(mvar.tensor), fw.ptr(sc)))
             mmean.touch()      # updated in place: the folded inference parameters must be rebuilt
             mvar.touch()
             y = torch.empty_like(z)
