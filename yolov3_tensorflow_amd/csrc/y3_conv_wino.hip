@@ -44,6 +44,8 @@ struct WinoArgs {
     unsigned spin_limit; // stream-K: polls per awaited flag before giving up
     int fault;           // stream-K test hook: producers skip raising their flag
     float* stats;        // STATS instantiations: [ceil(T/BT)][2][Cout] column sums of y, y^2 per 64-tile block
+    int bn_inner;        // block order: 0 = column block outer (consecutive blocks share a weight panel), 1 = column block
+                         // inner (the Cout/64 blocks of one tile block are neighbours and share its activations in the L2)
 };
 
 // Balanced contiguous partition of `items` over `workers` (same as y3_conv_common.h)
@@ -247,7 +249,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     // weight panel; workgroup b runs on XCD b%8 and gets a contiguous eighth of the id space
     long long item, item_end;
     int worker = 0, grp = 0, lw = 0;     // stream-K: global worker index, XCD group, local worker in the group
-    const int nblocks = nbt * ((p.Cout + BNW - 1) / BNW);
+    const int nbn_ = (p.Cout + BNW - 1) / BNW;
+    const int nblocks = nbt * nbn_;
     {
         const int nt = gridDim.x;
         const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
@@ -281,7 +284,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     int t0 = 0, n0 = 0;
     // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers
     auto setup_tables = [&](int blk) {
-        const int bn = fastdiv(blk, nbt), bt = blk - bn * nbt;
+        int bn, bt;
+        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
+        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
         t0 = bt * BT;
         n0 = bn * BNW;
         if (a_pair == 0) {
@@ -292,7 +297,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         }
     };
     auto setup_voff = [&](int blk) {
-        const int bn = fastdiv(blk, nbt), bt = blk - bn * nbt;
+        int bn, bt;
+        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
+        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
         const int t0 = bt * BT, n0 = bn * BNW;
         const int tid = opaque(threadIdx.x);
         {
@@ -733,6 +740,18 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.partial = nullptr; a.flags = nullptr; a.workers = 0;
     a.err = nullptr; a.spin_limit = 0; a.fault = 0;
     a.stats = sk ? sk->stats : nullptr;
+    // Block order.  Column block OUTER streams the whole activation tensor once per 64-channel column block (Cout/64
+    // passes that miss the 4 MB L2 of an XCD); column block INNER reads each tile block's activations once and re-reads
+    // the weight panels per tile block instead — the better trade while all panels (16*Cin*Cout floats) stay L2-resident.
+    // Y3_WINO_ORDER=0/1 overrides (experiment hook).
+    {
+        static int force = -2;
+        if (force == -2) {
+            const char* e = getenv("Y3_WINO_ORDER");
+            force = e ? atoi(e) : -1;
+        }
+        a.bn_inner = force >= 0 ? (force != 0) : ((size_t)16 * d->cin * d->cout * sizeof(float) <= (size_t)(3u << 20));
+    }
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
     auto kern = a.stats ? conv_wino_f32_kernel<2, 2, false, true> : conv_wino_f32_kernel<2, 2, false>;
