@@ -462,8 +462,14 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                 wino = False
                 args.precision = 'f32'
                 model.compute_dtype = 'f32'
-        for _ in range(args.warmup):
+        for i in range(args.warmup):
+            # (two warm-up steps run with layer profiling on, so that the event objects the timed region records into
+            # already exist: creating them inside the timed region stalled the host for milliseconds on a cold box)
+            model.set_layer_profiling(i < 2)
             fms = model.forward(x, False)
+        model.set_layer_profiling(False)
+        if args.warmup:
+            model.read_layer_ms()
         # per-layer hipEvents (for `roofline`) are recorded inside the timed region on every 8th step only: 76 event
         # records cost ~1.5 % of a profiled step
         barrier()

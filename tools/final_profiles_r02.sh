@@ -1,5 +1,5 @@
 # Round-2 measurement set (run on the GPU box through gpurun; results are copied into profiles/r02_* by hand).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_r02; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final5_r02; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof.log 2>&1
 python $R/tools/trace_gaps.py $O/prof/p_kernel_trace.csv > $O/trace_gaps.json 2>&1

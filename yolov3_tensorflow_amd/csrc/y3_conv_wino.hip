@@ -742,7 +742,9 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.stats = sk ? sk->stats : nullptr;
     // Block order.  Column block OUTER streams the whole activation tensor once per 64-channel column block (Cout/64
     // passes that miss the 4 MB L2 of an XCD); column block INNER reads each tile block's activations once and re-reads
-    // the weight panels per tile block instead — the better trade while all panels (16*Cin*Cout floats) stay L2-resident.
+    // the weight panels per tile block instead — the better trade only while all panels (16*Cin*Cout floats) are small
+    // next to the 4 MB L2: measured (FETCH_SIZE, profiles/r02_wino_block_order.txt) -17 % fabric fetch on the 104-grid
+    // layers (0.5 MB of panels), +20 % on the 52-grid layers (2 MB), time unchanged either way.
     // Y3_WINO_ORDER=0/1 overrides (experiment hook).
     {
         static int force = -2;
@@ -750,7 +752,7 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
             const char* e = getenv("Y3_WINO_ORDER");
             force = e ? atoi(e) : -1;
         }
-        a.bn_inner = force >= 0 ? (force != 0) : ((size_t)16 * d->cin * d->cout * sizeof(float) <= (size_t)(3u << 20));
+        a.bn_inner = force >= 0 ? (force != 0) : ((size_t)16 * d->cin * d->cout * sizeof(float) <= (size_t)(1u << 20));
     }
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
