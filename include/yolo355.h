@@ -109,7 +109,10 @@ size_t y3_conv_workspace_bytes(const y3_conv_desc* d);
  * whole, among 8 workgroup groups (blockIdx %% 8); inside group `group` its workers/8 local workers own equal
  * contiguous ranges of (unit, K-step) items: [*begin, *end) for `local_worker`.  A unit cut by a range boundary is
  * finished inside the kernel by the worker owning its K-step 0, from the partial sums the following local workers
- * publish; tests/test_streamk_partition.py replays that protocol on these ranges. */
+ * publish; tests/test_streamk_partition.py replays that protocol on these ranges.
+ * kind 2 = the Winograd kernel's default schedule: of group g's blocks [b0, b1) the first R*G (G = workers/8, R =
+ * (b1-b0)/G whole rounds) are computed whole - round r, local worker j: block b0 + r*G + j - and [*begin, *end) is
+ * `local_worker`'s range of the remaining (b1 - b0 - R*G) * ksteps items, cut as above. */
 int y3_streamk_range(int kind, int units, int ksteps, int workers, int group, int local_worker, long long* begin,
                      long long* end);
 int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* x_up,

@@ -2,7 +2,7 @@
 """The stream-K work split and its in-kernel hand-off protocol, replayed on the host (no GPU).
 
 The conv kernels (y3_conv_common.h sk_range / y3_conv_wino.hip wk_range) divide (unit, K-step) items among
-persistent workgroups and finish a cut unit inside the kernel: the worker owning the unit's K-step 0 (its LAST
+persistent workgroups (the Winograd kernel: whole rounds of blocks first, kind 2) and finish a cut unit inside the kernel: the worker owning the unit's K-step 0 (its LAST
 segment) adds the partial sums published by the following local workers of its group (their FIRST segments).
 `y3_streamk_range` evaluates the same functions on the host; this test replays the protocol on the ranges it
 returns for the network's layer shapes and checks the invariants the device code relies on:
@@ -30,12 +30,32 @@ def ranges(kind, units, ksteps, workers):
     return out
 
 
+def group_blocks(units, x):
+    q, r = divmod(units, 8)
+    b0 = x * q + min(x, r)
+    return b0, b0 + q + (1 if x < r else 0)
+
+
 def replay(kind, units, ksteps, workers):
     G = workers // 8
     rng = ranges(kind, units, ksteps, workers)
     covered = 0
     published = {}           # worker -> (unit, first K-step, end K-step)
     finished = {}            # unit -> K-steps accounted for by its finishing worker
+    if kind == 2:
+        # hybrid: whole rounds of every group's blocks are computed uncut (round r, local worker j: block b0 + r*G + j);
+        # the ranges returned describe the remaining blocks only
+        for x in range(8):
+            b0, b1 = group_blocks(units, x)
+            R = (b1 - b0) // G
+            for r in range(R):
+                for j in range(G):
+                    unit = b0 + r * G + j
+                    assert unit not in finished
+                    finished[unit] = ksteps
+            covered += R * G * ksteps
+            assert rng[(x, 0)][0] == (b0 + R * G) * ksteps and rng[(x, G - 1)][1] == b1 * ksteps
+            assert b1 - (b0 + R * G) < G                        # less than one round is ever cut
     for x in range(8):
         pos = None
         for j in range(G):
@@ -94,6 +114,11 @@ def test_direct_streamk_partition(units, ksteps):
 @pytest.mark.parametrize('units,ksteps', WINO)
 def test_winograd_streamk_partition(units, ksteps):
     replay(1, units, ksteps, 256)
+
+
+@pytest.mark.parametrize('units,ksteps', WINO + [(256, 16), (264, 4), (3000, 2)])
+def test_winograd_hybrid_streamk_partition(units, ksteps):
+    replay(2, units, ksteps, 256)
 
 
 def test_streamk_range_rejects_bad_arguments():

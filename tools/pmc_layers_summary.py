@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-layer table from the rocprofv3 --pmc passes of tools/pmc_layers.py.
+
+    python tools/pmc_layers_summary.py <out.json> <counter_collection.csv> [<counter_collection.csv> ...]
+
+Every csv holds the same dispatch sequence (same program), so counters of different passes are joined on the ordinal
+of the dispatch among the conv kernels of the LAST forward (75 conv launches: the 75 layers in order).  The calibration
+copy (largest-grid non-conv dispatch after the warm-up) gives bytes per counter unit for a 16-B/lane streaming kernel.
+"""
+import csv
+import json
+import sys
+from collections import OrderedDict, defaultdict
+
+CONV = ('conv_wino', 'conv_mfma_f32_kernel', 'conv_stem_kernel')
+
+
+def load(path):
+    disp = OrderedDict()        # dispatch id -> (kernel, {counter: value})
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            d = int(r['Dispatch_Id'])
+            if d not in disp:
+                disp[d] = (r['Kernel_Name'], defaultdict(float))
+            disp[d][1][r['Counter_Name']] += float(r['Counter_Value'])
+            disp[d][1]['duration_ns'] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    return [disp[k] for k in sorted(disp)]
+
+
+def main():
+    out, paths = sys.argv[1], sys.argv[2:]
+    layers, calib = None, {}
+    for p in paths:
+        seq = load(p)
+        convs = [(n, c) for (n, c) in seq if any(k in n for k in CONV)]
+        last = convs[-75:]
+        if layers is None:
+            layers = [dict(kernel=n.replace('(anonymous namespace)::', '').replace('y3conv::', '').split('(')[0].replace('void ', '')) for n, _ in last]
+        for row, (n, c) in zip(layers, last):
+            row.update({k: v for k, v in c.items()})
+        # calibration: the elementwise copy kernel with the largest counters
+        cands = [(n, c) for (n, c) in seq if 'elementwise' in n or 'copyBuffer' in n]
+        if cands:
+            n, c = max(cands, key=lambda t: sum(t[1].values()))
+            calib.update({k: v for k, v in c.items()})
+            calib['kernel'] = n[:80]
+    res = {"calibration_1GiB_copy": calib, "layers": layers}
+    with open(out, 'w') as f:
+        json.dump(res, f, indent=1)
+    keys = [k for k in layers[0] if k != 'kernel']
+    print('calibration (1 GiB read + 1 GiB written):', {k: v for k, v in calib.items() if k != 'kernel'})
+    print('layer kernel ' + ' '.join(keys))
+    for i, row in enumerate(layers):
+        print(i, row['kernel'][:40], ' '.join('%.4g' % row.get(k, float('nan')) for k in keys))
+
+
+if __name__ == '__main__':
+    main()

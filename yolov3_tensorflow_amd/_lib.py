@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libyolo355.so")
+LIB_PATH = os.environ.get("Y3_LIB_PATH") or os.path.join(HERE, "csrc", "libyolo355.so")   # (override: probe builds)
 
 Y3_OK, Y3_EINVAL, Y3_EHIP, Y3_ESTATE = 0, -1, -2, -3
 Y3_NMS_TF, Y3_NMS_PY = 0, 1

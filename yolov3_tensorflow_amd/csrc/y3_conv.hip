@@ -379,7 +379,7 @@ int y3_streamk_range_impl(int kind, int units, int ksteps, int workers, int grou
                      local_worker >= 0 && local_worker < workers / 8 && (long long)units * ksteps < (1LL << 31),
                  "y3_streamk_range: bad argument");
     if (kind == 0) sk_range(units, ksteps, workers, group, local_worker, *begin, *end);
-    else y3_wino_range_impl(units, ksteps, workers, group, local_worker, begin, end);
+    else y3_wino_range_impl(units, ksteps, workers, group, local_worker, kind == 2, begin, end);
     return Y3_OK;
 }
 

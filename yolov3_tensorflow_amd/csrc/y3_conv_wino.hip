@@ -44,6 +44,7 @@ struct WinoArgs {
     unsigned spin_limit; // stream-K: polls per awaited flag before giving up
     int fault;           // stream-K test hook: producers skip raising their flag
     float* stats;        // STATS instantiations: [ceil(T/BT)][2][Cout] column sums of y, y^2 per 64-tile block
+    int hybrid;          // stream-K: whole rounds of blocks first (see wk_range), only the remainder is cut
     int bn_inner;        // block order: 0 = column block outer (consecutive blocks share a weight panel), 1 = column block
                          // inner (the Cout/64 blocks of one tile block are neighbours and share its activations in the L2)
 };
@@ -66,13 +67,26 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // Local worker j runs in workgroup blockIdx = x + 8*(G-1-j): every consumer j waits only for workers j+1.. of its own
 // group, which have SMALLER workgroup ids, i.e. were dispatched earlier - the wait cannot deadlock even when fewer
 // than `workers` workgroups are resident.
-__device__ __host__ __forceinline__ void wk_range(int blocks, int ksteps, int workers, int x, int j, long long& begin,
-                                                  long long& end) {
+//
+// HYBRID (p.hybrid; off by default, see the launcher): a group's first R*G blocks (R = its block count / G whole rounds) are NOT cut - in round r
+// local worker j computes block b0 + r*G + j, start to end - and only the remaining < G blocks are divided as above.
+// The G workers of an XCD then walk neighbouring blocks of one weight panel at the same K-step, so a weight slab
+// (and the halo rows two neighbouring tile strips share) is fetched into that XCD's L2 once and hit by the others;
+// with every block cut at a different K position (the plain split) each worker streams its own copy of the panel from
+// the fabric: 862 MB per launch on the 13-grid layers against 45 MB of tensors (profiles/r02_pmc_layers.txt).
+// The cut remainder runs LAST, so a consumer's producers have long published when it looks.
+__device__ __host__ __forceinline__ void wk_range(int blocks, int ksteps, int workers, int x, int j, int hybrid,
+                                                  long long& begin, long long& end, int* rounds = nullptr,
+                                                  int* first_block = nullptr) {
     const int G = workers >> 3;
     const long long b0 = wk_begin(blocks, 8, x), b1 = wk_begin(blocks, 8, x + 1);
-    const long long items = (b1 - b0) * ksteps;
-    begin = b0 * ksteps + wk_begin(items, G, j);
-    end = b0 * ksteps + wk_begin(items, G, j + 1);
+    const int R = hybrid ? (int)((b1 - b0) / G) : 0;
+    const long long s0 = b0 + (long long)R * G;
+    const long long items = (b1 - s0) * ksteps;
+    begin = s0 * ksteps + wk_begin(items, G, j);
+    end = s0 * ksteps + wk_begin(items, G, j + 1);
+    if (rounds) *rounds = R;
+    if (first_block) *first_block = (int)b0 + j;
 }
 
 typedef __attribute__((address_space(1))) unsigned gu32;   // flags are only ever touched by agent-scope global atomics
@@ -113,11 +127,13 @@ __device__ __forceinline__ void input_transform(const V (&d)[16], V (&v)[16]) {
 // The kernel's tail, in two steps so that the residual loads fly under the output transform: prepare() computes the output offsets of this thread's
 // float4 rows of the staging tile cs[BT*4][LDC] and issues the residual loads; finish() reads the staged rows ->
 // scale/shift, LeakyReLU, + residual -> global.  tile_pix / tile_ok describe the workgroup's tiles (see the kernel).
-template <int BT, int BNW>
+// NT = threads per workgroup; TWO: the staged sums are the element-wise sum of two staging tiles (cs and cs + BT*4*LDC:
+// the eight-wave kernel's two position halves).
+template <int BT, int BNW, int NT = 256, bool TWO = false>
 struct WinoRows {
     static constexpr int LDC = BNW + 4;
     static constexpr int C4 = BNW / 4;            // float4 columns per staged row
-    static constexpr int RPP = 256 / C4;          // rows per pass
+    static constexpr int RPP = NT / C4;           // rows per pass
     static constexpr int PASSES = BT * 4 / RPP;
     static_assert(PASSES <= 32, "one validity bit per pass");
     unsigned off[PASSES];                         // element offsets (the launcher bounds M * Cout by 2^29)
@@ -171,6 +187,7 @@ struct WinoRows {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + i * RPP) * LDC + tc);
+            if (TWO) v += *reinterpret_cast<const f32x4*>(cs + (BT * 4 + tr + i * RPP) * LDC + tc);
             for (int e = 0; e < n_extra; ++e)
                 v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                          rs_x, (unsigned)((tr + i * RPP) * BNW + tc) * 4u,
@@ -249,6 +266,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     // weight panel; workgroup b runs on XCD b%8 and gets a contiguous eighth of the id space
     long long item, item_end;
     int worker = 0, grp = 0, lw = 0;     // stream-K: global worker index, XCD group, local worker in the group
+    int dp_left = 0, dp_blk = 0;         // stream-K hybrid: whole blocks still to do (rounds), and the next one
     const int nbn_ = (p.Cout + BNW - 1) / BNW;
     const int nblocks = nbt * nbn_;
     {
@@ -259,14 +277,15 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             grp = xcd;
             lw = (p.workers >> 3) - 1 - k8;
             worker = grp * (p.workers >> 3) + lw;
-            wk_range(nblocks, ksteps, p.workers, grp, lw, item, item_end);
+            wk_range(nblocks, ksteps, p.workers, grp, lw, p.hybrid, item, item_end, &dp_left, &dp_blk);
         } else {
             item = (long long)id * ksteps;
             item_end = item + ksteps;
         }
     }
-    if (item >= item_end) return;
-    const int first_blk = (int)(item / ksteps);
+    if (dp_left == 0 && item >= item_end) return;
+    const int first_blk = dp_left > 0 ? dp_blk : (int)(item / ksteps);
+    const int first_ks = dp_left > 0 ? 0 : (int)(item - (long long)first_blk * ksteps);
 
     // ---- staging: every thread does a 1/256 share of both operands, so that the whole K-step (loads, MFMAs,
     // input transform, LDS writes) is ONE basic block that the scheduling hints below can interleave ------------
@@ -402,13 +421,20 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 #define Y3_STAMP(k)
 #endif
     setup_voff(first_blk);
-    issue((int)(item - (long long)first_blk * ksteps));
-    while (item < item_end) {
-        const int blk = (int)(item / ksteps);
-        const int ks0 = (int)(item - (long long)blk * ksteps);
+    issue(first_ks);
+    while (dp_left > 0 || item < item_end) {
+        // this segment: a whole block of the round-robin part, or the next run of the cut range
+        const bool whole = STREAMK && dp_left > 0;
+        const int blk = whole ? dp_blk : (int)(item / ksteps);
+        const int ks0 = whole ? 0 : (int)(item - (long long)blk * ksteps);
         const long long blk_end = (long long)(blk + 1) * ksteps;
-        const long long seg_end = blk_end < item_end ? blk_end : item_end;
-        const int ks1 = ks0 + (int)(seg_end - item);          // K-steps [ks0, ks1) of this block
+        const long long seg_end = whole ? item : (blk_end < item_end ? blk_end : item_end);   // (whole: item stays)
+        const int ks1 = whole ? ksteps : ks0 + (int)(seg_end - item);          // K-steps [ks0, ks1) of this block
+        // ... and the one after it (its first K-step is fetched under this one's tail)
+        const bool whole_next = whole && dp_left > 1;
+        const bool has_next = whole_next || seg_end < item_end;
+        const int next_blk = whole_next ? blk + (p.workers >> 3) : (int)(seg_end / ksteps);
+        const int next_ks = whole_next ? 0 : (int)(seg_end - (long long)next_blk * ksteps);
         setup_tables(blk);
         store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
         __syncthreads();
@@ -549,7 +575,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             const int G = p.workers >> 3;
             for (int jj = lw + 1; jj < G; ++jj) {
                 long long b, e;
-                wk_range(nblocks, ksteps, p.workers, grp, jj, b, e);
+                wk_range(nblocks, ksteps, p.workers, grp, jj, p.hybrid, b, e);
                 if (b >= blk_end) break;
                 ++n_extra;
             }
@@ -570,11 +596,11 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             }
             __syncthreads();
         }
-        if (STREAMK && seg_end < item_end) {
-            // the next block's first K-step is fetched under this block's tail (its registers are free: the tail
+        if (STREAMK && has_next) {
+            // the next segment's first K-step is fetched under this block's tail (its registers are free: the tail
             // holds 81 and the accumulators are dead)
-            setup_voff(blk + 1);
-            issue(0);
+            setup_voff(next_blk);
+            issue(next_ks);
             __builtin_amdgcn_sched_barrier(0);
         }
         Y3_STAMP(4);    // next block's offsets + loads issued
@@ -632,6 +658,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         }
         if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
         Y3_STAMP(5);    // scale/shift/activation/residual/stores (or the partial-slot copy), barrier
+        if (whole) { --dp_left; dp_blk += p.workers >> 3; }
         item = seg_end;
     }
 #ifdef Y3_WINO_CLOCK
@@ -641,6 +668,500 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         out[1] = clk_loop;
         out[2] = clk_steps;
         for (int k = 0; k < 6; ++k) out[3 + k] = clk_phase[k];
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Eight-wave form of the kernel above: the same 64-tile x 64-channel block, LDS layout and K-step, computed by 512
+// threads - waves 0-3 own transform positions 0-7 (rows 0,1 of the 4x4 transform), waves 4-7 positions 8-15 - so a
+// wave holds 128 accumulator registers and a SIMD runs TWO waves: while one waits for its loads, the barrier or its
+// stores, the other one keeps the matrix pipe busy (the four-wave kernel measures 63 % pipe occupancy with one wave
+// per SIMD: ~1,000 exposed cycles per 4,096-cycle K-step and a 16k-cycle tail per block).
+//   * staging: thread = (position half, tile, channel pair) loads the three patch rows its two transform rows need
+//     (12 x 8 bytes), forms X = e0 - e2 and Y = e1 + c0*e0 + c2*e2 ((c0, c2) = (0, 1) for rows 0,1: Y = d1 + d2;
+//     (-1, 0) for rows 2,3: Y = d2 - d1, X = d1 - d3 - multiplications by 0 / +-1, exact), the column transform, and
+//     writes 8 positions; four 16-byte weight pieces per thread;
+//   * tail: each half applies A^T . A to its two rows of M (linear), the two partial 2x2 outputs go to two staging
+//     tiles and are summed when the rows are read back.
+template <bool STREAMK, bool STATS = false>
+__global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p) {
+    constexpr int BT = 64, BNW = 64, NT = 512;
+    constexpr int PLANE_V = BT * WROW, PLANE_U = BNW * WROW;
+    constexpr int STAGE_V = 16 * PLANE_V, STAGE_U = 16 * PLANE_U;
+    constexpr int LDC = BNW + 4;
+    constexpr int CS_BYTES = BT * 4 * LDC * 4;            // one output staging tile
+    static_assert(2 * CS_BYTES >= 2 * (STAGE_V + STAGE_U), "the tile tables sit behind the two staging tiles");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Vs = smem;                    // [2][16][BT][32 B]
+    unsigned char* Us = smem + 2 * STAGE_V;      // [2][16][BNW][32 B]
+    int* tile_pix = reinterpret_cast<int*>(smem + 2 * CS_BYTES);   // [BT]
+    int* tile_ok = tile_pix + BT;                                  // [BT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int nbt = (p.T + BT - 1) / BT;
+    const int ksteps = p.Cin / WKC;
+    long long item, item_end;
+    int worker = 0, grp = 0, lw = 0;
+    int dp_left = 0, dp_blk = 0;
+    const int nbn_ = (p.Cout + BNW - 1) / BNW;
+    const int nblocks = nbt * nbn_;
+    {
+        const int nt = gridDim.x;
+        const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+        if (STREAMK) {
+            grp = xcd;
+            lw = (p.workers >> 3) - 1 - k8;
+            worker = grp * (p.workers >> 3) + lw;
+            wk_range(nblocks, ksteps, p.workers, grp, lw, p.hybrid, item, item_end, &dp_left, &dp_blk);
+        } else {
+            item = (long long)id * ksteps;
+            item_end = item + ksteps;
+        }
+    }
+    if (dp_left == 0 && item >= item_end) return;
+    const int first_blk = dp_left > 0 ? dp_blk : (int)(item / ksteps);
+    const int first_ks = dp_left > 0 ? 0 : (int)(item - (long long)first_blk * ksteps);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.u), 0, (unsigned)((size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
+    unsigned voff_a[12];          // byte offsets of the 3x4 patch pixels this thread loads (OOB where padded)
+    unsigned voff_u[4];           // byte offsets of the 4 weight pieces
+    const int a_tile = (tid & 255) >> 2, a_pair = tid & 3, a_half = tid >> 8;
+    int t0 = 0, n0 = 0;
+    auto setup_tables = [&](int blk) {
+        int bn, bt;
+        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
+        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
+        t0 = bt * BT;
+        n0 = bn * BNW;
+        if (a_pair == 0 && a_half == 0) {
+            int pix, okbits, n, ty, tx;
+            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
+            tile_pix[a_tile] = pix;
+            tile_ok[a_tile] = okbits;
+        }
+    };
+    auto setup_voff = [&](int blk) {
+        int bn, bt;
+        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
+        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
+        const int t0 = bt * BT, n0 = bn * BNW;
+        const int tid = opaque(threadIdx.x);
+        {
+            const int a_tile = (tid & 255) >> 2, a_pair = tid & 3, a_half = tid >> 8;
+            int pix, okbits, n, ty, tx;
+            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
+            const bool tok = pix >= 0;
+            const int y0 = 2 * ty - 1 + a_half, x0 = 2 * tx - 1;       // patch rows a_half .. a_half + 2
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int yy = y0 + i, xx = x0 + j;
+                    const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                    voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + NT * j;
+            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+            const bool ok = (n0 + co) < p.Cout;
+            voff_u[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
+        }
+    };
+    f32x2 ra[12];
+    f32x4 ru[4];
+    auto issue = [&](int ks) {
+        const unsigned soff_a = (unsigned)(ks * WKC) * 4u, soff_u = (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+            ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
+#ifndef Y3_WINO8_UAUX
+#define Y3_WINO8_UAUX 0
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            ru[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[j], soff_u, Y3_WINO8_UAUX));
+    };
+    // rows of the transform this thread produces: X -> row (half ? 3 : 0), Y -> row (half ? 2 : 1)
+    const float c0s = a_half ? -1.f : 0.f, c2s = a_half ? 0.f : 1.f;
+    const f32x2 c0 = {c0s, c0s}, c2 = {c2s, c2s};
+    const int st_a = lds_off(a_tile, a_pair >> 1) + (a_pair & 1) * 8;
+    const int st_x = st_a + (a_half ? 12 : 0) * PLANE_V, st_y = st_a + (a_half ? 8 : 4) * PLANE_V;
+    auto store = [&](int buf) {
+        unsigned char* us = Us + buf * STAGE_U;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + NT * j;
+            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
+            *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = ru[j];
+        }
+        f32x2 x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = ra[0 * 4 + j] - ra[2 * 4 + j];
+            y[j] = __builtin_elementwise_fma(c0, ra[0 * 4 + j], __builtin_elementwise_fma(c2, ra[2 * 4 + j], ra[1 * 4 + j]));
+        }
+        unsigned char* vx = Vs + buf * STAGE_V + st_x;
+        unsigned char* vy = Vs + buf * STAGE_V + st_y;
+        *reinterpret_cast<f32x2*>(vx + 0 * PLANE_V) = x[0] - x[2];
+        *reinterpret_cast<f32x2*>(vx + 1 * PLANE_V) = x[1] + x[2];
+        *reinterpret_cast<f32x2*>(vx + 2 * PLANE_V) = x[2] - x[1];
+        *reinterpret_cast<f32x2*>(vx + 3 * PLANE_V) = x[1] - x[3];
+        *reinterpret_cast<f32x2*>(vy + 0 * PLANE_V) = y[0] - y[2];
+        *reinterpret_cast<f32x2*>(vy + 1 * PLANE_V) = y[1] + y[2];
+        *reinterpret_cast<f32x2*>(vy + 2 * PLANE_V) = y[2] - y[1];
+        *reinterpret_cast<f32x2*>(vy + 3 * PLANE_V) = y[1] - y[3];
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int pos = 0; pos < 8; ++pos)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+
+    const int frag_a = lds_off(wm * 32 + (lane & 31), lane >> 5) + ph * 8 * PLANE_V;
+    const int frag_b = lds_off(wn * 32 + (lane & 31), lane >> 5) + ph * 8 * PLANE_U;
+    // fragments of position pair g of this wave's half (4 reads) and its 8 MFMAs (k pairs [j0, j1))
+    auto frags = [&](int buf, int g, f32x4 (&a)[2], f32x4 (&b)[2]) {
+        const unsigned char* vs = Vs + buf * STAGE_V + frag_a;
+        const unsigned char* us = Us + buf * STAGE_U + frag_b;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 2 + i) * PLANE_V);
+            b[i] = *reinterpret_cast<const f32x4*>(us + (g * 2 + i) * PLANE_U);
+        }
+    };
+    auto mfmas = [&](int g, const f32x4 (&a)[2], const f32x4 (&b)[2], int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[g * 2 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[i][j], acc[g * 2 + i], 0, 0, 0);
+    };
+    f32x4 a0[2], b0[2];            // pair 0 of the current K-step
+
+    float* cs = reinterpret_cast<float*>(smem);
+#ifdef Y3_WINO8_CLOCK
+    unsigned long long clk_phase[6] = {0, 0, 0, 0, 0, 0}, clk_steps = 0;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    setup_voff(first_blk);
+    issue(first_ks);
+    while (dp_left > 0 || item < item_end) {
+        const bool whole = STREAMK && dp_left > 0;
+        const int blk = whole ? dp_blk : (int)(item / ksteps);
+        const int ks0 = whole ? 0 : (int)(item - (long long)blk * ksteps);
+        const long long blk_end = (long long)(blk + 1) * ksteps;
+        const long long seg_end = whole ? item : (blk_end < item_end ? blk_end : item_end);
+        const int ks1 = whole ? ksteps : ks0 + (int)(seg_end - item);
+        const bool whole_next = whole && dp_left > 1;
+        const bool has_next = whole_next || seg_end < item_end;
+        const int next_blk = whole_next ? blk + (p.workers >> 3) : (int)(seg_end / ksteps);
+        const int next_ks = whole_next ? 0 : (int)(seg_end - (long long)next_blk * ksteps);
+        setup_tables(blk);
+        store(0);
+        __syncthreads();
+        frags(0, 0, a0, b0);
+        // The two position halves run the K-step in OPPOSITE phase, so that one wave of every SIMD has MFMAs to issue
+        // while the other one waits for its loads, transforms and writes the next K-step's tiles:
+        //   ph 0: 16 MFMAs(ks) | transform + LDS writes(ks+1) | loads(ks+2) | 12 MFMAs(ks) | barrier | fragments(ks+1), last 4 MFMAs(ks)
+        //   ph 1: transform + LDS writes(ks+1) | loads(ks+2) | 32 MFMAs(ks) | barrier | fragments(ks+1)
+        // Both fetch a whole K-step ahead (the loads stay in flight across the barrier): L2 misses take 1-2 us here, half
+        // a K-step is not enough.  (tools/issue_probe.hip: with two waves per SIMD, LDS and VMEM instructions are free
+        // next to a stream of MFMAs, but every VALU instruction takes ~4.6 cycles of the matrix pipe.)
+        // Y3_WINO8_KO (probe builds, tools/wino8_probe.sh): bit 0 no loads, 1 no transform / LDS writes, 2 no fragment
+        // reads, 3 no MFMAs inside the K-loop; they compute garbage, only the launch times mean anything
+#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 1)
+#define W8_ISSUE(k)
+#else
+#define W8_ISSUE(k) issue(k)
+#endif
+#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 2)
+#define W8_STORE(b)
+#else
+#define W8_STORE(b) store(b)
+#endif
+#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 4)
+#define W8_FRAGS(b, g, x, y)
+#else
+#define W8_FRAGS(b, g, x, y) frags(b, g, x, y)
+#endif
+#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 8)
+#define W8_MFMAS(g, x, y, j0, j1)
+#else
+#define W8_MFMAS(g, x, y, j0, j1) mfmas(g, x, y, j0, j1)
+#endif
+#ifdef Y3_WINO8_CLOCK   // probe build: s_memtime stamps of wave 0 (ph 0) and wave 4 (ph 1) of workgroup 0 -> first bytes of y
+#define W8_T(i) tk[i] = __builtin_amdgcn_s_memtime()
+#else
+#define W8_T(i)
+#endif
+#if defined(Y3_WINO8_AMID)
+        if (ks0 + 1 < ks1) issue(ks0 + 1);
+#else
+        if (ph && ks0 + 1 < ks1) issue(ks0 + 1);
+#endif
+        for (int ks = ks0; ks + 1 < ks1; ++ks) {
+            const int cur = (ks - ks0) & 1;
+            f32x4 a1[2], b1[2];
+#ifdef Y3_WINO8_CLOCK
+            unsigned long long tk[7];
+#endif
+            W8_T(0);
+            if (ph == 0) {
+#if defined(Y3_WINO8_AMID)      // experiment: ph 0 stages in the middle of its MFMAs (both halves fetch a K-step ahead)
+                W8_FRAGS(cur, 1, a1, b1);
+                W8_MFMAS(0, a0, b0, 0, 4);
+                W8_FRAGS(cur, 2, a0, b0);
+                W8_MFMAS(1, a1, b1, 0, 4);
+                __builtin_amdgcn_sched_barrier(0);
+                W8_T(1);
+                W8_STORE(cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                W8_T(2);
+                if (ks + 2 < ks1) W8_ISSUE(ks + 2);
+                W8_T(3);
+                W8_FRAGS(cur, 3, a1, b1);
+                W8_MFMAS(2, a0, b0, 0, 4);
+                W8_MFMAS(3, a1, b1, 0, 2);
+#else
+                W8_ISSUE(ks + 1);
+                W8_FRAGS(cur, 1, a1, b1);
+                W8_MFMAS(0, a0, b0, 0, 4);
+                W8_FRAGS(cur, 2, a0, b0);
+                W8_MFMAS(1, a1, b1, 0, 4);
+                W8_FRAGS(cur, 3, a1, b1);
+                W8_MFMAS(2, a0, b0, 0, 4);
+                W8_MFMAS(3, a1, b1, 0, 2);
+#if !defined(Y3_WINO8_NOSCHED) && !defined(Y3_WINO8_CLOCK)
+                // the 16 loads go out two per MFMA under the first position pair (back to back they hold the wave for
+                // ~900 cycles before its first MFMA), the fragment reads one pair ahead of their MFMAs
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                W8_T(3);
+                W8_STORE(cur ^ 1);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                W8_T(4);
+                __syncthreads();
+                W8_T(5);
+                W8_FRAGS(cur ^ 1, 0, a0, b0);
+                W8_MFMAS(3, a1, b1, 2, 4);
+                W8_T(6);
+            } else {
+                W8_STORE(cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                W8_T(1);
+#if !defined(Y3_WINO8_BBURST)   // ph 1's loads go out under its MFMAs too (unconditional: on the last pass they re-read
+                                // K-step ks+1 - in range - and are never used); BBURST = back to back (+4..11 %)
+                W8_ISSUE(ks + 2 < ks1 ? ks + 2 : ks + 1);
+                W8_FRAGS(cur, 1, a1, b1);
+                W8_MFMAS(0, a0, b0, 0, 4);
+                W8_FRAGS(cur, 2, a0, b0);
+                W8_MFMAS(1, a1, b1, 0, 4);
+                W8_FRAGS(cur, 3, a1, b1);
+                W8_MFMAS(2, a0, b0, 0, 4);
+                W8_MFMAS(3, a1, b1, 0, 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#else
+                if (ks + 2 < ks1) W8_ISSUE(ks + 2);
+                W8_T(2);
+                W8_FRAGS(cur, 1, a1, b1);
+                W8_MFMAS(0, a0, b0, 0, 4);
+                W8_FRAGS(cur, 2, a0, b0);
+                W8_MFMAS(1, a1, b1, 0, 4);
+                W8_T(3);
+                W8_FRAGS(cur, 3, a1, b1);
+                W8_MFMAS(2, a0, b0, 0, 4);
+                W8_MFMAS(3, a1, b1, 0, 4);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                W8_T(4);
+                __syncthreads();
+                W8_T(5);
+                W8_FRAGS(cur ^ 1, 0, a0, b0);
+                W8_T(6);
+            }
+#ifdef Y3_WINO8_CLOCK
+#pragma unroll
+            for (int i = 0; i < 6; ++i) clk_phase[i] += tk[i + 1] - tk[i];
+            ++clk_steps;
+#endif
+        }
+        {
+            const int cur = (ks1 - 1 - ks0) & 1;
+            f32x4 a1[2], b1[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) frags(cur, g + 1, a1, b1);
+                mfmas(g, a0, b0, 0, 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; }
+            }
+        }
+
+        // (1) this half's share of A^T M A per (tile, channel): 2x2 partial outputs -> its staging tile
+        __syncthreads();
+        const bool producer = STREAMK && ks0 > 0;
+        WinoRows<BT, BNW, NT, true> rows;
+        rows.prepare(p, tile_pix, tile_ok, n0);
+        {
+            const int col = wn * 32 + (lane & 31);
+            float* csh = cs + ph * (BT * 4 * LDC);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float m[8];
+#pragma unroll
+                for (int pos = 0; pos < 8; ++pos) {
+                    m[pos] = acc[pos][r];
+                    asm volatile("" : "+v"(m[pos]));
+                }
+                // rows 0,1 of M (ph 0): s0 = m0 + m1, s1 = m1;  rows 2,3 (ph 1): s0 = m2, s1 = -m2 - m3
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = ph ? m[j] : m[j] + m[4 + j];
+                    s1[j] = ph ? -m[j] - m[4 + j] : m[4 + j];
+                }
+                float* row = csh + (tl * 4) * LDC + col;
+                row[0 * LDC] = s0[0] + s0[1] + s0[2];
+                row[1 * LDC] = s0[1] - s0[2] - s0[3];
+                row[2 * LDC] = s1[0] + s1[1] + s1[2];
+                row[3 * LDC] = s1[1] - s1[2] - s1[3];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        int n_extra = 0;
+        if (STREAMK && ks1 < ksteps) {
+            const int G = p.workers >> 3;
+            for (int jj = lw + 1; jj < G; ++jj) {
+                long long b, e;
+                wk_range(nblocks, ksteps, p.workers, grp, jj, p.hybrid, b, e);
+                if (b >= blk_end) break;
+                ++n_extra;
+            }
+            if (tid == 0) {
+                for (int e = 0; e < n_extra; ++e) {
+                    gu32* flag = (gu32*)(p.flags + worker + 1 + e);
+                    unsigned spins = 0;
+                    for (; spins < p.spin_limit; ++spins) {
+                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (spins == p.spin_limit && p.err)
+                        __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        if (STREAMK && has_next) {
+            setup_voff(next_blk);
+            issue(next_ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!producer) {
+            static_assert(WinoRows<BT, BNW, NT, true>::PASSES == 8, "one accumulator set is reset per store pass");
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            rows.template finish<STATS>(p, cs, n0, [&](int i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4), &s1, &s2);
+            if (STATS) {
+                constexpr int C4 = BNW / 4, RPP = NT / C4;
+                const int tc = (tid % C4) * 4, tr = tid / C4;
+                __syncthreads();
+                float* red = cs;                           // [RPP][2][BNW]
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BNW + tc) = s1;
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BNW + tc) = s2;
+                __syncthreads();
+                if (tid < C4 && n0 + tc < p.Cout) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < RPP; ++k) {
+                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BNW + tc);
+                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BNW + tc);
+                    }
+                    float* st = p.stats + (size_t)(t0 / BT) * 2 * p.Cout;
+                    *reinterpret_cast<f32x4*>(st + n0 + tc) = a;
+                    *reinterpret_cast<f32x4*>(st + p.Cout + n0 + tc) = b;
+                }
+                if (!STREAMK) __syncthreads();
+            }
+        } else {
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial, 0, (unsigned)((size_t)p.workers * BT * 4 * BNW * 4), 0x00020000);
+            const unsigned slot_off = (unsigned)worker * (unsigned)(BT * 4 * BNW * 4);
+            constexpr int C4 = BNW / 4;
+            for (int f = tid; f < BT * 4 * C4; f += NT) {
+                const int rr = f / C4, c4 = f - rr * C4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4) +
+                                *reinterpret_cast<const f32x4*>(cs + (BT * 4 + rr) * LDC + c4 * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_part,
+                                                       slot_off + (unsigned)f * 16u, 0, 16);   // aux 16 = sc1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && !p.fault)
+                __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (STREAMK) __syncthreads();
+        if (whole) { --dp_left; dp_blk += p.workers >> 3; }
+        item = seg_end;
+    }
+#ifdef Y3_WINO8_CLOCK
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.y) + (wave >> 2) * 8;
+        out[0] = __builtin_amdgcn_s_memtime() - clk0;
+        out[1] = clk_steps;
+        for (int k = 0; k < 6; ++k) out[2 + k] = clk_phase[k];
     }
 #endif
 }
@@ -696,8 +1217,9 @@ __global__ void __launch_bounds__(256) pack_weights_wino_kernel(const float* __r
 
 }  // namespace
 
-void y3_wino_range_impl(int units, int ksteps, int workers, int group, int local_worker, long long* begin, long long* end) {
-    wk_range(units, ksteps, workers, group, local_worker, *begin, *end);
+void y3_wino_range_impl(int units, int ksteps, int workers, int group, int local_worker, int hybrid, long long* begin,
+                        long long* end) {
+    wk_range(units, ksteps, workers, group, local_worker, hybrid, *begin, *end);
 }
 
 int y3_conv_wino_eligible_impl(const y3_conv_desc* d) {
@@ -740,6 +1262,18 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     a.partial = nullptr; a.flags = nullptr; a.workers = 0;
     a.err = nullptr; a.spin_limit = 0; a.fault = 0;
     a.stats = sk ? sk->stats : nullptr;
+    {
+        // Y3_WINO_SK_HYBRID=1: whole rounds of blocks first (wk_range).  Measured (profiles/r02_wino_hybrid_schedule.txt):
+        // fabric reads of the 13-grid layers 862 -> 294 MB per launch, time +1..6 % on every stream-K layer (the
+        // re-reads are Infinity-Cache hits and off the critical path; workgroups in lock-step collide in their store
+        // tails) - so the default stays the plain split.
+        static int hyb = -1;
+        if (hyb < 0) {
+            const char* e = getenv("Y3_WINO_SK_HYBRID");
+            hyb = e ? (atoi(e) != 0) : 0;
+        }
+        a.hybrid = hyb;
+    }
     // Block order.  Column block OUTER streams the whole activation tensor once per 64-channel column block (Cout/64
     // passes that miss the 4 MB L2 of an XCD); column block INNER reads each tile block's activations once and re-reads
     // the weight panels per tile block instead — the better trade only while all panels (16*Cin*Cout floats) are small
@@ -756,6 +1290,25 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     }
     constexpr int BT = 64, BNW = 64;
     constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
+    // Y3_WINO8=0 selects the four-wave kernel (one wave per SIMD); default: the eight-wave one (two waves per SIMD)
+    static int w8 = -1;
+    if (w8 < 0) {
+        const char* e = getenv("Y3_WINO8");
+        w8 = e ? (atoi(e) != 0) : 1;
+    }
+    constexpr size_t lds8 = (size_t)2 * BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
+    if (w8) {
+        auto k8 = a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>;
+        auto k8_sk = a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>;
+        static bool attr8_set[2] = {false, false};
+        if (!attr8_set[a.stats ? 1 : 0]) {
+            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k8),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k8_sk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            attr8_set[a.stats ? 1 : 0] = true;
+        }
+    }
     auto kern = a.stats ? conv_wino_f32_kernel<2, 2, false, true> : conv_wino_f32_kernel<2, 2, false>;
     auto kern_sk = a.stats ? conv_wino_f32_kernel<2, 2, true, true> : conv_wino_f32_kernel<2, 2, true>;
     static bool attr_set[2] = {false, false};   // per (STATS) pair of instantiations; benign race (idempotent)
@@ -791,7 +1344,15 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
             a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + WK_FLAGS_OFFSET);
             Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)WK_WORKERS * sizeof(unsigned), stream));
         }
-        hipLaunchKernelGGL(kern_sk, dim3(WK_WORKERS), dim3(256), lds, stream, a);
+        if (w8) {
+            auto k8_sk = a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>;
+            hipLaunchKernelGGL(k8_sk, dim3(WK_WORKERS), dim3(512), lds8, stream, a);
+        } else {
+            hipLaunchKernelGGL(kern_sk, dim3(WK_WORKERS), dim3(256), lds, stream, a);
+        }
+    } else if (w8) {
+        auto k8 = a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>;
+        hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), lds8, stream, a);
     } else {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
     }

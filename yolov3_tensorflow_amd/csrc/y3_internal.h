@@ -57,10 +57,11 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
 size_t y3_conv_workspace_bytes_impl(const y3_conv_desc* d);
 int y3_conv_schedule_impl(const y3_conv_desc* d);
 // host evaluation of the device-side stream-K work split (test hook): kind 0 = sk_range (direct / split kernels,
-// y3_conv_common.h), 1 = wk_range (Winograd kernel)
+// y3_conv_common.h), 1 = wk_range (Winograd kernel, every block may be cut), 2 = wk_range hybrid (whole rounds first)
 int y3_streamk_range_impl(int kind, int units, int ksteps, int workers, int group, int local_worker, long long* begin,
                           long long* end);
-void y3_wino_range_impl(int units, int ksteps, int workers, int group, int local_worker, long long* begin, long long* end);
+void y3_wino_range_impl(int units, int ksteps, int workers, int group, int local_worker, int hybrid, long long* begin,
+                        long long* end);
 int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                          const float* w_d, const float* ones, const float* zeros, int accumulate, float* dx,
                          void* workspace, size_t workspace_bytes, const y3_sk_opts* sk = nullptr);
