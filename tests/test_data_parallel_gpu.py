@@ -68,24 +68,11 @@ def _worker(rank, world, init_file, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_train_steps_on_device_tensors():
-    d = tempfile.mkdtemp()
-    mp.spawn(_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
-    r0, r1 = np.load(os.path.join(d, 'r0.npz')), np.load(os.path.join(d, 'r1.npz'))
-    m0 = torch.load(os.path.join(d, 'm0.pt'))
-    assert m0['world'] == 2 and m0['buckets'] >= 8
-    assert all(k >= 2 for k in m0['issued_before_end']), 'no bucket was issued before backward finished: nothing overlaps'
-    # the trainable variables end identical on both ranks (the BN moving statistics are per rank: no sync-BN, like the reference)
-    for k in r0.files:
-        if k.endswith(('moving_mean', 'moving_variance')):
-            continue
-        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
-    assert np.abs(r0['yolov3/darknet53_body/Conv/BatchNorm/moving_mean'] -
-                  r1['yolov3/darknet53_body/Conv/BatchNorm/moving_mean']).max() > 0       # different shards, different statistics
-
-    # single-process replay of the step: local gradients of the two shards by hand -> mean -> clip -> momentum update
+def _replay(_, out_dir):
+    """Local gradients of the two shards by hand -> mean -> clip -> momentum update, in one process."""
     from yolov3_tensorflow_amd import training
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    torch.cuda.set_device(0)
     grads = []
     for rank in range(2):
         y3, model = _setup()
@@ -105,8 +92,30 @@ def test_two_rank_train_steps_on_device_tensors():
         trainer.backward()
         trainer.flat.copy_((grads[0] + grads[1]) * 0.5)       # what the exchange + grad_scale produce
         trainer.apply_gradients()
-    after1 = {v.op_name: v.numpy() for v in y3.global_variables(scope='yolov3')}
-    for k, want in after1.items():
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, 'replay.npz'), **{v.op_name: v.numpy() for v in y3.global_variables(scope='yolov3')})
+
+
+def test_two_rank_train_steps_on_device_tensors():
+    d = tempfile.mkdtemp()
+    mp.spawn(_worker, args=(2, os.path.join(d, 'init'), d), nprocs=2, join=True)
+    r0, r1 = np.load(os.path.join(d, 'r0.npz')), np.load(os.path.join(d, 'r1.npz'))
+    m0 = torch.load(os.path.join(d, 'm0.pt'))
+    assert m0['world'] == 2 and m0['buckets'] >= 8
+    assert all(k >= 2 for k in m0['issued_before_end']), 'no bucket was issued before backward finished: nothing overlaps'
+    # the trainable variables end identical on both ranks (the BN moving statistics are per rank: no sync-BN, like the reference)
+    for k in r0.files:
         if k.endswith(('moving_mean', 'moving_variance')):
             continue
-        np.testing.assert_allclose(r0[k], want, rtol=2e-6, atol=1e-7, err_msg=k)
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    assert np.abs(r0['yolov3/darknet53_body/Conv/BatchNorm/moving_mean'] -
+                  r1['yolov3/darknet53_body/Conv/BatchNorm/moving_mean']).max() > 0       # different shards, different statistics
+
+    # single-process replay of the step (in its own process: it resets the default graph, which the session-scoped
+    # model of the other test files lives in)
+    mp.spawn(_replay, args=(d,), nprocs=1, join=True)
+    after1 = np.load(os.path.join(d, 'replay.npz'))
+    for k in after1.files:
+        if k.endswith(('moving_mean', 'moving_variance')):
+            continue
+        np.testing.assert_allclose(r0[k], after1[k], rtol=2e-6, atol=1e-7, err_msg=k)
