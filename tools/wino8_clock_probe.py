@@ -23,12 +23,17 @@ def main():
         for _ in range(3):
             y = engine.conv2d_fwd_wino(x, wu, sc, sh, cout, True)
         torch.cuda.synchronize()
-        c = y.view(-1)[:32].view(torch.int64).cpu().numpy()
+        c = y.view(-1)[:64].view(torch.int64).cpu().numpy()
         for half in (0, 1):
-            total, steps = int(c[half * 8]), max(int(c[half * 8 + 1]), 1)
-            ph = [int(v) / steps for v in c[half * 8 + 2: half * 8 + 8]]
+            o = half * 16
+            total, steps = int(c[o]), max(int(c[o + 1]), 1)
+            ph = [int(v) / steps for v in c[o + 2: o + 8]]
+            segs = max(int(c[o + 8]), 1)
+            sg = [int(v) / segs for v in c[o + 9: o + 15]]
             print('H=%3d %4d->%4d half %d: kernel %d cycles, %d K-steps in loops, %.0f cycles per K-step: ' % (h, cin, cout, half, total, steps, sum(ph))
                   + ' | '.join('%.0f' % v for v in ph), flush=True)
+            print('      %d segments, cycles per segment: prologue %.0f | K-loop + last K-step %.0f | output transform %.0f | '
+                  'stream-K wait %.0f | next-segment prefetch %.0f | finish / publish %.0f' % ((segs,) + tuple(sg)), flush=True)
 
 
 if __name__ == '__main__':

@@ -21,7 +21,7 @@ def main():
         w = torch.randn((3, 3, cin, cout), device=dev) * float(np.sqrt(2.0 / (9 * cin)))
         wu = engine.pack_wino(w)
         sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-        r = torch.randn((n, h, h, cout), device=dev)
+        r = None if os.environ.get('Y3_PROBE_NORES') else torch.randn((n, h, h, cout), device=dev)
         for _ in range(5):
             engine.conv2d_fwd_wino(x, wu, sc, sh, cout, True, residual=r)
         iters = 40

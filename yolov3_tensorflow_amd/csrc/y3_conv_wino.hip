@@ -850,8 +850,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 
     float* cs = reinterpret_cast<float*>(smem);
 #ifdef Y3_WINO8_CLOCK
-    unsigned long long clk_phase[6] = {0, 0, 0, 0, 0, 0}, clk_steps = 0;
+    unsigned long long clk_phase[6] = {0, 0, 0, 0, 0, 0}, clk_steps = 0, clk_seg[6] = {0, 0, 0, 0, 0, 0}, clk_segs = 0, ts[7];
+#define W8_S(i) do { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#else
+#define W8_S(i)
 #endif
     setup_voff(first_blk);
     issue(first_ks);
@@ -866,10 +869,12 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         const bool has_next = whole_next || seg_end < item_end;
         const int next_blk = whole_next ? blk + (p.workers >> 3) : (int)(seg_end / ksteps);
         const int next_ks = whole_next ? 0 : (int)(seg_end - (long long)next_blk * ksteps);
+        W8_S(0);
         setup_tables(blk);
         store(0);
         __syncthreads();
         frags(0, 0, a0, b0);
+        W8_S(1);
         // The two position halves run the K-step in OPPOSITE phase, so that one wave of every SIMD has MFMAs to issue
         // while the other one waits for its loads, transforms and writes the next K-step's tiles:
         //   ph 0: 16 MFMAs(ks) | transform + LDS writes(ks+1) | loads(ks+2) | 12 MFMAs(ks) | barrier | fragments(ks+1), last 4 MFMAs(ks)
@@ -1041,6 +1046,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
             }
         }
 
+        W8_S(2);
         // (1) this half's share of A^T M A per (tile, channel): 2x2 partial outputs -> its staging tile
         __syncthreads();
         const bool producer = STREAMK && ks0 > 0;
@@ -1056,7 +1062,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #pragma unroll
                 for (int pos = 0; pos < 8; ++pos) {
                     m[pos] = acc[pos][r];
+#if defined(Y3_WINO8_TAILBAR)
                     asm volatile("" : "+v"(m[pos]));
+#endif
                 }
                 // rows 0,1 of M (ph 0): s0 = m0 + m1, s1 = m1;  rows 2,3 (ph 1): s0 = m2, s1 = -m2 - m3
                 float s0[4], s1[4];
@@ -1070,10 +1078,13 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 row[1 * LDC] = s0[1] - s0[2] - s0[3];
                 row[2 * LDC] = s1[0] + s1[1] + s1[2];
                 row[3 * LDC] = s1[1] - s1[2] - s1[3];
+#if defined(Y3_WINO8_TAILBAR)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
         __syncthreads();
+        W8_S(3);
         int n_extra = 0;
         if (STREAMK && ks1 < ksteps) {
             const int G = p.workers >> 3;
@@ -1098,11 +1109,13 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
             }
             __syncthreads();
         }
+        W8_S(4);
         if (STREAMK && has_next) {
             setup_voff(next_blk);
             issue(next_ks);
             __builtin_amdgcn_sched_barrier(0);
         }
+        W8_S(5);
         if (!producer) {
             static_assert(WinoRows<BT, BNW, NT, true>::PASSES == 8, "one accumulator set is reset per store pass");
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -1153,15 +1166,23 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (STREAMK) __syncthreads();
+        W8_S(6);
+#ifdef Y3_WINO8_CLOCK
+#pragma unroll
+        for (int i = 0; i < 6; ++i) clk_seg[i] += ts[i + 1] - ts[i];
+        ++clk_segs;
+#endif
         if (whole) { --dp_left; dp_blk += p.workers >> 3; }
         item = seg_end;
     }
 #ifdef Y3_WINO8_CLOCK
     if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.y) + (wave >> 2) * 8;
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.y) + (wave >> 2) * 16;
         out[0] = __builtin_amdgcn_s_memtime() - clk0;
         out[1] = clk_steps;
         for (int k = 0; k < 6; ++k) out[2 + k] = clk_phase[k];
+        out[8] = clk_segs;
+        for (int k = 0; k < 6; ++k) out[9 + k] = clk_seg[k];
     }
 #endif
 }
