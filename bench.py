@@ -20,7 +20,7 @@ Workloads
 Prints ONE JSON line on rank 0.
 
 roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the
-Winograd F(2x2,3x3) kernel conv_wino_f32_kernel (the stride-1 3x3 convs: 32 launches, ~65 % of the step).
+Winograd F(2x2,3x3) kernel conv_wino8_f32_kernel (the stride-1 3x3 convs: 32 launches, ~65 % of the step).
 `achieved` = the MFMA work those launches ISSUE (16/36 of the direct-convolution FLOPs) / the sum of their durations,
 measured with hipEvents recorded on the launch stream inside the timed region; `peak` = 157.3 TFLOP/s (fp32 MFMA);
 `frac` = achieved / peak.  `achieved_algorithmic` counts the direct-convolution FLOPs (it may exceed `peak`: Winograd
@@ -137,9 +137,10 @@ def conv_bytes(table, n, h, w, esize=4):
 
 
 def traffic_from_profile(names):
-    """HBM-side bytes per launch of the dominant kernel from a committed PMC pass (profiles/*.json: FETCH_SIZE x2 +
-    WRITE_SIZE collected with rocprofv3 --pmc over this same command; rocprofv3 cannot run inside this process, so
-    this is a static figure and is labelled as such).  Returns (bytes or None, source)."""
+    """HBM-side bytes per launch of the dominant kernel from a committed PMC pass (profiles/*.json; round 2: the
+    byte-weighted TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B counters over one forward of this workload,
+    tools/pmc_layers.py + tools/pmc_traffic_layers.py; rocprofv3 cannot run inside this process, so this is a static
+    figure and is labelled as such).  Returns (bytes or None, source)."""
     for name in names:
         path = os.path.join(ROOT, 'profiles', name)
         try:
@@ -558,7 +559,7 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else
-              "conv_wino_f32_kernel (Winograd F(2x2,3x3) conv, fp32 MFMA): `achieved` = MFMA work ISSUED (16/36 of the "
+              "conv_wino8_f32_kernel (Winograd F(2x2,3x3) conv, fp32 MFMA, two waves per SIMD): `achieved` = MFMA work ISSUED (16/36 of the "
               "direct-convolution FLOPs) per second; `achieved_algorithmic` counts the direct-convolution FLOPs" if wino else
               "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, stream-K schedule)")
     out = {
