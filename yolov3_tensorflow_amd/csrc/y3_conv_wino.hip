@@ -765,7 +765,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 for (int j = 0; j < 4; ++j) {
                     const int yy = y0 + i, xx = x0 + j;
                     const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+#if defined(Y3_WINO8_BLOCKED_IN)   // timing experiment: activations read as [Cin/8][N][H][W][8] (garbage results)
+                    voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * 8 + a_pair * 2) * 4u : OOB;
+#else
                     voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
+#endif
                 }
         }
 #pragma unroll
@@ -779,7 +783,12 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
     f32x2 ra[12];
     f32x4 ru[4];
     auto issue = [&](int ks) {
-        const unsigned soff_a = (unsigned)(ks * WKC) * 4u, soff_u = (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
+#if defined(Y3_WINO8_BLOCKED_IN)
+        const unsigned soff_a = (unsigned)ks * (unsigned)(p.N * p.H * p.W) * 32u;
+#else
+        const unsigned soff_a = (unsigned)(ks * WKC) * 4u;
+#endif
+        const unsigned soff_u = (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
 #pragma unroll
         for (int j = 0; j < 12; ++j)
             ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
