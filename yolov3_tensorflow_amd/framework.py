@@ -116,6 +116,19 @@ def variable_scope(name):
         stack.pop()
 
 
+@contextlib.contextmanager
+def variable_scope_absolute(name):
+    """Run the block under exactly the scope `name` ('' = the root), whatever scopes are open around it: deferred
+    graph pieces (compat layer) are evaluated long after their `with variable_scope(...)` block was left."""
+    stack = _scope_stack()
+    saved = list(stack)
+    stack[:] = [(name, {})] if name else []
+    try:
+        yield
+    finally:
+        stack[:] = saved
+
+
 def current_scope_name():
     return "/".join(n for n, _ in _scope_stack())
 
