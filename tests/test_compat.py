@@ -55,6 +55,68 @@ def test_reference_convert_script_runs_unchanged_in_dry_run(tmp_path):
     assert 'checkpoint has been saved' in out
 
 
+def _tiny_eval_set(root, count=3, seed=0):
+    """A few random PNGs + an annotation file in the reference's line format; returns the file's path."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, 'imgs'), exist_ok=True)
+    lines = []
+    for i in range(count):
+        w, h = int(rng.randint(200, 400)), int(rng.randint(150, 300))
+        path = os.path.join(root, 'imgs', '%d.png' % i)
+        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(path)
+        lines.append('%d %s %d %d 3 20 30 120 140 17 50 60 150 145' % (i, path, w, h))
+    val = os.path.join(root, 'val.txt')
+    with open(val, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return val
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='the reference checkout is not on this machine')
+def test_reference_eval_script_runs_unchanged_in_dry_run(tmp_path):
+    """tf.data pipeline + py_func feeder (which really reads and resizes the images), flag placeholders, the per-image
+    Session.run loop and the mAP report of the reference's eval.py, byte-unchanged, without a device."""
+    os.makedirs(tmp_path / 'data')
+    for f in ('yolo_anchors.txt', 'coco.names'):
+        with open(os.path.join(ROOT, 'data', f)) as src, open(tmp_path / 'data' / f, 'w') as dst:
+            dst.write(src.read())
+    val = _tiny_eval_set(str(tmp_path))
+    rc, out = _run(os.path.join(REF, 'eval.py'), ['--eval_file', val], str(tmp_path), {'Y3_COMPAT_DRY_RUN': '1'})
+    assert rc == 0, out[-3000:]
+    assert 'final mAP: 0.0000' in out and 'total_loss: 0.000' in out
+
+
+def test_tf_data_pipeline_and_py_func(tmp_path):
+    from yolov3_tensorflow_amd import compat
+    from yolov3_tensorflow_amd.compat import lazy
+    compat.install()
+    try:
+        import tensorflow as tf
+        p = tmp_path / 'lines.txt'
+        p.write_text('a 1\nb 2\nc 3\nd 4\ne 5\n')
+        seen = []
+
+        def host(batch, k):
+            seen.append([x.decode() for x in batch])
+            return np.int64(len(batch) * k), np.asarray([float(x.split()[1]) for x in batch], np.float32)
+        ds = tf.data.TextLineDataset(str(p)).batch(2).map(lambda x: tf.py_func(host, [x, 10], [tf.int64, tf.float32]))
+        ds.prefetch(3)                                          # result discarded, like ref eval.py:82
+        n, v = ds.make_one_shot_iterator().get_next()
+        v.set_shape([None])
+        with tf.Session() as sess:
+            got = [sess.run([n, v]) for _ in range(3)]
+            assert [int(g[0]) for g in got] == [20, 20, 10] and got[2][1].tolist() == [5.0]
+            assert got[0][0].dtype == np.int64 and got[0][1].dtype == np.float32
+            assert seen == [['a 1', 'b 2'], ['c 3', 'd 4'], ['e 5']]      # one pull per Session.run, shared by both outputs
+            with pytest.raises(tf.errors.OutOfRangeError):
+                sess.run(n)
+        assert isinstance(n, lazy.Node) and n.host                    # host-only work also runs in a dry run
+    finally:
+        sys.path.remove(compat.SHIM_DIR)
+        for m in [m for m in sys.modules if m.split('.')[0] in ('tensorflow', 'cv2')]:
+            del sys.modules[m]
+
+
 def test_cv2_shim_known_values(tmp_path):
     from yolov3_tensorflow_amd import compat
     compat.install()
@@ -146,3 +208,35 @@ def test_tf1_style_scripts_reproduce_the_golden_detections(tmp_path):
     from PIL import Image
     with Image.open(jpg) as im:
         assert im.size == (1296, 729)
+
+
+@pytest.mark.gpu
+def test_tf1_style_eval_matches_the_native_eval_script(tmp_path):
+    """The TF-1 style evaluation twin (tf.data + py_func feeder, flag placeholders, per-image Session.run) against this
+    package's own eval.py on the same tiny annotation file and weights: same mAP, same detections, same mean loss."""
+    import json
+    from oracle import yolo_ref
+    weights = str(tmp_path / 'synthetic.weights')
+    yolo_ref.write_darknet(yolo_ref.synthetic_params(80, seed=1), weights)
+    val = _tiny_eval_set(str(tmp_path), count=4, seed=3)
+    rep = str(tmp_path / 'report.json')
+    rc, out = _run(os.path.join(HERE, 'compat_scripts', 'tf1_eval.py'),
+                   ['--eval_file', val, '--restore_path', weights, '--anchor_path', ANCHORS_TXT, '--json', rep,
+                    '--score_threshold', '0.02'], ROOT)
+    assert rc == 0, out[-3000:]
+    got = json.load(open(rep))
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'eval.py'), '--eval_file', val, '--restore_path', weights,
+                        '--anchor_path', ANCHORS_TXT, '--class_name_path', os.path.join(ROOT, 'data', 'coco.names'),
+                        '--batch_size', '1', '--score_threshold', '0.02'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    native = r.stdout.decode(errors='replace')
+    assert r.returncode == 0, native[-3000:]
+    import re
+    m_ap = float(re.search(r'final mAP: ([0-9.naNA]+)', native).group(1))        # nan when a class has no ground truth
+    total = float(re.search(r'total_loss: ([0-9.]+)', native).group(1))        # (0/0 in voc_eval, like the reference)
+    assert np.isclose(got['mAP'], m_ap, atol=1e-4, equal_nan=True), (got, m_ap)
+    per_class = dict((int(c), float(a)) for c, a in re.findall(r'Class (\d+): .*AP: ([0-9.]+)', native))
+    assert per_class, native[-2000:]
+    assert abs(got['loss'][0] - total) <= 1e-3 * max(total, 1.0) + 6e-4, (got, total)      # the report prints 3 decimals
+    assert got['detections'] > 0

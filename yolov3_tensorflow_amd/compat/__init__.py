@@ -5,12 +5,14 @@ run BYTE-UNCHANGED on the MI355X-native path, with no TensorFlow and no OpenCV i
     python -m yolov3_tensorflow_amd.compat.run <path to the reference's test_single_image.py> ./data/demo_data/messi.jpg \
         --restore_path ./data/darknet_weights/yolov3.ckpt
     python -m yolov3_tensorflow_amd.compat.run <path to the reference's convert_weight.py>
+    python -m yolov3_tensorflow_amd.compat.run <path to the reference's eval.py> --eval_file ./data/my_data/val.txt
 
 `run` puts `compat/shims` at the front of sys.path for that one process; the modules there carry the names the scripts
 import (ref: test_single_image.py:5-15, convert_weight.py:8-12):
 
     tensorflow   a deferred graph of exactly the symbols those scripts touch - placeholder, Session.run(fetches,
-                 feed_dict), variable_scope, global_variables, train.Saver - evaluated by this package's eager ops
+                 feed_dict), variable_scope, global_variables, train.Saver, the tf.data text-line pipeline + py_func of
+                 eval.py - evaluated by this package's eager ops
     cv2          imread / imwrite / resize / cvtColor / rectangle / putText / getTextSize on numpy + PIL; imshow and
                  waitKey do nothing (there is no display)
     model        class yolov3 with the reference's methods, accepting graph tensors

@@ -8,8 +8,10 @@ class Node(object):
     """One graph tensor.  fn(*evaluated args) -> value; `index` picks one output of a multi-output op; `empty` is what
     a dry run (no device) returns for it."""
 
-    def __init__(self, fn, args=(), name=None, index=None, empty=None, shape=None):
+    def __init__(self, fn, args=(), name=None, index=None, empty=None, shape=None, host=False):
         self.fn, self.args, self.name, self.index, self.empty, self._shape = fn, tuple(args), name, index, empty, shape
+        self.dtype = None
+        self.host = host          # pure host work (input pipeline): also evaluated in a dry run
 
     # the arithmetic the driver scripts apply to graph tensors (ref: test_single_image.py:55 `pred_confs * pred_probs`)
     def __mul__(self, other):
@@ -57,11 +59,11 @@ def is_node(x):
     return False
 
 
-def multi(fn, args, nout, name, empties=None):
+def multi(fn, args, nout, name, empties=None, host=False):
     """An op with `nout` outputs: one hidden node computing the tuple, `nout` visible nodes indexing it."""
-    whole = Node(fn, args, name=name)
+    whole = Node(fn, args, name=name, host=host)
     return tuple(Node(lambda t, i=i: t[i], (whole,), name='%s:%d' % (name, i), index=i,
-                      empty=None if empties is None else empties[i]) for i in range(nout))
+                      empty=None if empties is None else empties[i], host=host) for i in range(nout))
 
 
 def _to_numpy(v):
@@ -110,7 +112,7 @@ def evaluate(fetches, feed_dict=None, dry=False):
         if isinstance(x, (list, tuple)):
             return [out(v) for v in x]
         if isinstance(x, Node):
-            if dry:
+            if dry and not x.host:
                 return x.empty
             return _to_numpy(ev(x))
         if hasattr(x, 'run'):          # an assign op (utils.misc_utils.AssignOp) or a group of them

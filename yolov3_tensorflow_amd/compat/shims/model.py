@@ -15,7 +15,7 @@ class yolov3(_y3.yolov3):
     def forward(self, inputs, is_training=False, reuse=False):
         if not _lazy.is_node(inputs):
             return _y3.yolov3.forward(self, inputs, is_training, reuse)
-        if is_training:
+        if is_training is True:
             raise NotImplementedError("the compat graph runs inference only; train through train.py of this package")
         scope = _fw.current_scope_name()
         shape = inputs.get_shape()
@@ -25,13 +25,27 @@ class yolov3(_y3.yolov3):
             with _y3.variable_scope_absolute(scope):
                 self._get_net(_fw.default_device())            # creates the variables in the reference's order
 
-        def run(x):
+        def run(x, training_flag):
+            if bool(training_flag):        # eval.py feeds its `is_training` placeholder with False (ref: eval.py:66,116)
+                raise NotImplementedError("the compat graph runs inference only (is_training was fed True)")
+            self.img_size = [int(x.shape[1]), int(x.shape[2])]
             with _y3.variable_scope_absolute(scope):
                 return _y3.yolov3.forward(self, x, False, reuse)
 
         det = 3 * (5 + self.class_num)
         empties = [_np.zeros((0, 0, 0, det), _np.float32)] * 3
-        return _lazy.multi(run, (inputs,), 3, 'yolov3/forward', empties)
+        return _lazy.multi(run, (inputs, is_training), 3, 'yolov3/forward', empties)
+
+    def compute_loss(self, y_pred, y_true):
+        if not (_lazy.is_node(y_pred) or _lazy.is_node(y_true)):
+            return _y3.yolov3.compute_loss(self, y_pred, y_true)
+
+        def run(*args):
+            loss = _y3.yolov3.compute_loss(self, list(args[:3]), list(args[3:]))
+            return tuple(float(v) for v in loss)
+
+        return list(_lazy.multi(run, tuple(y_pred) + tuple(y_true), 5, 'yolov3/compute_loss',
+                                [_np.float32(0.0)] * 5))
 
     def predict(self, feature_maps, with_scores=False):
         if not _lazy.is_node(feature_maps):

@@ -11,6 +11,7 @@ from yolov3_tensorflow_amd.compat import lazy as _lazy
 __version__ = '1.15.0-yolo355-compat'
 
 float32, float64, int32, int64, uint8, bool = _np.float32, _np.float64, _np.int32, _np.int64, _np.uint8, _np.bool_
+string = _np.object_
 
 Tensor = _lazy.Node
 
@@ -125,3 +126,118 @@ class _Train(object):
 
 
 train = _Train()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tf.py_func / tf.data: the input pipeline of eval.py (ref: eval.py:75-92) as Python iterators behind graph tensors
+# ---------------------------------------------------------------------------------------------------------------
+class _Errors(object):
+    class OutOfRangeError(Exception):
+        """Raised by Session.run when a one-shot iterator is exhausted (tf.errors.OutOfRangeError)."""
+
+
+errors = _Errors()
+
+
+def py_func(func, inp, Tout, stateful=True, name=None):
+    """tf.py_func: `func` runs on the host with the evaluated inputs (numpy arrays / Python values); one graph tensor
+    per entry of Tout, cast to that dtype."""
+    single = not isinstance(Tout, (list, tuple))
+    touts = [Tout] if single else list(Tout)
+
+    def call(*args):
+        res = func(*args)
+        res = [res] if single else list(res)
+        if len(res) != len(touts):
+            raise ValueError("py_func: the function returned %d values, Tout names %d" % (len(res), len(touts)))
+        return tuple(_np.asarray(r, dtype=t) for r, t in zip(res, touts))
+
+    host = all(getattr(a, 'host', True) for a in inp)          # constants and host tensors only -> runs in a dry run too
+    outs = _lazy.multi(call, tuple(inp), len(touts), name or 'PyFunc', [_np.zeros((0,), t) for t in touts], host=host)
+    return outs[0] if single else list(outs)
+
+
+class _Dataset(object):
+    """The slice of tf.data the reference uses: TextLineDataset -> shuffle / batch / map / prefetch -> one-shot
+    iterator.  `source()` returns a fresh Python iterator of elements; `graph` maps an element tensor to output tensors."""
+
+    def __init__(self, source, graph=None):
+        self._source, self._graph = source, graph
+
+    def batch(self, batch_size, drop_remainder=False):
+        src = self._source
+
+        def batched():
+            chunk = []
+            for item in src():
+                chunk.append(item)
+                if len(chunk) == batch_size:
+                    yield _np.asarray(chunk, dtype=object)
+                    chunk = []
+            if chunk and not drop_remainder:
+                yield _np.asarray(chunk, dtype=object)
+        return _Dataset(batched, self._graph)
+
+    def shuffle(self, buffer_size, seed=None, reshuffle_each_iteration=None):
+        src = self._source
+
+        def shuffled():
+            items = list(src())
+            _np.random.RandomState(seed).shuffle(items)
+            return iter(items)
+        return _Dataset(shuffled, self._graph)
+
+    def map(self, map_func, num_parallel_calls=None):
+        prev = self._graph
+        return _Dataset(self._source, (lambda x: map_func(prev(x))) if prev else map_func)
+
+    def prefetch(self, buffer_size):
+        return self
+
+    def repeat(self, count=None):
+        src = self._source
+
+        def repeated():
+            n = 0
+            while count is None or n < count:
+                for item in src():
+                    yield item
+                n += 1
+        return _Dataset(repeated, self._graph)
+
+    def make_one_shot_iterator(self):
+        return _Iterator(self)
+
+
+class _Iterator(object):
+    def __init__(self, dataset):
+        self._dataset, self._it = dataset, None
+
+    def get_next(self, name=None):
+        def pull():
+            if self._it is None:
+                self._it = iter(self._dataset._source())
+            try:
+                return next(self._it)
+            except StopIteration:
+                raise errors.OutOfRangeError('End of sequence')
+        element = _lazy.Node(pull, (), name='IteratorGetNext', empty=_np.zeros((0,), object), host=True)
+        return self._dataset._graph(element) if self._dataset._graph else element
+
+
+class _Data(object):
+    Dataset = _Dataset
+
+    @staticmethod
+    def TextLineDataset(filenames):
+        names = [filenames] if isinstance(filenames, str) else list(filenames)
+
+        def lines():
+            for name in names:
+                with open(name, 'rb') as f:
+                    for line in f:
+                        yield line.rstrip(b'\r\n')
+        return _Dataset(lines)
+
+
+data = _Data()
