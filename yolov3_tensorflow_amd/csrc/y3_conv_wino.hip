@@ -947,6 +947,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_MFMAS(2, a0, b0, 0, 4);
                 W8_MFMAS(3, a1, b1, 0, 2);
 #else
+#ifdef Y3_WINO8_CLOCK
+                tk[1] = tk[2] = tk[0];       // phases of ph 0: - | - | loads + 28 MFMAs | staging | barrier | fragments + 4 MFMAs
+#endif
                 W8_ISSUE(ks + 1);
                 W8_FRAGS(cur, 1, a1, b1);
                 W8_MFMAS(0, a0, b0, 0, 4);
@@ -955,7 +958,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_FRAGS(cur, 3, a1, b1);
                 W8_MFMAS(2, a0, b0, 0, 4);
                 W8_MFMAS(3, a1, b1, 0, 2);
-#if !defined(Y3_WINO8_NOSCHED) && !defined(Y3_WINO8_CLOCK)
+#if !defined(Y3_WINO8_NOSCHED)
                 // the 16 loads go out two per MFMA under the first position pair (back to back they hold the wave for
                 // ~900 cycles before its first MFMA), the fragment reads one pair ahead of their MFMAs
 #pragma unroll
@@ -991,6 +994,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_STORE(cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(1);
+#if defined(Y3_WINO8_CLOCK) && !defined(Y3_WINO8_BBURST)
+                tk[2] = tk[3] = tk[1];       // phases of ph 1: staging | - | - | loads + 32 MFMAs | barrier | fragments
+#endif
 #if !defined(Y3_WINO8_BBURST)   // ph 1's loads go out under its MFMAs too (unconditional: on the last pass they re-read
                                 // K-step ks+1 - in range - and are never used); BBURST = back to back (+4..11 %)
                 W8_ISSUE(ks + 2 < ks1 ? ks + 2 : ks + 1);
