@@ -24,6 +24,7 @@
 // Numerics: the transforms use only additions and the constants 1/2, so the result differs from the direct sum by a
 // few fp32 roundings per term (tests/test_conv_gpu.py holds it to the same 1e-4 tolerance against fp64).
 #include <cstdlib>
+#include <type_traits>
 #include "y3_internal.h"
 
 namespace {
@@ -679,9 +680,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 // stores, the other one keeps the matrix pipe busy (the four-wave kernel measures 63 % pipe occupancy with one wave
 // per SIMD: ~1,000 exposed cycles per 4,096-cycle K-step and a 16k-cycle tail per block).
 //   * staging: thread = (position half, tile, channel pair) loads the three patch rows its two transform rows need
-//     (12 x 8 bytes), forms X = e0 - e2 and Y = e1 + c0*e0 + c2*e2 ((c0, c2) = (0, 1) for rows 0,1: Y = d1 + d2;
-//     (-1, 0) for rows 2,3: Y = d2 - d1, X = d1 - d3 - multiplications by 0 / +-1, exact), the column transform, and
-//     writes 8 positions; four 16-byte weight pieces per thread;
+//     (12 x 8 bytes), forms X = e0 - e2 and Y = e1 + e2 (rows 0,1: d0 - d2, d1 + d2) or e1 - e0 (rows 2,3: Y = d2 - d1,
+//     X = d1 - d3) - the half is the wave's position half, a compile-time constant on either side of the K-step's
+//     phase branch -, the column transform, and writes 8 positions; four 16-byte weight pieces per thread;
 //   * tail: each half applies A^T . A to its two rows of M (linear), the two partial 2x2 outputs go to two staging
 //     tiles and are summed when the rows are read back.
 template <bool STREAMK, bool STATS = false>
@@ -799,12 +800,12 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         for (int j = 0; j < 4; ++j)
             ru[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[j], soff_u, Y3_WINO8_UAUX));
     };
-    // rows of the transform this thread produces: X -> row (half ? 3 : 0), Y -> row (half ? 2 : 1)
-    const float c0s = a_half ? -1.f : 0.f, c2s = a_half ? 0.f : 1.f;
-    const f32x2 c0 = {c0s, c0s}, c2 = {c2s, c2s};
+    // rows of the transform this thread produces: X -> row (half ? 3 : 0), Y -> row (half ? 2 : 1).  The half is the
+    // wave's position half (a_half == ph: threads 256.. are waves 4-7), so it is a compile-time constant on each side of
+    // the K-step's phase branch: no multiplications by 0 / +-1 are needed to keep the K-step branch-free.
     const int st_a = lds_off(a_tile, a_pair >> 1) + (a_pair & 1) * 8;
-    const int st_x = st_a + (a_half ? 12 : 0) * PLANE_V, st_y = st_a + (a_half ? 8 : 4) * PLANE_V;
-    auto store = [&](int buf) {
+    auto store = [&](int buf, auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
         unsigned char* us = Us + buf * STAGE_U;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -815,11 +816,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         f32x2 x[4], y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            x[j] = ra[0 * 4 + j] - ra[2 * 4 + j];
-            y[j] = __builtin_elementwise_fma(c0, ra[0 * 4 + j], __builtin_elementwise_fma(c2, ra[2 * 4 + j], ra[1 * 4 + j]));
+            x[j] = ra[0 * 4 + j] - ra[2 * 4 + j];                                   // rows 0 / 3: d0 - d2 / d1 - d3
+            y[j] = HALF ? ra[1 * 4 + j] - ra[0 * 4 + j] : ra[1 * 4 + j] + ra[2 * 4 + j];     // rows 1 / 2: d1 + d2 / d2 - d1
         }
-        unsigned char* vx = Vs + buf * STAGE_V + st_x;
-        unsigned char* vy = Vs + buf * STAGE_V + st_y;
+        unsigned char* vx = Vs + buf * STAGE_V + st_a + (HALF ? 12 : 0) * PLANE_V;
+        unsigned char* vy = Vs + buf * STAGE_V + st_a + (HALF ? 8 : 4) * PLANE_V;
         *reinterpret_cast<f32x2*>(vx + 0 * PLANE_V) = x[0] - x[2];
         *reinterpret_cast<f32x2*>(vx + 1 * PLANE_V) = x[1] + x[2];
         *reinterpret_cast<f32x2*>(vx + 2 * PLANE_V) = x[2] - x[1];
@@ -880,7 +881,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         const int next_ks = whole_next ? 0 : (int)(seg_end - (long long)next_blk * ksteps);
         W8_S(0);
         setup_tables(blk);
-        store(0);
+        if (ph) store(0, std::integral_constant<int, 1>());
+        else store(0, std::integral_constant<int, 0>());
         __syncthreads();
         frags(0, 0, a0, b0);
         W8_S(1);
@@ -899,9 +901,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #define W8_ISSUE(k) issue(k)
 #endif
 #if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 2)
-#define W8_STORE(b)
+#define W8_STORE(b, h)
 #else
-#define W8_STORE(b) store(b)
+#define W8_STORE(b, h) store(b, std::integral_constant<int, h>())
 #endif
 #if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 4)
 #define W8_FRAGS(b, g, x, y)
@@ -938,7 +940,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_MFMAS(1, a1, b1, 0, 4);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(1);
-                W8_STORE(cur ^ 1);
+                W8_STORE(cur ^ 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(2);
                 if (ks + 2 < ks1) W8_ISSUE(ks + 2);
@@ -981,7 +983,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(3);
-                W8_STORE(cur ^ 1);
+                W8_STORE(cur ^ 1, 0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(4);
@@ -991,7 +993,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_MFMAS(3, a1, b1, 2, 4);
                 W8_T(6);
             } else {
-                W8_STORE(cur ^ 1);
+                W8_STORE(cur ^ 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(1);
 #if defined(Y3_WINO8_CLOCK) && !defined(Y3_WINO8_BBURST)
