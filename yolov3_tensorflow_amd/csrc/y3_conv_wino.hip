@@ -793,12 +793,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #pragma unroll
         for (int j = 0; j < 12; ++j)
             ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
-#ifndef Y3_WINO8_UAUX
-#define Y3_WINO8_UAUX 0
-#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            ru[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[j], soff_u, Y3_WINO8_UAUX));
+            ru[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[j], soff_u, 0));
     };
     // rows of the transform this thread produces: X -> row (half ? 3 : 0), Y -> row (half ? 2 : 1).  The half is the
     // wave's position half (a_half == ph: threads 256.. are waves 4-7), so it is a compile-time constant on each side of
@@ -920,11 +917,23 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #else
 #define W8_T(i)
 #endif
-#if defined(Y3_WINO8_AMID)
-        if (ks0 + 1 < ks1) issue(ks0 + 1);
-#else
+        // (a macro: sched_group_barrier wants literal counts) the wave's 16 loads go out two per MFMA under its first
+        // position pair - back to back they hold the wave for ~900 cycles before its first MFMA - and the fragment reads
+        // one pair ahead of their MFMAs; TAIL = MFMAs left after the three full pairs
+#define W8_WEAVE(TAIL)                                                   \
+    do {                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);           \
+            if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+        }                                                                \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+            if ((i & 7) >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+        }                                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, TAIL, 0);            \
+    } while (0)
         if (ph && ks0 + 1 < ks1) issue(ks0 + 1);
-#endif
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
             const int cur = (ks - ks0) & 1;
             f32x4 a1[2], b1[2];
@@ -933,22 +942,6 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #endif
             W8_T(0);
             if (ph == 0) {
-#if defined(Y3_WINO8_AMID)      // experiment: ph 0 stages in the middle of its MFMAs (both halves fetch a K-step ahead)
-                W8_FRAGS(cur, 1, a1, b1);
-                W8_MFMAS(0, a0, b0, 0, 4);
-                W8_FRAGS(cur, 2, a0, b0);
-                W8_MFMAS(1, a1, b1, 0, 4);
-                __builtin_amdgcn_sched_barrier(0);
-                W8_T(1);
-                W8_STORE(cur ^ 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                W8_T(2);
-                if (ks + 2 < ks1) W8_ISSUE(ks + 2);
-                W8_T(3);
-                W8_FRAGS(cur, 3, a1, b1);
-                W8_MFMAS(2, a0, b0, 0, 4);
-                W8_MFMAS(3, a1, b1, 0, 2);
-#else
 #ifdef Y3_WINO8_CLOCK
                 tk[1] = tk[2] = tk[0];       // phases of ph 0: - | - | loads + 28 MFMAs | staging | barrier | fragments + 4 MFMAs
 #endif
@@ -960,31 +953,10 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_FRAGS(cur, 3, a1, b1);
                 W8_MFMAS(2, a0, b0, 0, 4);
                 W8_MFMAS(3, a1, b1, 0, 2);
-#if !defined(Y3_WINO8_NOSCHED)
-                // the 16 loads go out two per MFMA under the first position pair (back to back they hold the wave for
-                // ~900 cycles before its first MFMA), the fragment reads one pair ahead of their MFMAs
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#endif
+                W8_WEAVE(4);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(3);
                 W8_STORE(cur ^ 1, 0);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(4);
                 __syncthreads();
@@ -996,11 +968,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_STORE(cur ^ 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(1);
-#if defined(Y3_WINO8_CLOCK) && !defined(Y3_WINO8_BBURST)
+#ifdef Y3_WINO8_CLOCK
                 tk[2] = tk[3] = tk[1];       // phases of ph 1: staging | - | - | loads + 32 MFMAs | barrier | fragments
 #endif
-#if !defined(Y3_WINO8_BBURST)   // ph 1's loads go out under its MFMAs too (unconditional: on the last pass they re-read
-                                // K-step ks+1 - in range - and are never used); BBURST = back to back (+4..11 %)
+                // its loads go out under its MFMAs too (unconditional: on the last pass they re-read K-step ks+1 - in
+                // range - and are never used; issued back to back after the staging they cost +4..11 %)
                 W8_ISSUE(ks + 2 < ks1 ? ks + 2 : ks + 1);
                 W8_FRAGS(cur, 1, a1, b1);
                 W8_MFMAS(0, a0, b0, 0, 4);
@@ -1009,35 +981,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 W8_FRAGS(cur, 3, a1, b1);
                 W8_MFMAS(2, a0, b0, 0, 4);
                 W8_MFMAS(3, a1, b1, 0, 4);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#else
-                if (ks + 2 < ks1) W8_ISSUE(ks + 2);
-                W8_T(2);
-                W8_FRAGS(cur, 1, a1, b1);
-                W8_MFMAS(0, a0, b0, 0, 4);
-                W8_FRAGS(cur, 2, a0, b0);
-                W8_MFMAS(1, a1, b1, 0, 4);
-                W8_T(3);
-                W8_FRAGS(cur, 3, a1, b1);
-                W8_MFMAS(2, a0, b0, 0, 4);
-                W8_MFMAS(3, a1, b1, 0, 4);
-#endif
+                W8_WEAVE(8);
                 __builtin_amdgcn_sched_barrier(0);
                 W8_T(4);
                 __syncthreads();
