@@ -14,7 +14,6 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 
 
 def main():
@@ -23,8 +22,6 @@ def main():
     cal = d['calibration_1GiB_copy']
     R, W = 'TCC_EA0_RDREQ_DRAM_32B_sum', 'TCC_EA0_WRREQ_WRITE_DRAM_32B_sum'
     fr, fw = (1 << 30) / (cal[R] * 32.0), (1 << 30) / (cal[W] * 32.0)
-    import bench
-    table = None
     rows = []
     for i, l in enumerate(d['layers']):
         rows.append(dict(layer=i, kernel=l['kernel'], read_bytes=int(l[R] * 32 * fr), write_bytes=int(l[W] * 32 * fw)))
