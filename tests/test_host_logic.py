@@ -295,3 +295,22 @@ def test_native_checkpoint_round_trip_scopes_and_optimizer_slots(tmp_path):
     misc_utils.Saver([other]).restore(path, optimizer=opt4, variables=False)
     assert other.value is None and other.op_name not in opt4.slots
 
+
+
+def test_bench_reads_the_committed_traffic_figure():
+    """bench.py's `roofline.traffic` is the committed PMC figure of the dominant kernel (rocprofv3 cannot run inside the
+    bench process): the round's file must exist, parse, and be labelled as a static figure."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    val, src = bench.traffic_from_profile(['r02_pmc_traffic_wino.json', 'r01_pmc_traffic_wino.json'])
+    with open(os.path.join(root, 'profiles', 'r02_pmc_traffic_wino.json')) as f:
+        d = json.load(f)
+    assert val == d['traffic_bytes_per_launch'] and 'r02_pmc_traffic_wino.json' in src and 'static' in src
+    assert d['read_bytes_per_launch'] + d['write_bytes_per_launch'] == d['traffic_bytes_per_launch']
+    assert abs(d['calibration']['read_factor'] - 1.0) < 1e-3 and abs(d['calibration']['write_factor'] - 1.0) < 1e-3
+    assert len(d['per_layer']) == 75 and sum('conv_wino' in r['kernel'] for r in d['per_layer']) == 32
+    assert bench.traffic_from_profile(['does_not_exist.json']) == (None, None)
