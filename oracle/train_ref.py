@@ -40,6 +40,7 @@ class TrainGraph(object):
             self.p[k] = t
         self.batch_stats = OrderedDict()   # conv name -> (mean, biased var, unbiased var)
         self.trace = OrderedDict()         # conv name -> activation (NCHW), for per-layer checks
+        self.keep_trace = True             # False: large no-grad forwards (bs=64 @416 in fp64 would pin ~48 GB)
 
     # ---- graph --------------------------------------------------------------------------------------
     def _conv(self, x, filters, k, stride=1, bn=True, act=True):
@@ -64,7 +65,8 @@ class TrainGraph(object):
         if act:
             pos = (z > 0) if self.masks is None or name not in self.masks else self.masks[name]
             z = torch.where(pos, z, LEAKY * z)
-        self.trace[name] = z
+        if self.keep_trace:
+            self.trace[name] = z
         return z
 
     def _res(self, x, f):

@@ -26,7 +26,10 @@ def _fms(rng, n, h, w, C, std=2.0):
     return [(rng.standard_normal((n, h // s, w // s, ch)) * std).astype(np.float32) for s in (32, 16, 8)]
 
 
-@pytest.mark.parametrize('n,h,w,C', [(2, 416, 416, 80), (1, 608, 608, 80), (3, 320, 480, 20), (1, 64, 32, 1)])
+@pytest.mark.parametrize('n,h,w,C', [(2, 416, 416, 80), (1, 608, 608, 80), (3, 320, 480, 20), (1, 64, 32, 1),
+                                     # large heads: 248 is the last class count on the LDS-staged kernel, 252 and 600
+                                     # need more than 64 KB of LDS per workgroup and take the 4-byte kernel
+                                     (1, 96, 64, 248), (1, 96, 64, 252), (2, 64, 64, 600)])
 def test_predict_matches_oracle(anchors, n, h, w, C):
     from oracle import yolo_ref
     rng = np.random.RandomState(h + C)

@@ -235,6 +235,14 @@ def test_bilinear_resize_follows_opencv_inter_linear():
     im, bb = resize_with_bbox(np.zeros((729, 1296, 3), np.uint8), [[100, 50, 300, 250]], 416, 416, interp=1, letterbox=False)
     np.testing.assert_allclose(bb, [[100 / 1296 * 416, 50 / 729 * 416, 300 / 1296 * 416, 250 / 729 * 416]], rtol=1e-6)
     assert im.shape == (416, 416, 3)
+    # [N,5] boxes (parse_data's box + mix-up weight, utils/data_utils.py:179-224): the fifth column is carried through
+    b5 = np.array([[100, 50, 300, 250, 0.5], [10, 20, 30, 40, 1.0], [0, 0, 8, 8, 0.25], [1, 2, 3, 4, 0.75]], np.float32)
+    im, bb = resize_with_bbox(np.zeros((729, 1296, 3), np.uint8), b5.copy(), 416, 416, interp=1, letterbox=False)
+    assert bb.shape == (4, 5)
+    np.testing.assert_array_equal(bb[:, 4], b5[:, 4])
+    np.testing.assert_allclose(bb[0, :4], [100 / 1296 * 416, 50 / 729 * 416, 300 / 1296 * 416, 250 / 729 * 416], rtol=1e-6)
+    with pytest.raises(ValueError):
+        resize_with_bbox(np.zeros((8, 8, 3), np.uint8), np.zeros((2, 3), np.float32), 4, 4)
 
 
 def test_native_checkpoint_round_trip_scopes_and_optimizer_slots(tmp_path):
@@ -297,20 +305,34 @@ def test_native_checkpoint_round_trip_scopes_and_optimizer_slots(tmp_path):
 
 
 
-def test_bench_reads_the_committed_traffic_figure():
-    """bench.py's `roofline.traffic` is the committed PMC figure of the dominant kernel (rocprofv3 cannot run inside the
-    bench process): the round's file must exist, parse, and be labelled as a static figure."""
+def test_bench_reports_traffic_only_from_a_profile_of_this_build(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from a committed PMC pass (rocprofv3 cannot run inside the bench process) and
+    is reported ONLY when that file is stamped with the hash of this build's kernel sources; a file taken on other
+    sources gives traffic = None and a source line that says why (no stale bytes next to fresh timings)."""
     import importlib.util
     import json
+    from yolov3_tensorflow_amd.build import csrc_sha16
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    val, src = bench.traffic_from_profile(['r02_pmc_traffic_wino.json', 'r01_pmc_traffic_wino.json'])
+    # the committed round-2 file: parses, self-consistent, unstamped -> stale on any later build
     with open(os.path.join(root, 'profiles', 'r02_pmc_traffic_wino.json')) as f:
         d = json.load(f)
-    assert val == d['traffic_bytes_per_launch'] and 'r02_pmc_traffic_wino.json' in src and 'static' in src
     assert d['read_bytes_per_launch'] + d['write_bytes_per_launch'] == d['traffic_bytes_per_launch']
     assert abs(d['calibration']['read_factor'] - 1.0) < 1e-3 and abs(d['calibration']['write_factor'] - 1.0) < 1e-3
     assert len(d['per_layer']) == 75 and sum('conv_wino' in r['kernel'] for r in d['per_layer']) == 32
+    if d.get('csrc_sha16') != csrc_sha16():
+        val, src = bench.traffic_from_profile(['r02_pmc_traffic_wino.json'])
+        assert val is None and 'not reported' in src
+    # a file stamped with this build's hash is reported; one with another hash is not
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles')
+    for name, sha in (('fresh.json', csrc_sha16()), ('old.json', '0' * 16)):
+        with open(tmp_path / 'profiles' / name, 'w') as f:
+            json.dump({'traffic_bytes_per_launch': 123456789, 'csrc_sha16': sha}, f)
+    val, src = bench.traffic_from_profile(['old.json', 'fresh.json'])
+    assert val == 123456789 and 'fresh.json' in src
+    val, src = bench.traffic_from_profile(['old.json'])
+    assert val is None and 'old.json' in src
     assert bench.traffic_from_profile(['does_not_exist.json']) == (None, None)

@@ -63,10 +63,48 @@ def test_config1_pipeline_on_messi_matches_the_golden_detections(gpu_model, dtyp
     want = {(int(a), int(c)): k for k, (a, c) in enumerate(zip(g['labels'], g['index']))}
     common = set(got) & set(want)
     print('%s: %d golden detections, %d on the GPU, %d in common' % (dtype, len(want), len(got), len(common)))
-    # a detection may be missing / extra only if its score is within 1e-3 of the threshold (or displaced by such a one)
+    # A detection may be missing / extra only for a stated reason, checked PER DETECTION (no blanket
+    # excuse): (a) its own score sits within 1e-3 of the threshold; (b) a same-class box with a higher-or-equal score
+    # that the other side kept overlaps it with an IoU within 2e-3 of the 0.45 decision; (c) it was displaced by a
+    # detection that is itself missing / extra (and therefore has to pass (a) or (b) on its own).
     assert len(common) >= len(want) - 2 and len(got) <= len(want) + 2
-    for key in set(want) - set(got):
-        assert abs(float(g['scores'][want[key]]) - thr) < 1e-3 or len(set(got) - set(want)) > 0, key
+    all_b = back(boxes[0].cpu().numpy().copy()).astype(np.float64)       # IoU is invariant under the letterbox map
+    all_s = scores[0].cpu().numpy()
+
+    def iou(p, q):
+        iw = min(p[2], q[2]) - max(p[0], q[0])
+        ih = min(p[3], q[3]) - max(p[1], q[1])
+        if iw <= 0 or ih <= 0:
+            return 0.0
+        inter = iw * ih
+        return inter / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - inter)
+
+    def own_margin(key, kept_by_other):
+        label, index = key
+        sc = float(all_s[index, label])
+        if abs(sc - thr) < 1e-3:
+            return 'score %.6f within 1e-3 of the threshold %.6f' % (sc, thr)
+        for (l2, i2) in kept_by_other:
+            if l2 == label and i2 != index and float(all_s[i2, label]) >= sc - 1e-3:
+                v = iou(all_b[index], all_b[i2])
+                if abs(v - 0.45) < 2e-3:
+                    return 'IoU %.5f with kept box %d within 2e-3 of 0.45' % (v, i2)
+        return None
+
+    missing, extra = set(want) - set(got), set(got) - set(want)
+    reasons = {k: own_margin(k, got) for k in missing}
+    reasons.update({k: own_margin(k, want) for k in extra})
+    for group, others in ((missing, extra), (extra, missing)):
+        for key in group:
+            if reasons[key] is None:        # (c): displaced by a justified detection of the opposite kind
+                for o in others:
+                    if o[0] == key[0] and reasons[o] is not None and iou(all_b[key[1]], all_b[o[1]]) > 0.45 - 2e-3:
+                        reasons[key] = 'displaced by %s (%s)' % (o, reasons[o])
+                        break
+    for key in sorted(missing | extra):
+        print('%s: %s detection %s: %s' % (dtype, 'missing' if key in missing else 'extra', key, reasons[key]))
+        assert reasons[key] is not None, ('%s detection (label, box) = %s has no margin that explains it'
+                                          % ('missing' if key in missing else 'extra', key))
     gi = np.array([got[k] for k in sorted(common)])
     wi = np.array([want[k] for k in sorted(common)])
     np.testing.assert_allclose(s[gi], g['scores'][wi], atol=1e-3, rtol=0)

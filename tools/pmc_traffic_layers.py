@@ -10,10 +10,12 @@ the factor found is applied (it is 1.000 on this stack).  Unlike FETCH_SIZE (whi
 Cache hits are included, so the figures bound HBM traffic from above.
 """
 import json
+import os
 import sys
 
 import numpy as np
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
 
 def main():
@@ -31,6 +33,7 @@ def main():
     wr = float(np.mean([r['write_bytes'] for r in sel]))
     res = {
         "kernel": needle,
+        "csrc_sha16": __import__('yolov3_tensorflow_amd.build', fromlist=['csrc_sha16']).csrc_sha16(),
         "launches_counted": len(sel),
         "read_bytes_per_launch": int(rd),
         "write_bytes_per_launch": int(wr),

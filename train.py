@@ -243,7 +243,7 @@ def main(argv=None):
         meters = [AverageMeter() for _ in range(5)]
         for i in range(args.train_batch_num):
             if args.multi_scale_train and i % 10 == 0:
-                side = random.randint(10, 20) * 32                             # 320 .. 640, like get_batch_data
+                side = random.randrange(10, 20) * 32      # 320 .. 608: range(10, 20) of utils/data_utils.py:196
                 size = [side, side]
             elif not args.multi_scale_train:
                 size = list(args.img_size)

@@ -28,7 +28,6 @@ SOURCES = [
     ("y3_wgrad_wino.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-COMMON += os.environ.get("Y3_EXTRA_HIPCC_FLAGS", "").split()   # experiment hook (e.g. -DY3_EXP=1)
 
 
 def _hipcc():
@@ -36,6 +35,18 @@ def _hipcc():
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     raise RuntimeError("hipcc not found")
+
+
+def csrc_sha16():
+    """Hash of the kernel sources (csrc/*.hip, csrc/*.h, include/yolo355.h): stamps the PMC traffic files under
+    profiles/ so that bench.py can tell a figure taken on THIS build from a stale one."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(n for n in os.listdir(CSRC) if n.endswith(('.hip', '.h')))
+    for path in [os.path.join(CSRC, n) for n in names] + [os.path.join(HERE, "..", "include", "yolo355.h")]:
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build():

@@ -40,8 +40,34 @@ extern "C" int y3_ctx_create(int device, void* stream, y3_ctx** out) {
 extern "C" int y3_ctx_destroy(y3_ctx* ctx) {
     if (ctx) {
         if (ctx->err_host) (void)hipHostFree(ctx->err_host);
+        if (ctx->stage_ev) { (void)hipEventSynchronize(ctx->stage_ev); (void)hipEventDestroy(ctx->stage_ev); }
+        if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
         delete ctx;
     }
+    return Y3_OK;
+}
+
+int y3_ctx_stage_acquire(y3_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->stage_busy) {                          // the previous upload may still be reading the buffer
+        Y3_CHECK_HIP(hipEventSynchronize(ctx->stage_ev));
+        ctx->stage_busy = false;
+    }
+    if (ctx->stage_bytes < bytes) {
+        if (ctx->stage_host) Y3_CHECK_HIP(hipHostFree(ctx->stage_host));
+        ctx->stage_host = nullptr;
+        ctx->stage_bytes = 0;
+        const size_t cap = (bytes + 4095) & ~(size_t)4095;
+        Y3_CHECK_HIP(hipHostMalloc(&ctx->stage_host, cap, hipHostMallocDefault));
+        ctx->stage_bytes = cap;
+    }
+    if (!ctx->stage_ev) Y3_CHECK_HIP(hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming));
+    *out = ctx->stage_host;
+    return Y3_OK;
+}
+
+int y3_ctx_stage_release(y3_ctx* ctx) {
+    Y3_CHECK_HIP(hipEventRecord(ctx->stage_ev, ctx->stream));
+    ctx->stage_busy = true;
     return Y3_OK;
 }
 

@@ -407,20 +407,6 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
     constexpr int LDC = BNW + 4;
     static_assert((size_t)BT * 4 * LDC * 4 <= (size_t)2 * (STAGE_V + STAGE_U), "output staging must fit in the tile LDS");
     float* cs = reinterpret_cast<float*>(smem);
-#ifdef Y3_WINO_CLOCK   // probe build (tools/wino_clock_probe.py): shader-clock cycles of workgroup 0 -> first bytes of y
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
-    unsigned long long clk_loop = 0, clk_steps = 0, clk_last = clk0, clk_phase[6] = {0, 0, 0, 0, 0, 0};
-    auto stamp = [&](int k) {     // cycles since the previous stamp -> phase k
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        clk_phase[k] += t - clk_last;
-        clk_last = t;
-        __builtin_amdgcn_sched_barrier(0);
-    };
-#define Y3_STAMP(k) stamp(k)
-#else
-#define Y3_STAMP(k)
-#endif
     setup_voff(first_blk);
     issue(first_ks);
     while (dp_left > 0 || item < item_end) {
@@ -440,10 +426,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
         store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
         __syncthreads();
         frags(0, 0, a0, b0);
-        Y3_STAMP(0);    // block prologue: tile tables, accumulator reset, first transform + LDS writes, barrier
-#ifdef Y3_WINO_CLOCK
-        const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
-#endif
+        // block prologue: tile tables, accumulator reset, first transform + LDS writes, barrier
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
             // One basic block per K-step: loads(ks+1) | 64 MFMAs of K-step ks | input transform + LDS writes (ks+1)
             // into the other LDS stage, all interleaved by the hints below so that only the barrier is serial
@@ -456,13 +439,9 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             // 8 weight writes after them; the transform's 32 packed adds float between the MFMAs of groups 1-2.
             // (A VMEM issue costs the wave 20-70 cycles, an LDS write ~16, a 32x32x2 fp32 MFMA holds the matrix pipe
             // for 64.)  The loaded registers are first read ~1500-2000 cycles after the last load issues.
-            // Y3_WINO_KO (bit 0: no loads, bit 1: no transform / LDS writes) are the knock-out builds of
-            // tools/wino_clock_probe.py; they compute garbage.
             const int cur = (ks - ks0) & 1;
             f32x4 a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
-#if !(defined(Y3_WINO_KO) && (Y3_WINO_KO & 1))
             issue(ks + 1);
-#endif
             frags(cur, 1, a1, b1);
             mfmas(0, a0, b0, 0, 4);
             frags(cur, 2, a2, b2);
@@ -470,9 +449,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             frags(cur, 3, a3, b3);
             mfmas(2, a2, b2, 0, 4);
             mfmas(3, a3, b3, 0, 2);
-#if !(defined(Y3_WINO_KO) && (Y3_WINO_KO & 2))
             store(cur ^ 1);
-#endif
 #pragma unroll
             for (int i = 0; i < 8; ++i) {                            // group 0: activation loads ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -516,11 +493,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
-#ifdef Y3_WINO_CLOCK
-        clk_loop += __builtin_amdgcn_s_memtime() - clk1;
-        clk_steps += ks1 - 1 - ks0;
-#endif
-        Y3_STAMP(1);    // K-loop
+        // K-loop
         {
             const int cur = (ks1 - 1 - ks0) & 1;
             f32x4 a1[4], b1[4];
@@ -535,7 +508,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
 
         // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
         __syncthreads();                 // every wave is done reading the last K-step's tiles
-        Y3_STAMP(2);    // last K-step's MFMAs + barrier
+        // last K-step's MFMAs + barrier
         const bool producer = STREAMK && ks0 > 0;       // later K-steps of a cut block: publish partial sums
         WinoRows<BT, BNW> rows;
         rows.prepare(p, tile_pix, tile_ok, n0);   // residual loads fly under the output transform (unconditional:
@@ -568,7 +541,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             }
         }
         __syncthreads();
-        Y3_STAMP(3);    // residual loads issued, A^T M A, staging writes, barrier
+        // residual loads issued, A^T M A, staging writes, barrier
         int n_extra = 0;
         if (STREAMK && ks1 < ksteps) {
             // this worker owns K-steps [0, ks1) of a cut block: the rest was summed by the next workers of its
@@ -604,7 +577,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
             issue(next_ks);
             __builtin_amdgcn_sched_barrier(0);
         }
-        Y3_STAMP(4);    // next block's offsets + loads issued
+        // next block's offsets + loads issued
         if (!producer) {
             // (2) all threads: float4 rows of the staging tile (+ the partial sums other workers published for this
             // block) -> scale/shift, LeakyReLU, + residual -> global
@@ -658,19 +631,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p)
                 __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
-        Y3_STAMP(5);    // scale/shift/activation/residual/stores (or the partial-slot copy), barrier
+        // scale/shift/activation/residual/stores (or the partial-slot copy), barrier
         if (whole) { --dp_left; dp_blk += p.workers >> 3; }
         item = seg_end;
     }
-#ifdef Y3_WINO_CLOCK
-    if (blockIdx.x == 0 && tid == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.y);
-        out[0] = __builtin_amdgcn_s_memtime() - clk0;
-        out[1] = clk_loop;
-        out[2] = clk_steps;
-        for (int k = 0; k < 6; ++k) out[3 + k] = clk_phase[k];
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -766,11 +730,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 for (int j = 0; j < 4; ++j) {
                     const int yy = y0 + i, xx = x0 + j;
                     const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-#if defined(Y3_WINO8_BLOCKED_IN)   // timing experiment: activations read as [Cin/8][N][H][W][8] (garbage results)
-                    voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * 8 + a_pair * 2) * 4u : OOB;
-#else
                     voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
-#endif
                 }
         }
 #pragma unroll
@@ -784,11 +744,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
     f32x2 ra[12];
     f32x4 ru[4];
     auto issue = [&](int ks) {
-#if defined(Y3_WINO8_BLOCKED_IN)
-        const unsigned soff_a = (unsigned)ks * (unsigned)(p.N * p.H * p.W) * 32u;
-#else
         const unsigned soff_a = (unsigned)(ks * WKC) * 4u;
-#endif
         const unsigned soff_u = (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
 #pragma unroll
         for (int j = 0; j < 12; ++j)
@@ -856,13 +812,6 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
     f32x4 a0[2], b0[2];            // pair 0 of the current K-step
 
     float* cs = reinterpret_cast<float*>(smem);
-#ifdef Y3_WINO8_CLOCK
-    unsigned long long clk_phase[6] = {0, 0, 0, 0, 0, 0}, clk_steps = 0, clk_seg[6] = {0, 0, 0, 0, 0, 0}, clk_segs = 0, ts[7];
-#define W8_S(i) do { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
-#else
-#define W8_S(i)
-#endif
     setup_voff(first_blk);
     issue(first_ks);
     while (dp_left > 0 || item < item_end) {
@@ -876,13 +825,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         const bool has_next = whole_next || seg_end < item_end;
         const int next_blk = whole_next ? blk + (p.workers >> 3) : (int)(seg_end / ksteps);
         const int next_ks = whole_next ? 0 : (int)(seg_end - (long long)next_blk * ksteps);
-        W8_S(0);
         setup_tables(blk);
         if (ph) store(0, std::integral_constant<int, 1>());
         else store(0, std::integral_constant<int, 0>());
         __syncthreads();
         frags(0, 0, a0, b0);
-        W8_S(1);
         // The two position halves run the K-step in OPPOSITE phase, so that one wave of every SIMD has MFMAs to issue
         // while the other one waits for its loads, transforms and writes the next K-step's tiles:
         //   ph 0: 16 MFMAs(ks) | transform + LDS writes(ks+1) | loads(ks+2) | 12 MFMAs(ks) | barrier | fragments(ks+1), last 4 MFMAs(ks)
@@ -890,33 +837,6 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         // Both fetch a whole K-step ahead (the loads stay in flight across the barrier): L2 misses take 1-2 us here, half
         // a K-step is not enough.  (tools/issue_probe.hip: with two waves per SIMD, LDS and VMEM instructions are free
         // next to a stream of MFMAs, but every VALU instruction takes ~4.6 cycles of the matrix pipe.)
-        // Y3_WINO8_KO (probe builds, tools/wino8_probe.sh): bit 0 no loads, 1 no transform / LDS writes, 2 no fragment
-        // reads, 3 no MFMAs inside the K-loop; they compute garbage, only the launch times mean anything
-#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 1)
-#define W8_ISSUE(k)
-#else
-#define W8_ISSUE(k) issue(k)
-#endif
-#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 2)
-#define W8_STORE(b, h)
-#else
-#define W8_STORE(b, h) store(b, std::integral_constant<int, h>())
-#endif
-#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 4)
-#define W8_FRAGS(b, g, x, y)
-#else
-#define W8_FRAGS(b, g, x, y) frags(b, g, x, y)
-#endif
-#if defined(Y3_WINO8_KO) && (Y3_WINO8_KO & 8)
-#define W8_MFMAS(g, x, y, j0, j1)
-#else
-#define W8_MFMAS(g, x, y, j0, j1) mfmas(g, x, y, j0, j1)
-#endif
-#ifdef Y3_WINO8_CLOCK   // probe build: s_memtime stamps of wave 0 (ph 0) and wave 4 (ph 1) of workgroup 0 -> first bytes of y
-#define W8_T(i) tk[i] = __builtin_amdgcn_s_memtime()
-#else
-#define W8_T(i)
-#endif
         // (a macro: sched_group_barrier wants literal counts) the wave's 16 loads go out two per MFMA under its first
         // position pair - back to back they hold the wave for ~900 cycles before its first MFMA - and the fragment reads
         // one pair ahead of their MFMAs; TAIL = MFMAs left after the three full pairs
@@ -937,63 +857,40 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
         for (int ks = ks0; ks + 1 < ks1; ++ks) {
             const int cur = (ks - ks0) & 1;
             f32x4 a1[2], b1[2];
-#ifdef Y3_WINO8_CLOCK
-            unsigned long long tk[7];
-#endif
-            W8_T(0);
             if (ph == 0) {
-#ifdef Y3_WINO8_CLOCK
-                tk[1] = tk[2] = tk[0];       // phases of ph 0: - | - | loads + 28 MFMAs | staging | barrier | fragments + 4 MFMAs
-#endif
-                W8_ISSUE(ks + 1);
-                W8_FRAGS(cur, 1, a1, b1);
-                W8_MFMAS(0, a0, b0, 0, 4);
-                W8_FRAGS(cur, 2, a0, b0);
-                W8_MFMAS(1, a1, b1, 0, 4);
-                W8_FRAGS(cur, 3, a1, b1);
-                W8_MFMAS(2, a0, b0, 0, 4);
-                W8_MFMAS(3, a1, b1, 0, 2);
+                issue(ks + 1);
+                frags(cur, 1, a1, b1);
+                mfmas(0, a0, b0, 0, 4);
+                frags(cur, 2, a0, b0);
+                mfmas(1, a1, b1, 0, 4);
+                frags(cur, 3, a1, b1);
+                mfmas(2, a0, b0, 0, 4);
+                mfmas(3, a1, b1, 0, 2);
                 W8_WEAVE(4);
                 __builtin_amdgcn_sched_barrier(0);
-                W8_T(3);
-                W8_STORE(cur ^ 1, 0);
+                store(cur ^ 1, std::integral_constant<int, 0>());
                 __builtin_amdgcn_sched_barrier(0);
-                W8_T(4);
                 __syncthreads();
-                W8_T(5);
-                W8_FRAGS(cur ^ 1, 0, a0, b0);
-                W8_MFMAS(3, a1, b1, 2, 4);
-                W8_T(6);
+                frags(cur ^ 1, 0, a0, b0);
+                mfmas(3, a1, b1, 2, 4);
             } else {
-                W8_STORE(cur ^ 1, 1);
+                store(cur ^ 1, std::integral_constant<int, 1>());
                 __builtin_amdgcn_sched_barrier(0);
-                W8_T(1);
-#ifdef Y3_WINO8_CLOCK
-                tk[2] = tk[3] = tk[1];       // phases of ph 1: staging | - | - | loads + 32 MFMAs | barrier | fragments
-#endif
                 // its loads go out under its MFMAs too (unconditional: on the last pass they re-read K-step ks+1 - in
                 // range - and are never used; issued back to back after the staging they cost +4..11 %)
-                W8_ISSUE(ks + 2 < ks1 ? ks + 2 : ks + 1);
-                W8_FRAGS(cur, 1, a1, b1);
-                W8_MFMAS(0, a0, b0, 0, 4);
-                W8_FRAGS(cur, 2, a0, b0);
-                W8_MFMAS(1, a1, b1, 0, 4);
-                W8_FRAGS(cur, 3, a1, b1);
-                W8_MFMAS(2, a0, b0, 0, 4);
-                W8_MFMAS(3, a1, b1, 0, 4);
+                issue(ks + 2 < ks1 ? ks + 2 : ks + 1);
+                frags(cur, 1, a1, b1);
+                mfmas(0, a0, b0, 0, 4);
+                frags(cur, 2, a0, b0);
+                mfmas(1, a1, b1, 0, 4);
+                frags(cur, 3, a1, b1);
+                mfmas(2, a0, b0, 0, 4);
+                mfmas(3, a1, b1, 0, 4);
                 W8_WEAVE(8);
                 __builtin_amdgcn_sched_barrier(0);
-                W8_T(4);
                 __syncthreads();
-                W8_T(5);
-                W8_FRAGS(cur ^ 1, 0, a0, b0);
-                W8_T(6);
+                frags(cur ^ 1, 0, a0, b0);
             }
-#ifdef Y3_WINO8_CLOCK
-#pragma unroll
-            for (int i = 0; i < 6; ++i) clk_phase[i] += tk[i + 1] - tk[i];
-            ++clk_steps;
-#endif
         }
         {
             const int cur = (ks1 - 1 - ks0) & 1;
@@ -1007,7 +904,6 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
             }
         }
 
-        W8_S(2);
         // (1) this half's share of A^T M A per (tile, channel): 2x2 partial outputs -> its staging tile
         __syncthreads();
         const bool producer = STREAMK && ks0 > 0;
@@ -1023,9 +919,6 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
 #pragma unroll
                 for (int pos = 0; pos < 8; ++pos) {
                     m[pos] = acc[pos][r];
-#if defined(Y3_WINO8_TAILBAR)
-                    asm volatile("" : "+v"(m[pos]));
-#endif
                 }
                 // rows 0,1 of M (ph 0): s0 = m0 + m1, s1 = m1;  rows 2,3 (ph 1): s0 = m2, s1 = -m2 - m3
                 float s0[4], s1[4];
@@ -1039,13 +932,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 row[1 * LDC] = s0[1] - s0[2] - s0[3];
                 row[2 * LDC] = s1[0] + s1[1] + s1[2];
                 row[3 * LDC] = s1[1] - s1[2] - s1[3];
-#if defined(Y3_WINO8_TAILBAR)
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         }
         __syncthreads();
-        W8_S(3);
         int n_extra = 0;
         if (STREAMK && ks1 < ksteps) {
             const int G = p.workers >> 3;
@@ -1070,13 +959,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
             }
             __syncthreads();
         }
-        W8_S(4);
         if (STREAMK && has_next) {
             setup_voff(next_blk);
             issue(next_ks);
             __builtin_amdgcn_sched_barrier(0);
         }
-        W8_S(5);
         if (!producer) {
             static_assert(WinoRows<BT, BNW, NT, true>::PASSES == 8, "one accumulator set is reset per store pass");
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -1127,25 +1014,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
                 __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (STREAMK) __syncthreads();
-        W8_S(6);
-#ifdef Y3_WINO8_CLOCK
-#pragma unroll
-        for (int i = 0; i < 6; ++i) clk_seg[i] += ts[i + 1] - ts[i];
-        ++clk_segs;
-#endif
         if (whole) { --dp_left; dp_blk += p.workers >> 3; }
         item = seg_end;
     }
-#ifdef Y3_WINO8_CLOCK
-    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.y) + (wave >> 2) * 16;
-        out[0] = __builtin_amdgcn_s_memtime() - clk0;
-        out[1] = clk_steps;
-        for (int k = 0; k < 6; ++k) out[2 + k] = clk_phase[k];
-        out[8] = clk_segs;
-        for (int k = 0; k < 6; ++k) out[9 + k] = clk_seg[k];
-    }
-#endif
 }
 
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]

@@ -234,7 +234,11 @@ extern "C" int y3_decode(y3_ctx* ctx, const float* fm1, const float* fm2, const 
     a.boxes = boxes; a.confs = confs; a.probs = probs; a.scores = scores;
     const bool aligned = (((uintptr_t)fm1 | (uintptr_t)fm2 | (uintptr_t)fm3 | (uintptr_t)boxes | (uintptr_t)probs |
                            (uintptr_t)scores) & 15) == 0;
-    if (class_num % 4 == 0 && aligned && class_num <= 1024) {
+    // the staged kernel needs (DRPB*(5+C) + 8 + DRPB) floats of dynamic LDS; it is used while that stays inside the
+    // 64 KB every launch may ask for without raising the function's dynamic-LDS limit (C <= 248); larger class counts
+    // take the 4-byte-per-lane kernel below, which handles any class count (a 600-class head used to fail)
+    const size_t staged_lds = (size_t)(DRPB * a.F + 8 + DRPB) * sizeof(float);
+    if (class_num % 4 == 0 && aligned && staged_lds <= (size_t)64 * 1024) {
         StagedArgs sa;
         sa.d = a;
         long long chunks = 0;
@@ -244,8 +248,7 @@ extern "C" int y3_decode(y3_ctx* ctx, const float* fm1, const float* fm2, const 
             Y3_CHECK_ARG(chunks < (1LL << 31), "y3_decode: too many boxes");
             sa.chunk_end[s] = (int)chunks;
         }
-        const size_t lds = (size_t)(DRPB * a.F + 8 + DRPB) * sizeof(float);
-        hipLaunchKernelGGL(decode_staged_kernel, dim3((unsigned)chunks), dim3(256), lds, ctx->stream, sa);
+        hipLaunchKernelGGL(decode_staged_kernel, dim3((unsigned)chunks), dim3(256), staged_lds, ctx->stream, sa);
         Y3_CHECK_HIP(hipGetLastError());
         return Y3_OK;
     }

@@ -10,7 +10,18 @@ struct y3_ctx {
     hipStream_t stream;
     unsigned* err_host;   // one pinned, device-visible word: kernels OR a non-zero code into it when a stream-K
                           // hand-off times out; read (no sync) at the next call on the context and by y3_ctx_check
+    // pinned staging for small host->device descriptor uploads (y3_clip_update_multi): the buffer is rewritten only
+    // after `stage_ev` (recorded behind the previous upload) has completed, so an in-flight copy never reads a
+    // buffer the host is rewriting, whatever the runtime does with pageable memory
+    void* stage_host = nullptr;
+    size_t stage_bytes = 0;
+    hipEvent_t stage_ev = nullptr;
+    bool stage_busy = false;
 };
+// returns a pinned buffer of at least `bytes` that no earlier upload is still reading (waits for it if needed)
+int y3_ctx_stage_acquire(y3_ctx* ctx, size_t bytes, void** out);
+// records that an asynchronous copy out of the staging buffer was just enqueued on ctx->stream
+int y3_ctx_stage_release(y3_ctx* ctx);
 
 // stream-K plumbing handed down to the conv launchers by the ctx entry points / y3_net_forward
 struct y3_sk_opts {

@@ -870,10 +870,15 @@ extern "C" int y3_clip_update_multi(y3_ctx* ctx, int kind, const y3_param_desc* 
     Y3_CHECK_ARG(kind >= 0 && kind <= 3, "y3_clip_update_multi: unknown optimizer kind %d", kind);
     Y3_CHECK_ARG(scratch_bytes >= y3_clip_update_multi_scratch_bytes(params, count) && ((uintptr_t)scratch & 15) == 0,
                  "y3_clip_update_multi: scratch too small or misaligned");
-    // host staging of the device descriptors: thread-local so that the asynchronous copy below never reads a buffer
-    // another call is rewriting (the copy is enqueued before this call returns; HIP stages pageable memory itself)
-    static thread_local std::vector<MtDesc> host;
-    host.resize(count);
+    // host staging of the device descriptors: the context's pinned buffer, handed out only once the previous upload
+    // out of it has completed (an event behind that copy), so the asynchronous copy below can never race with this
+    // or a later call's rewrite of the buffer
+    void* stage = nullptr;
+    {
+        const int rc = y3_ctx_stage_acquire(ctx, (size_t)count * sizeof(MtDesc), &stage);
+        if (rc != Y3_OK) return rc;
+    }
+    MtDesc* host = static_cast<MtDesc*>(stage);
     long long chunks = 0;
     for (int i = 0; i < count; ++i) {
         const y3_param_desc& q = params[i];
@@ -891,7 +896,11 @@ extern "C" int y3_clip_update_multi(y3_ctx* ctx, int kind, const y3_param_desc* 
     float* partial = reinterpret_cast<float*>(base + (((size_t)count * sizeof(MtDesc) + 255) & ~(size_t)255));
     float* norm = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + (((size_t)chunks * 4 + 255) & ~(size_t)255));
     hipStream_t st = ctx->stream;
-    Y3_CHECK_HIP(hipMemcpyAsync(descs, host.data(), (size_t)count * sizeof(MtDesc), hipMemcpyHostToDevice, st));
+    Y3_CHECK_HIP(hipMemcpyAsync(descs, host, (size_t)count * sizeof(MtDesc), hipMemcpyHostToDevice, st));
+    {
+        const int rc = y3_ctx_stage_release(ctx);
+        if (rc != Y3_OK) return rc;
+    }
     hipLaunchKernelGGL(mt_prepare_kernel, dim3((unsigned)chunks), dim3(256), 0, st, descs, count, grad_scale, partial);
     Y3_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(mt_norms_kernel, dim3(count), dim3(256), 0, st, descs, count, (int)chunks, partial, norm);

@@ -54,6 +54,11 @@ class GradientExchange(object):
             self.world = dist.get_world_size(group)
         self.edges = plan_buckets(list(segment_ends), bucket_bytes, flat.element_size())
         self.grad_scale = 1.0 / self.world
+        # test hooks (tests/test_rccl_gpu.py, the only RCCL evidence a one-GPU box can give): `force` issues the
+        # collectives even in a one-rank group, `op` replaces SUM (a pre-multiplied sum makes a one-rank all-reduce
+        # change the values, so a stream-ordering mistake shows up in the numbers)
+        self.force = False
+        self.op = dist.ReduceOp.SUM
         self._next = 0          # next bucket to issue
         self._works = []
         self.issued = []        # (lo, hi) of every bucket issued in this step, in order (introspection / tests)
@@ -65,8 +70,8 @@ class GradientExchange(object):
 
     def _issue(self, lo, hi):
         self.issued.append((lo, hi))
-        if self.world > 1 and hi > lo:
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if (self.world > 1 or self.force) and hi > lo:
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=self.op, group=self.group, async_op=True))
 
     def ready(self, upto):
         """Everything in flat[0:upto) has been written (enqueued on the current stream)."""

@@ -173,7 +173,13 @@ def resize_with_bbox(img, bbox, new_width, new_height, interp=0, letterbox=False
     '''
     Resize the image and correct the bbox accordingly (reference utils/data_aug.py:296-320).
     '''
-    bbox = np.array(bbox, np.float32).reshape(-1, 4)
+    # columns 0-3 are scaled, any further column (parse_data hands over [N,5]: the mix-up weight) is kept, as in the
+    # reference; a flat list of 4*k numbers is accepted as k boxes
+    bbox = np.array(bbox, np.float32)
+    if bbox.ndim == 1:
+        bbox = bbox.reshape(-1, 4)
+    if bbox.ndim != 2 or bbox.shape[1] < 4:
+        raise ValueError("resize_with_bbox: bbox must be [N, >=4], got %s" % (bbox.shape,))
     if letterbox:
         image_padded, resize_ratio, dw, dh = letterbox_resize(img, new_width, new_height, interp)
         bbox[:, [0, 2]] = bbox[:, [0, 2]] * resize_ratio + dw
