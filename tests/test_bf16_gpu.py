@@ -40,6 +40,11 @@ def ref_conv(x, w_hwio, scale, shift, k, stride, act, resid=None):
     (3, 20, 28, 1, 1, 256, 128, False, 0, 0), (2, 26, 26, 1, 1, 768, 256, False, 256, 0),
     (2, 19, 19, 1, 1, 1024, 255, False, 0, 1), (3, 20, 28, 3, 1, 32, 64, True, 0, 0),
     (2, 24, 24, 1, 1, 64, 32, False, 0, 0), (1, 13, 13, 3, 1, 512, 1024, False, 0, 0),
+    # the LDS-DMA kernel's tile shapes (y3_conv_bf16x.hip): 256x256 / 256x128 tiles need > 448 tiles, so larger maps;
+    # stride 2 with Cin = 32 (64-byte rows), a ragged last row block, a 1x1 with Cout = 64, fused upsample with 128+256
+    (4, 76, 76, 3, 1, 128, 256, True, 0, 0), (8, 76, 76, 3, 1, 256, 512, False, 0, 0),
+    (2, 38, 50, 3, 2, 32, 64, False, 0, 0), (1, 37, 41, 3, 1, 64, 128, True, 0, 0),
+    (3, 20, 28, 1, 1, 128, 64, False, 0, 0), (2, 26, 26, 1, 1, 384, 128, False, 128, 0),
 ])
 def test_bf16_conv_matches_fp64_on_rounded_operands(n, h, w, k, stride, cin, cout, resid, c_up, out_f32):
     from yolov3_tensorflow_amd import framework as fw, _lib

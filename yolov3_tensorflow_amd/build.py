@@ -18,6 +18,7 @@ SOURCES = [
     ("y3_abi.hip", []),
     ("y3_conv.hip", []),
     ("y3_conv_bf16.hip", []),
+    ("y3_conv_bf16x.hip", []),
     ("y3_conv_split.hip", []),
     ("y3_conv_wino.hip", []),
     ("y3_decode.hip", ["-ffp-contract=off"]),

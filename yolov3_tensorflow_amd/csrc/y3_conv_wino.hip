@@ -240,405 +240,8 @@ __device__ __forceinline__ void wino_tile_info(const WinoArgs& p, int t, int& pi
     }
 }
 
-// STREAMK: a persistent grid of p.workers workgroups (one per CU), each owning an equal contiguous range of
-// (block, K-step) work items; a block computed by several workers is summed in output space by
-// the consumer worker inside the kernel (fixed worker order: deterministic; wk_range above).
-template <int WGM, int WGN, bool STREAMK, bool STATS = false>
-__global__ void __launch_bounds__(256, 1) conv_wino_f32_kernel(const WinoArgs p) {
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
-    constexpr int BT = WGM * 32, BNW = WGN * 32;
-    constexpr int PLANE_V = BT * WROW, PLANE_U = BNW * WROW;          // bytes per transform position
-    constexpr int STAGE_V = 16 * PLANE_V, STAGE_U = 16 * PLANE_U;
-    static_assert(BT * 2 <= 128 && 16 * BNW * 2 <= 128 * 16, "staging assignment below assumes BT <= 64, BNW <= 64");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Vs = smem;                    // [2][16][BT][32 B]
-    unsigned char* Us = smem + 2 * STAGE_V;      // [2][16][BNW][32 B]
-    // per tile of this workgroup: index of output pixel (n, 2ty, 2tx) (-1: no such tile) and which of the 2x2 outputs
-    // exist (bit dy*2+dx) — written once by the staging threads, read by the epilogue
-    int* tile_pix = reinterpret_cast<int*>(smem + 2 * STAGE_V + 2 * STAGE_U);   // [BT]
-    int* tile_ok = tile_pix + BT;                                                // [BT]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int nbt = (p.T + BT - 1) / BT;
-    const int ksteps = p.Cin / WKC;
-    // work range: items = (block, K-step), blocks column-major (bn outer) so that the workgroups of one XCD share a
-    // weight panel; workgroup b runs on XCD b%8 and gets a contiguous eighth of the id space
-    long long item, item_end;
-    int worker = 0, grp = 0, lw = 0;     // stream-K: global worker index, XCD group, local worker in the group
-    int dp_left = 0, dp_blk = 0;         // stream-K hybrid: whole blocks still to do (rounds), and the next one
-    const int nbn_ = (p.Cout + BNW - 1) / BNW;
-    const int nblocks = nbt * nbn_;
-    {
-        const int nt = gridDim.x;
-        const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
-        const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
-        if (STREAMK) {
-            grp = xcd;
-            lw = (p.workers >> 3) - 1 - k8;
-            worker = grp * (p.workers >> 3) + lw;
-            wk_range(nblocks, ksteps, p.workers, grp, lw, p.hybrid, item, item_end, &dp_left, &dp_blk);
-        } else {
-            item = (long long)id * ksteps;
-            item_end = item + ksteps;
-        }
-    }
-    if (dp_left == 0 && item >= item_end) return;
-    const int first_blk = dp_left > 0 ? dp_blk : (int)(item / ksteps);
-    const int first_ks = dp_left > 0 ? 0 : (int)(item - (long long)first_blk * ksteps);
-
-    // ---- staging: every thread does a 1/256 share of both operands, so that the whole K-step (loads, MFMAs,
-    // input transform, LDS writes) is ONE basic block that the scheduling hints below can interleave ------------
-    //   activations: thread = (tile tid>>2, channel pair tid&3): the 4x4 patch as 16 bounds-checked 8-byte loads
-    //                (padding = OOB = 0), B^T d B on the float2s (32 packed adds), 16 8-byte LDS writes
-    //   weights:     16 positions x BNW channels x 2 halves = 32*BNW 16-byte pieces, 8 per thread
-    static_assert(4 * BT == 256 && 32 * BNW == 256 * 8, "one (tile, channel pair) and eight weight pieces per thread");
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.u), 0, (unsigned)((size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
-    unsigned voff_a[16];          // byte offsets of the 16 patch pixels (OOB where padded)
-    unsigned voff_u[8];           // byte offsets of the 8 weight pieces
-    const int a_tile = tid >> 2, a_pair = tid & 3;
-    int t0 = 0, n0 = 0;
-    // per-block state: tile tables in the LDS + t0/n0, and the staging offsets in registers
-    auto setup_tables = [&](int blk) {
-        int bn, bt;
-        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
-        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
-        t0 = bt * BT;
-        n0 = bn * BNW;
-        if (a_pair == 0) {
-            int pix, okbits, n, ty, tx;
-            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
-            tile_pix[a_tile] = pix;
-            tile_ok[a_tile] = okbits;
-        }
-    };
-    auto setup_voff = [&](int blk) {
-        int bn, bt;
-        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
-        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
-        const int t0 = bt * BT, n0 = bn * BNW;
-        const int tid = opaque(threadIdx.x);
-        {
-            const int a_tile = tid >> 2, a_pair = tid & 3;
-            int pix, okbits, n, ty, tx;
-            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
-            const bool tok = pix >= 0;
-            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int yy = y0 + i, xx = x0 + j;
-                    const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                    voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
-                }
-        }
-        // piece q = tid + 256*j, j < 8: position = q / (2*BNW), channel = (q / 2) % BNW, half = q & 1.
-        // Packed weights: [pos][Cin/8][Cout][8] floats.
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int q = tid + 256 * j;
-            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
-            const bool ok = (n0 + co) < p.Cout;
-            voff_u[j] = ok ? (unsigned)(((size_t)pos * ksteps * p.Cout + (n0 + co)) * WKC + half * 4) * 4u : OOB;
-        }
-    };
-
-    f32x2 ra[16];
-    f32x4 ru[8];
-    auto issue = [&](int ks) {
-        // A: channels ks*8 + pair*2, +1 of the 16 patch pixels.  U: slab (pos, ks) = [Cout][8] floats.
-        const unsigned soff_a = (unsigned)(ks * WKC) * 4u, soff_u = (unsigned)((size_t)ks * p.Cout * WKC) * 4u;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            ru[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u[j], soff_u, 0));
-    };
-    const int st_a = lds_off(a_tile, a_pair >> 1) + (a_pair & 1) * 8;
-    auto store = [&](int buf) {
-        unsigned char* us = Us + buf * STAGE_U;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int q = tid + 256 * j;
-            const int pos = q / (2 * BNW), co = (q >> 1) % BNW, half = q & 1;
-            *reinterpret_cast<f32x4*>(us + pos * PLANE_U + lds_off(co, half)) = ru[j];
-        }
-        f32x2 v[16];
-        input_transform(ra, v);       // 32 v_pk_add_f32 (two scalar transforms were measured: +14 % per K-step)
-        unsigned char* vs = Vs + buf * STAGE_V + st_a;
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) *reinterpret_cast<f32x2*>(vs + pos * PLANE_V) = v[pos];
-    };
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int pos = 0; pos < 16; ++pos)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
-
-    const int frag_a = lds_off(wm * 32 + (lane & 31), lane >> 5);
-    const int frag_b = lds_off(wn * 32 + (lane & 31), lane >> 5);
-    // fragments of position group g (four positions: 8 reads) and its MFMAs for k pairs [j0, j1) of the K-step
-    auto frags = [&](int buf, int g, f32x4 (&a)[4], f32x4 (&b)[4]) {
-        const unsigned char* vs = Vs + buf * STAGE_V + frag_a;
-        const unsigned char* us = Us + buf * STAGE_U + frag_b;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 4 + i) * PLANE_V);
-            b[i] = *reinterpret_cast<const f32x4*>(us + (g * 4 + i) * PLANE_U);
-        }
-    };
-    auto mfmas = [&](int g, const f32x4 (&a)[4], const f32x4 (&b)[4], int j0, int j1) {
-#pragma unroll
-        for (int j = j0; j < j1; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[g * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[i][j], acc[g * 4 + i], 0, 0, 0);
-    };
-    f32x4 a0[4], b0[4];            // group 0 of the current K-step: read one half group ahead of the barrier
-
-    // ---- segments: maximal runs of K-steps of one block inside this workgroup's item range ------------------------
-    constexpr int LDC = BNW + 4;
-    static_assert((size_t)BT * 4 * LDC * 4 <= (size_t)2 * (STAGE_V + STAGE_U), "output staging must fit in the tile LDS");
-    float* cs = reinterpret_cast<float*>(smem);
-    setup_voff(first_blk);
-    issue(first_ks);
-    while (dp_left > 0 || item < item_end) {
-        // this segment: a whole block of the round-robin part, or the next run of the cut range
-        const bool whole = STREAMK && dp_left > 0;
-        const int blk = whole ? dp_blk : (int)(item / ksteps);
-        const int ks0 = whole ? 0 : (int)(item - (long long)blk * ksteps);
-        const long long blk_end = (long long)(blk + 1) * ksteps;
-        const long long seg_end = whole ? item : (blk_end < item_end ? blk_end : item_end);   // (whole: item stays)
-        const int ks1 = whole ? ksteps : ks0 + (int)(seg_end - item);          // K-steps [ks0, ks1) of this block
-        // ... and the one after it (its first K-step is fetched under this one's tail)
-        const bool whole_next = whole && dp_left > 1;
-        const bool has_next = whole_next || seg_end < item_end;
-        const int next_blk = whole_next ? blk + (p.workers >> 3) : (int)(seg_end / ksteps);
-        const int next_ks = whole_next ? 0 : (int)(seg_end - (long long)next_blk * ksteps);
-        setup_tables(blk);
-        store(0);                        // K-step ks0, in flight since the previous block's epilogue (or the prologue)
-        __syncthreads();
-        frags(0, 0, a0, b0);
-        // block prologue: tile tables, accumulator reset, first transform + LDS writes, barrier
-        for (int ks = ks0; ks + 1 < ks1; ++ks) {
-            // One basic block per K-step: loads(ks+1) | 64 MFMAs of K-step ks | input transform + LDS writes (ks+1)
-            // into the other LDS stage, all interleaved by the hints below so that only the barrier is serial
-            // (position group g = 16 MFMAs; its fragments are read half a group ahead):
-            //   group 0: 16 x (MFMA, activation load), fragments of group 1 behind the last 8
-            //   group 1:  8 x (MFMA, weight load), 8 x (MFMA, fragment read of group 2)
-            //   group 2:  8 x (MFMA, LDS write), 8 x (MFMA, fragment read of group 3)
-            //   group 3:  8 x (MFMA, LDS write) | barrier | group-0 fragments of K-step ks+1, last 8 MFMAs
-            // hipcc fills the 16 write slots with the 8 transformed-activation writes (ds_write2st64_b64) first and the
-            // 8 weight writes after them; the transform's 32 packed adds float between the MFMAs of groups 1-2.
-            // (A VMEM issue costs the wave 20-70 cycles, an LDS write ~16, a 32x32x2 fp32 MFMA holds the matrix pipe
-            // for 64.)  The loaded registers are first read ~1500-2000 cycles after the last load issues.
-            const int cur = (ks - ks0) & 1;
-            f32x4 a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
-            issue(ks + 1);
-            frags(cur, 1, a1, b1);
-            mfmas(0, a0, b0, 0, 4);
-            frags(cur, 2, a2, b2);
-            mfmas(1, a1, b1, 0, 4);
-            frags(cur, 3, a3, b3);
-            mfmas(2, a2, b2, 0, 4);
-            mfmas(3, a3, b3, 0, 2);
-            store(cur ^ 1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // group 0: activation loads ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // ... and the fragments of group 1
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // group 1: weight loads ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // ... and the fragments of group 2
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // group 2: weight writes ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // ... and the fragments of group 3
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                            // group 3, first half: activation writes
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-            __syncthreads();
-            // the second half of group 3 covers the latency of the next K-step's first fragment reads
-            frags(cur ^ 1, 0, a0, b0);
-            mfmas(3, a3, b3, 2, 4);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        }
-        // K-loop
-        {
-            const int cur = (ks1 - 1 - ks0) & 1;
-            f32x4 a1[4], b1[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) frags(cur, g + 1, a1, b1);
-                mfmas(g, a0, b0, 0, 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { a0[i] = a1[i]; b0[i] = b1[i]; }
-            }
-        }
-
-        // (1) A^T M A per (tile, channel) in registers; the 2x2 outputs go to an LDS staging tile [BT*4 pixels][BNW]
-        __syncthreads();                 // every wave is done reading the last K-step's tiles
-        // last K-step's MFMAs + barrier
-        const bool producer = STREAMK && ks0 > 0;       // later K-steps of a cut block: publish partial sums
-        WinoRows<BT, BNW> rows;
-        rows.prepare(p, tile_pix, tile_ok, n0);   // residual loads fly under the output transform (unconditional:
-                                                  // a partial block wastes them, a branch here makes hipcc spill them)
-        {
-            const int col = wn * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // D layout of the 32x32 MFMA: row (= tile) = (r&3) + 8*(r>>2) + 4*(lane>>5), column = lane&31
-                const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float m[16];
-#pragma unroll
-                for (int pos = 0; pos < 16; ++pos) {
-                    m[pos] = acc[pos][r];
-                    asm volatile("" : "+v"(m[pos]));      // one AGPR read per value (hipcc re-reads them otherwise)
-                }
-                float s0[4], s1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
-                    s1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
-                }
-                float* row = cs + (tl * 4) * LDC + col;
-                row[0 * LDC] = s0[0] + s0[1] + s0[2];       // (dy,dx) = (0,0)
-                row[1 * LDC] = s0[1] - s0[2] - s0[3];       // (0,1)
-                row[2 * LDC] = s1[0] + s1[1] + s1[2];       // (1,0)
-                row[3 * LDC] = s1[1] - s1[2] - s1[3];       // (1,1)
-                // one accumulator row at a time: left free, hipcc copies all 256 AGPRs to VGPRs up front and spills
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-        // residual loads issued, A^T M A, staging writes, barrier
-        int n_extra = 0;
-        if (STREAMK && ks1 < ksteps) {
-            // this worker owns K-steps [0, ks1) of a cut block: the rest was summed by the next workers of its
-            // group, at the START of their ranges.  One lane polls their flags, one acquire, then plain loads.
-            const int G = p.workers >> 3;
-            for (int jj = lw + 1; jj < G; ++jj) {
-                long long b, e;
-                wk_range(nblocks, ksteps, p.workers, grp, jj, p.hybrid, b, e);
-                if (b >= blk_end) break;
-                ++n_extra;
-            }
-            if (tid == 0) {
-                for (int e = 0; e < n_extra; ++e) {
-                    gu32* flag = (gu32*)(p.flags + worker + 1 + e);
-                    // bounded: the launch always ends; on expiry the block's sum is incomplete and the failure is
-                    // made loud through the context's error word (y3_conv_common.h, sk_consume)
-                    unsigned spins = 0;
-                    for (; spins < p.spin_limit; ++spins) {
-                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    if (spins == p.spin_limit && p.err)
-                        __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-        }
-        if (STREAMK && has_next) {
-            // the next segment's first K-step is fetched under this block's tail (its registers are free: the tail
-            // holds 81 and the accumulators are dead)
-            setup_voff(next_blk);
-            issue(next_ks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // next block's offsets + loads issued
-        if (!producer) {
-            // (2) all threads: float4 rows of the staging tile (+ the partial sums other workers published for this
-            // block) -> scale/shift, LeakyReLU, + residual -> global
-            static_assert(WinoRows<BT, BNW>::PASSES == 16, "one accumulator set is reset per store pass");
-            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-            rows.template finish<STATS>(p, cs, n0, [&](int i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4), &s1, &s2);
-            if (STATS) {
-                // combine the 16 row lanes of every column quad through the LDS in a fixed order (deterministic)
-                constexpr int C4 = BNW / 4, RPP = 256 / C4;
-                const int tc = (tid % C4) * 4, tr = tid / C4;
-                __syncthreads();                           // every thread is done reading the staged outputs
-                float* red = cs;                           // [RPP][2][BNW]
-                *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BNW + tc) = s1;
-                *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BNW + tc) = s2;
-                __syncthreads();
-                if (tid < C4 && n0 + tc < p.Cout) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < RPP; ++k) {
-                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BNW + tc);
-                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BNW + tc);
-                    }
-                    float* st = p.stats + (size_t)(t0 / BT) * 2 * p.Cout;
-                    *reinterpret_cast<f32x4*>(st + n0 + tc) = a;
-                    *reinterpret_cast<f32x4*>(st + p.Cout + n0 + tc) = b;
-                }
-                if (!STREAMK) __syncthreads();             // (STREAMK: the barrier below)
-            }
-        } else {
-#pragma unroll
-            for (int pos = 0; pos < 16; ++pos)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
-            // producer: the output-space sums go to this worker's slot, write-through (sc1), then the flag
-            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-                p.partial, 0, (unsigned)((size_t)p.workers * BT * 4 * BNW * 4), 0x00020000);
-            const unsigned slot_off = (unsigned)worker * (unsigned)(BT * 4 * BNW * 4);
-            constexpr int C4 = BNW / 4;
-            for (int f = tid; f < BT * 4 * C4; f += 256) {
-                const int rr = f / C4, c4 = f - rr * C4;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_part,
-                                                       slot_off + (unsigned)f * 16u, 0, 16);   // aux 16 = sc1
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its stores ...
-            __syncthreads();
-            if (tid == 0 && !p.fault)                              // ... before one lane raises the flag
-                __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (STREAMK) __syncthreads();     // the LDS is reused by the next segment
-        // scale/shift/activation/residual/stores (or the partial-slot copy), barrier
-        if (whole) { --dp_left; dp_blk += p.workers >> 3; }
-        item = seg_end;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
-// Eight-wave form of the kernel above: the same 64-tile x 64-channel block, LDS layout and K-step, computed by 512
+// The eight-wave kernel: a 64-tile x 64-channel block for all 16 transform positions, computed by 512
 // threads - waves 0-3 own transform positions 0-7 (rows 0,1 of the 4x4 transform), waves 4-7 positions 8-15 - so a
 // wave holds 128 accumulator registers and a SIMD runs TWO waves: while one waits for its loads, the barrier or its
 // stores, the other one keeps the matrix pipe busy (the four-wave kernel measures 63 % pipe occupancy with one wave
@@ -1019,6 +622,335 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Four-wave kernel, TWO workgroups per CU (round 3).  The eight-wave kernel above owns a whole CU (139 KB of LDS), so
+// nothing runs on the matrix pipe while it is in its ~26k-cycle tail (output transform, residual, stores, next block's
+// addresses): 27 % of a 52-grid launch, 58 % of the 208-grid one (profiles/r02_wino8_probes.txt, "barriers only").
+// Here a workgroup is half as large - 32 tiles x 64 channels, four waves = (position half) x (channel half), 128
+// accumulator registers each - and needs 70 KB of LDS, so two of them share a CU like the direct kernel's two
+// 128x128 workgroups do (88 % pipe occupancy there): one's tail, prologue and barrier waits run under the other's MFMAs.
+//   * activations: as in the eight-wave kernel - thread = (position half, tile, channel pair), 12 8-byte loads, the
+//     half's share of B^T d B, 8 LDS writes - into a double-buffered [16][32 tiles][32 B] image (32 KB);
+//   * weights never touch the LDS: with one 32-tile block per workgroup a weight fragment is used by exactly one wave,
+//     and lane (channel, k half) of the MFMA's operand is 16 contiguous bytes of the packed [pos][Cin/8][Cout][8] array -
+//     each wave loads its own 8 fragments per K-step (1 KB contiguous per load), re-issued for K-step ks+1 as soon as
+//     the MFMAs of ks have consumed them (one register set, a K-step of latency cover);
+//   * tail, stream-K hand-off and statistics as in the eight-wave kernel (two staging tiles, summed when read back).
+template <bool STREAMK, bool STATS = false>
+__global__ void __launch_bounds__(256, 2) conv_wino4_f32_kernel(const WinoArgs p) {
+    constexpr int BT = 32, BNW = 64, NT = 256;
+    constexpr int PLANE_V = BT * WROW;                    // 1 KB per transform position
+    constexpr int STAGE_V = 16 * PLANE_V;                 // 16 KB per K-step
+    constexpr int LDC = BNW + 4;
+    constexpr int CS_BYTES = BT * 4 * LDC * 4;            // one output staging tile (34,816 B)
+    static_assert(2 * CS_BYTES >= 2 * STAGE_V, "the tile tables sit behind the two staging tiles");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Vs = smem;                                      // [2][16][BT][32 B]
+    int* tile_pix = reinterpret_cast<int*>(smem + 2 * CS_BYTES);   // [BT]
+    int* tile_ok = tile_pix + BT;                                  // [BT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a SCALAR: it feeds the scalar offset of the weight loads (a per-lane value there makes hipcc wrap
+    // every load in a waterfall loop) and the phase branches below
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave >> 1, wn = wave & 1;
+    const int nbt = (p.T + BT - 1) / BT;
+    const int ksteps = p.Cin / WKC;
+    long long item, item_end;
+    int worker = 0, grp = 0, lw = 0;
+    const int nbn_ = (p.Cout + BNW - 1) / BNW;
+    const int nblocks = nbt * nbn_;
+    {
+        const int nt = gridDim.x;
+        const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+        if (STREAMK) {
+            grp = xcd;
+            lw = (p.workers >> 3) - 1 - k8;
+            worker = grp * (p.workers >> 3) + lw;
+            wk_range(nblocks, ksteps, p.workers, grp, lw, 0, item, item_end);
+        } else {
+            item = (long long)id * ksteps;
+            item_end = item + ksteps;
+        }
+    }
+    if (item >= item_end) return;
+    const int first_blk = (int)(item / ksteps);
+    const int first_ks = (int)(item - (long long)first_blk * ksteps);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.u), 0, (unsigned)((size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
+    unsigned voff_a[12];          // byte offsets of the 3x4 patch pixels this thread loads (OOB where padded)
+    unsigned voff_u = OOB;        // byte offset of this lane's 16-byte weight fragment inside a [Cout][8] slab
+    const int a_tile = (tid & 127) >> 2, a_pair = tid & 3, a_half = tid >> 7;      // a_half == ph
+    int t0 = 0, n0 = 0;
+    auto block_origin = [&](int blk, int& t0_, int& n0_) {
+        int bn, bt;
+        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
+        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
+        t0_ = bt * BT;
+        n0_ = bn * BNW;
+    };
+    auto setup_tables = [&](int blk) {
+        block_origin(blk, t0, n0);
+        if (a_pair == 0 && a_half == 0) {
+            int pix, okbits, n, ty, tx;
+            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
+            tile_pix[a_tile] = pix;
+            tile_ok[a_tile] = okbits;
+        }
+    };
+    auto setup_voff = [&](int blk) {
+        int t0_, n0_;
+        block_origin(blk, t0_, n0_);
+        const int tid = opaque(threadIdx.x);
+        const int a_tile = (tid & 127) >> 2, a_pair = tid & 3, a_half = tid >> 7;
+        int pix, okbits, n, ty, tx;
+        wino_tile_info(p, t0_ + a_tile, pix, okbits, n, ty, tx);
+        const bool tok = pix >= 0;
+        const int y0 = 2 * ty - 1 + a_half, x0 = 2 * tx - 1;       // patch rows a_half .. a_half + 2
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = y0 + i, xx = x0 + j;
+                const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
+            }
+        const int co = n0_ + (((tid >> 6) & 1) * 32) + (tid & 31);
+        voff_u = co < p.Cout ? (unsigned)(co * WKC + ((tid >> 5) & 1) * 4) * 4u : OOB;
+    };
+    f32x2 ra[12];
+    f32x4 ru[8];
+    auto issue_a = [&](int ks) {
+        const unsigned soff_a = (unsigned)(ks * WKC) * 4u;
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+            ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
+    };
+    // weight fragment of this wave's position i (of its half) for K-step ks: slab (pos, ks) = [Cout][8] floats
+    const unsigned slab = (unsigned)p.Cout * WKC * 4u;
+    auto issue_u = [&](int ks, int i) {
+        const unsigned soff = ((unsigned)(ph * 8 + i) * (unsigned)ksteps + (unsigned)ks) * slab;
+        ru[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, soff, 0));
+    };
+    const int st_a = lds_off(a_tile, a_pair >> 1) + (a_pair & 1) * 8;
+    auto store = [&](int buf, auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+        f32x2 x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = ra[0 * 4 + j] - ra[2 * 4 + j];                                   // rows 0 / 3: d0 - d2 / d1 - d3
+            y[j] = HALF ? ra[1 * 4 + j] - ra[0 * 4 + j] : ra[1 * 4 + j] + ra[2 * 4 + j];     // rows 1 / 2: d1 + d2 / d2 - d1
+        }
+        unsigned char* vx = Vs + buf * STAGE_V + st_a + (HALF ? 12 : 0) * PLANE_V;
+        unsigned char* vy = Vs + buf * STAGE_V + st_a + (HALF ? 8 : 4) * PLANE_V;
+        *reinterpret_cast<f32x2*>(vx + 0 * PLANE_V) = x[0] - x[2];
+        *reinterpret_cast<f32x2*>(vx + 1 * PLANE_V) = x[1] + x[2];
+        *reinterpret_cast<f32x2*>(vx + 2 * PLANE_V) = x[2] - x[1];
+        *reinterpret_cast<f32x2*>(vx + 3 * PLANE_V) = x[1] - x[3];
+        *reinterpret_cast<f32x2*>(vy + 0 * PLANE_V) = y[0] - y[2];
+        *reinterpret_cast<f32x2*>(vy + 1 * PLANE_V) = y[1] + y[2];
+        *reinterpret_cast<f32x2*>(vy + 2 * PLANE_V) = y[2] - y[1];
+        *reinterpret_cast<f32x2*>(vy + 3 * PLANE_V) = y[1] - y[3];
+    };
+    auto store_ph = [&](int buf) {
+        if (ph) store(buf, std::integral_constant<int, 1>());
+        else store(buf, std::integral_constant<int, 0>());
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int pos = 0; pos < 8; ++pos)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+
+    const int frag_a = lds_off(lane & 31, lane >> 5) + ph * 8 * PLANE_V;
+    auto frags = [&](int buf, int g, f32x4 (&a)[2]) {
+        const unsigned char* vs = Vs + buf * STAGE_V + frag_a;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 2 + i) * PLANE_V);
+    };
+    auto mfmas = [&](int g, const f32x4 (&a)[2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[g * 2 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], ru[g * 2 + i][j], acc[g * 2 + i], 0, 0, 0);
+    };
+    f32x4 a0[2];
+
+    float* cs = reinterpret_cast<float*>(smem);
+    setup_voff(first_blk);
+    issue_a(first_ks);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_u(first_ks, i);
+    while (item < item_end) {
+        const int blk = (int)(item / ksteps);
+        const int ks0 = (int)(item - (long long)blk * ksteps);
+        const long long blk_end = (long long)(blk + 1) * ksteps;
+        const long long seg_end = blk_end < item_end ? blk_end : item_end;
+        const int ks1 = ks0 + (int)(seg_end - item);
+        const bool has_next = seg_end < item_end;
+        const int next_blk = (int)(seg_end / ksteps);
+        const int next_ks = (int)(seg_end - (long long)next_blk * ksteps);
+        setup_tables(blk);
+        store_ph(0);
+        __syncthreads();
+        frags(0, 0, a0);
+        for (int ks = ks0; ks + 1 < ks1; ++ks) {
+            const int cur = (ks - ks0) & 1;
+            f32x4 a1[2];
+            issue_a(ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) frags(cur, g + 1, a1);
+                mfmas(g, a0);
+                issue_u(ks + 1, 2 * g);
+                issue_u(ks + 1, 2 * g + 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a0[i] = a1[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            store_ph(cur ^ 1);
+            __syncthreads();
+            frags(cur ^ 1, 0, a0);
+        }
+        {
+            const int cur = (ks1 - 1 - ks0) & 1;
+            f32x4 a1[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) frags(cur, g + 1, a1);
+                mfmas(g, a0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a0[i] = a1[i];
+            }
+        }
+
+        // (1) this half's share of A^T M A per (tile, channel): 2x2 partial outputs -> its staging tile
+        __syncthreads();
+        const bool producer = STREAMK && ks0 > 0;
+        WinoRows<BT, BNW, NT, true> rows;
+        rows.prepare(p, tile_pix, tile_ok, n0);
+        {
+            const int col = wn * 32 + (lane & 31);
+            float* csh = cs + ph * (BT * 4 * LDC);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float m[8];
+#pragma unroll
+                for (int pos = 0; pos < 8; ++pos) m[pos] = acc[pos][r];
+                // rows 0,1 of M (ph 0): s0 = m0 + m1, s1 = m1;  rows 2,3 (ph 1): s0 = m2, s1 = -m2 - m3
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = ph ? m[j] : m[j] + m[4 + j];
+                    s1[j] = ph ? -m[j] - m[4 + j] : m[4 + j];
+                }
+                float* row = csh + (tl * 4) * LDC + col;
+                row[0 * LDC] = s0[0] + s0[1] + s0[2];
+                row[1 * LDC] = s0[1] - s0[2] - s0[3];
+                row[2 * LDC] = s1[0] + s1[1] + s1[2];
+                row[3 * LDC] = s1[1] - s1[2] - s1[3];
+            }
+        }
+        __syncthreads();
+        int n_extra = 0;
+        if (STREAMK && ks1 < ksteps) {
+            const int G = p.workers >> 3;
+            for (int jj = lw + 1; jj < G; ++jj) {
+                long long b, e;
+                wk_range(nblocks, ksteps, p.workers, grp, jj, 0, b, e);
+                if (b >= blk_end) break;
+                ++n_extra;
+            }
+            if (tid == 0) {
+                for (int e = 0; e < n_extra; ++e) {
+                    gu32* flag = (gu32*)(p.flags + worker + 1 + e);
+                    unsigned spins = 0;
+                    for (; spins < p.spin_limit; ++spins) {
+                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (spins == p.spin_limit && p.err)
+                        __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        if (STREAMK && has_next) {
+            // the next segment's first K-step is fetched under this block's tail (the accumulators are dead)
+            setup_voff(next_blk);
+            issue_a(next_ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!producer) {
+            static_assert(WinoRows<BT, BNW, NT, true>::PASSES == 8, "one accumulator set is reset per store pass");
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            rows.template finish<STATS>(p, cs, n0, [&](int i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4), &s1, &s2);
+            if (STATS) {
+                constexpr int C4 = BNW / 4, RPP = NT / C4;
+                const int tc = (tid % C4) * 4, tr = tid / C4;
+                __syncthreads();
+                float* red = cs;                           // [RPP][2][BNW]
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BNW + tc) = s1;
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BNW + tc) = s2;
+                __syncthreads();
+                if (tid < C4 && n0 + tc < p.Cout) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < RPP; ++k) {
+                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BNW + tc);
+                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BNW + tc);
+                    }
+                    float* st = p.stats + (size_t)(t0 / BT) * 2 * p.Cout;
+                    *reinterpret_cast<f32x4*>(st + n0 + tc) = a;
+                    *reinterpret_cast<f32x4*>(st + p.Cout + n0 + tc) = b;
+                }
+                if (!STREAMK) __syncthreads();
+            }
+        } else {
+#pragma unroll
+            for (int pos = 0; pos < 8; ++pos)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial, 0, (unsigned)((size_t)p.workers * BT * 4 * BNW * 4), 0x00020000);
+            const unsigned slot_off = (unsigned)worker * (unsigned)(BT * 4 * BNW * 4);
+            constexpr int C4 = BNW / 4;
+            for (int f = tid; f < BT * 4 * C4; f += NT) {
+                const int rr = f / C4, c4 = f - rr * C4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4) +
+                                *reinterpret_cast<const f32x4*>(cs + (BT * 4 + rr) * LDC + c4 * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_part,
+                                                       slot_off + (unsigned)f * 16u, 0, 16);   // aux 16 = sc1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && !p.fault)
+                __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (STREAMK && has_next) {
+            // (the weight fragments of the next segment's first K-step go out here, once the tail's registers are free:
+            // issued with the activation loads above they cost 27 spilled registers)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_u(next_ks, i);
+        }
+        if (STREAMK) __syncthreads();
+        item = seg_end;
+    }
+}
+
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
 // dgrad != 0: (cin, cout) are those of the GRADIENT conv (cin = dz channels, cout = the forward layer's Cin) and w is
 // the forward kernel stored [3*3][cout][cin] (= [tap][fwd Cin][dz_stride]); the gradient conv's kernel is the forward
@@ -1087,15 +1019,32 @@ int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int co
     return Y3_OK;
 }
 
-constexpr int WK_WORKERS = 256;     // one persistent workgroup per CU (128 KB of LDS, 256 AGPRs + ~150 VGPRs per wave)
+constexpr int WK_WORKERS = 256;     // eight-wave kernel: one persistent workgroup per CU (139 KB of LDS)
+constexpr int WK4_WORKERS = 512;    // four-wave kernel: two per CU (70 KB of LDS, <= 256 registers per wave)
 
-// stream-K scratch: one partial-sum slot per worker, then one flag word per worker
+// stream-K scratch: one partial-sum slot per worker (256 x 64 KB or 512 x 32 KB), then one flag word per worker
 constexpr size_t WK_SLOT_BYTES = (size_t)64 * 4 * 64 * sizeof(float);
 constexpr size_t WK_FLAGS_OFFSET = (size_t)WK_WORKERS * WK_SLOT_BYTES;
+static_assert(WK_FLAGS_OFFSET == (size_t)WK4_WORKERS * 32 * 4 * 64 * sizeof(float), "both kernels share the scratch");
 
 size_t y3_conv_wino_workspace_bytes_impl(const y3_conv_desc* d) {
     if (!y3_conv_wino_eligible_impl(d)) return 0;
-    return WK_FLAGS_OFFSET + (size_t)WK_WORKERS * sizeof(unsigned);
+    return WK_FLAGS_OFFSET + (size_t)WK4_WORKERS * sizeof(unsigned);
+}
+
+// Which of the two kernels runs a layer: Y3_WINO_KERNEL=4 / 8 forces one (experiment hook for tools/layer_profile.py);
+// otherwise the rule measured in profiles/r03_wino_kernels.txt.  The training forward's statistics epilogue (STATS)
+// stays on the eight-wave kernel (its per-block partial sums are laid out per 64-tile block: y3_conv_stats_blocks).
+static bool use_wino4(const WinoArgs& a) {
+    if (a.stats) return false;
+    static int force = -2;
+    if (force == -2) {
+        const char* e = getenv("Y3_WINO_KERNEL");
+        force = e ? atoi(e) : -1;
+    }
+    if (force == 4) return true;
+    if (force == 8) return false;
+    return false;
 }
 
 int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
@@ -1141,40 +1090,28 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
         }
         a.bn_inner = force >= 0 ? (force != 0) : ((size_t)16 * d->cin * d->cout * sizeof(float) <= (size_t)(1u << 20));
     }
-    constexpr int BT = 64, BNW = 64;
-    constexpr size_t lds = (size_t)2 * 16 * (BT + BNW) * WROW + 2 * BT * sizeof(int);
-    // Y3_WINO8=0 selects the four-wave kernel (one wave per SIMD); default: the eight-wave one (two waves per SIMD)
-    static int w8 = -1;
-    if (w8 < 0) {
-        const char* e = getenv("Y3_WINO8");
-        w8 = e ? (atoi(e) != 0) : 1;
-    }
-    constexpr size_t lds8 = (size_t)2 * BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
-    if (w8) {
-        auto k8 = a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>;
-        auto k8_sk = a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>;
-        static bool attr8_set[2] = {false, false};
-        if (!attr8_set[a.stats ? 1 : 0]) {
-            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k8),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k8_sk),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-            attr8_set[a.stats ? 1 : 0] = true;
+    const bool k4 = use_wino4(a);
+    const int BT = k4 ? 32 : 64, BNW = 64;
+    const int workers = k4 ? WK4_WORKERS : WK_WORKERS;
+    const size_t lds = (size_t)2 * BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
+    auto kern = k4 ? conv_wino4_f32_kernel<false, false>
+                   : (a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>);
+    auto kern_sk = k4 ? conv_wino4_f32_kernel<true, false>
+                      : (a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>);
+    {
+        static bool attr_set[3] = {false, false, false};   // per pair of instantiations; benign race (idempotent)
+        const int slot = k4 ? 2 : (a.stats ? 1 : 0);
+        if (!attr_set[slot]) {
+            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[slot] = true;
         }
-    }
-    auto kern = a.stats ? conv_wino_f32_kernel<2, 2, false, true> : conv_wino_f32_kernel<2, 2, false>;
-    auto kern_sk = a.stats ? conv_wino_f32_kernel<2, 2, true, true> : conv_wino_f32_kernel<2, 2, true>;
-    static bool attr_set[2] = {false, false};   // per (STATS) pair of instantiations; benign race (idempotent)
-    if (!attr_set[a.stats ? 1 : 0]) {
-        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[a.stats ? 1 : 0] = true;
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = (a.Cout + BNW - 1) / BNW;
     const int blocks = nbt * nbn;
-    // stream-K when the block count is a small non-integer multiple of the 256 resident workgroups (the last round
+    // stream-K when the block count is a small non-integer multiple of the resident workgroups (the last round
     // would run partly empty); Y3_CONV_WINO_STREAMK=0/1 overrides (experiment hook)
     static int force = -2;
     if (force == -2) {
@@ -1183,11 +1120,11 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     }
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
-    bool use_sk = has_ws && blocks > WK_WORKERS && blocks < 8 * WK_WORKERS && blocks % WK_WORKERS != 0;
-    if (force >= 0) use_sk = has_ws && force != 0 && blocks >= WK_WORKERS;     // (>= workers: no worker range is empty)
+    bool use_sk = has_ws && blocks > workers && blocks < 8 * workers && blocks % workers != 0;
+    if (force >= 0) use_sk = has_ws && force != 0 && blocks >= workers;     // (>= workers: no worker range is empty)
     if (use_sk) {
         a.partial = static_cast<float*>(workspace);
-        a.workers = WK_WORKERS;
+        a.workers = workers;
         a.err = sk ? sk->err : nullptr;
         y3_sk_debug_env(&a.spin_limit, &a.fault);
         if (sk && sk->flags) {
@@ -1195,19 +1132,11 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
         } else {
             // every polled word is zeroed ahead of the launch (no state is assumed in the caller's workspace)
             a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + WK_FLAGS_OFFSET);
-            Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)WK_WORKERS * sizeof(unsigned), stream));
+            Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)workers * sizeof(unsigned), stream));
         }
-        if (w8) {
-            auto k8_sk = a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>;
-            hipLaunchKernelGGL(k8_sk, dim3(WK_WORKERS), dim3(512), lds8, stream, a);
-        } else {
-            hipLaunchKernelGGL(kern_sk, dim3(WK_WORKERS), dim3(256), lds, stream, a);
-        }
-    } else if (w8) {
-        auto k8 = a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>;
-        hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), lds8, stream, a);
+        hipLaunchKernelGGL(kern_sk, dim3(workers), dim3(k4 ? 256 : 512), lds, stream, a);
     } else {
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k4 ? 256 : 512), lds, stream, a);
     }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
