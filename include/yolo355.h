@@ -120,10 +120,13 @@ int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const floa
                   float* y, void* workspace, size_t workspace_bytes);
 
 /* ---- bf16 storage / fp32 accumulate variant (BASELINE configs[4]: 608x608 bf16 inference) -----------------
- * Same contract as y3_conv2d_fwd with bf16 (round-to-nearest-even) activations, residual and packed weights
- * ([k*k][cout][cin] bf16 from y3_pack_conv_weights_bf16); scale/shift stay fp32; the accumulator is fp32.
+ * Same contract as y3_conv2d_fwd (utils/layer_utils.py:9-22) with bf16 (round-to-nearest-even) activations, residual
+ * and packed weights; scale/shift stay fp32; the accumulator is fp32; ONE rounding to bf16 at the store.
  * out_f32 != 0 writes fp32 (used for the detection convs so that decode/NMS are unchanged).  The Cin==3 stem
- * takes the fp32 image and the fp32 HWIO kernel and writes bf16. */
+ * takes the fp32 image and the fp32 HWIO kernel and writes bf16.
+ * w_packed (k*k*cin*cout bf16) is OPAQUE: y3_pack_conv_weights_bf16 chooses the layout from (k, cin) -
+ * [tap][cin/64][cout][64] for the 3x3 convs with cin % 64 == 0, [tap][cin/32][cout][32] otherwise - and
+ * y3_conv2d_fwd_bf16 assumes the same rule. */
 int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, void* w_packed);
 int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);

@@ -1,0 +1,102 @@
+"""The feeder on the GPU box (ref: train.py:34-52, utils/data_utils.py:118-224): batches arrive
+device-resident with the targets assigned by y3_process_box, and a train loop fed by it runs at the speed of the same loop
+on resident tensors - decode / augmentation / resize / H2D of the next batches overlap the step."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import COCO_ANCHORS
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_set(tmp_path, n, classes=80, seed=5):
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    lines = []
+    for i in range(n):
+        w, h = int(rng.randint(280, 360)), int(rng.randint(200, 280))
+        path = str(tmp_path / ('img_%d.jpg' % i))
+        base = rng.randint(0, 256, (h // 8, w // 8, 3)).astype(np.uint8)
+        Image.fromarray(np.repeat(np.repeat(base, 8, 0), 8, 1)[:h, :w]).save(path, quality=85)
+        k = int(rng.randint(1, 5))
+        parts = ['%d' % i, path, '%d' % w, '%d' % h]
+        for _ in range(k):
+            x0, y0 = rng.uniform(0, w * 0.5), rng.uniform(0, h * 0.5)
+            parts += ['%d' % rng.randint(0, classes), '%.1f' % x0, '%.1f' % y0, '%.1f' % (x0 + rng.uniform(20, w * 0.45)),
+                      '%.1f' % (y0 + rng.uniform(20, h * 0.45))]
+        lines.append(' '.join(parts))
+    return lines
+
+
+def test_feeder_batches_are_device_resident_and_targets_match_the_oracle(tmp_path):
+    from yolov3_tensorflow_amd.feeder import Feeder
+    from oracle import train_ref
+    lines = _write_set(tmp_path, 21)
+    f = Feeder(lines, 8, 80, [416, 416], COCO_ANCHORS, mode='train', multi_scale=True, use_mix_up=True, num_threads=6,
+               prefetch=3, seed=1)
+    seen = 0
+    for batch in f.epoch(0):
+        n = len(batch.image_ids)
+        w, h = batch.img_size
+        assert batch.images.is_cuda and tuple(batch.images.shape) == (n, h, w, 3) and batch.images.dtype == torch.float32
+        assert 0.0 <= float(batch.images.min()) and float(batch.images.max()) <= 1.0
+        assert [tuple(y.shape) for y in batch.y_true] == [(n, h // s, w // s, 3, 86) for s in (32, 16, 8)]
+        bx, lb, ct = batch.boxes.cpu().numpy(), batch.labels.cpu().numpy(), batch.counts.cpu().numpy()
+        for i in range(n):
+            want = train_ref.process_box(bx[i, :ct[i]], lb[i, :ct[i]], [w, h], 80, COCO_ANCHORS)       # box i <-> labels[i]
+            for got, ref in zip(batch.y_true, want):
+                np.testing.assert_array_equal(got[i].cpu().numpy(), ref)
+        seen += n
+    assert seen == 21 and f.batches_served == 3
+    # the same epoch again: identical batches (every draw is seeded by (seed, epoch, batch, sample))
+    f2 = Feeder(lines, 8, 80, [416, 416], COCO_ANCHORS, mode='train', multi_scale=True, use_mix_up=True, num_threads=3,
+                prefetch=2, seed=1)
+    a = next(iter(f2.epoch(0)))
+    b = next(iter(Feeder(lines, 8, 80, [416, 416], COCO_ANCHORS, mode='train', multi_scale=True, use_mix_up=True,
+                         num_threads=9, prefetch=5, seed=1).epoch(0)))
+    assert torch.equal(a.images, b.images) and all(torch.equal(x, y) for x, y in zip(a.y_true, b.y_true))
+
+
+def test_train_loop_fed_by_the_feeder_keeps_the_resident_step_time(tmp_path, isolated_graph):
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.feeder import Feeder
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    bs, steps = 16, 12
+    lines = _write_set(tmp_path, bs * (steps + 2), seed=9)
+    y3.reset_default_graph()
+    model = y3.yolov3(80, COCO_ANCHORS, batch_norm_decay=0.99)
+    model.compute_dtype = 'f32_wino'
+    with y3.variable_scope('yolov3'):
+        model.forward(torch.zeros(1, 32, 32, 3))
+        trainer = training.Trainer(model, config_optimizer('momentum', 1e-4))
+        feeder = Feeder(lines, bs, 80, [416, 416], COCO_ANCHORS, mode='train', use_mix_up=True, num_threads=32,
+                        prefetch=5, seed=2)
+        it = feeder.epoch(0)
+        first = next(it)
+        for _ in range(2):                                   # warm-up (allocations, weight packing) on a resident batch
+            trainer.step(first.images, first.y_true)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(first.images, first.y_true)
+        torch.cuda.synchronize()
+        resident = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        done = 0
+        for batch in it:
+            trainer.step(batch.images, batch.y_true)
+            done += 1
+            if done == steps:
+                break
+        torch.cuda.synchronize()
+        fed = (time.perf_counter() - t0) / steps
+    it.close()
+    feeder.close()
+    print('train step bs=%d @416: %.1f ms on resident tensors, %.1f ms fed by the feeder (%d threads, prefetch %d): %.0f '
+          'images/s decoded, augmented, resized and uploaded under the steps' % (bs, resident * 1e3, fed * 1e3, 32, 5, bs / fed))
+    assert done == steps
+    assert fed <= 1.15 * resident + 2e-3, (fed, resident)

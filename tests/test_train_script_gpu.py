@@ -51,7 +51,8 @@ def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys, isolated
         '--optimizer_name', 'adam', '--learning_rate_init', '1e-3', '--lr_type', 'piecewise', '--pw_boundaries', '140',
         '--pw_values', '1e-3', '1e-4', '--update_part', 'None',
         '--multi_scale_train', 'false', '--use_warm_up', 'false', '--warm_up_epoch', '0', '--use_label_smooth', 'false',
-        '--use_focal_loss', 'false', '--score_threshold', '0.3', '--nms_topk', '20', '--weight_decay', '0'])
+        '--use_focal_loss', 'false', '--score_threshold', '0.3', '--nms_topk', '20', '--weight_decay', '0', '--augment', 'false',
+        '--num_threads', '4'])
     # (learning rate 1e-3 for 140 steps, then 1e-4: at a constant 1e-3 Adam on this 8-image set throws loss spikes
     # in the last 50 steps whose position depends on the last bit of every kernel — tools/train_converge_probe.py
     # shows five numerically equivalent builds agreeing to 1e-5 for the first steps and ending anywhere between

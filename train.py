@@ -10,10 +10,12 @@ forward(is_training=True) -> compute_loss -> backward -> clip -> update, all on 
 `python -m torch.distributed.run --nproc-per-node N train.py ...` every rank trains on its shard of each batch and
 the flat gradient buffer is all-reduced over RCCL.
 
-What it does not have (out of scope): the cv2 augmentation pipeline (random colour distortion, expand,
-crop, flip) and mix-up, TensorBoard summaries, TF checkpoints — weights are saved as darknet `.weights` files.
-Images are read with PIL and resized like the reference's validation path (cv2.INTER_LINEAR restated without OpenCV,
-plain or letterboxed: utils.data_utils.resize_with_bbox(interp=1)).
+The batches come from yolov3_tensorflow_amd.feeder.Feeder = the reference's tf.data pipeline (train.py:34-52:
+shuffle -> batch -> get_batch_data on `num_threads` threads -> prefetch): decode, the augmentation chain of
+utils/data_aug.py (colour distortion, expansion, constrained crop, random-interpolation resize, flip, mix-up), resize and
+the host-to-device copy of the next `prefetech_buffer` batches run under the current step; targets are assigned on the
+device.  What it does not have: TensorBoard summaries and TF checkpoints - weights are saved as darknet `.weights` files
+and native `.npz` checkpoints.
 """
 from __future__ import division, print_function
 
@@ -76,7 +78,14 @@ def build_parser():
                    default=['yolov3/yolov3_head/Conv_14', 'yolov3/yolov3_head/Conv_6', 'yolov3/yolov3_head/Conv_22'])
     p.add_argument('--update_part', type=_scopes, default=['yolov3/yolov3_head'],
                    help="comma separated scopes to train; 'None' = the whole model")
+    # tf.data parameters (args.py:33-34)
+    p.add_argument('--num_threads', type=int, default=10, help='threads decoding / augmenting / resizing images')
+    p.add_argument('--prefetech_buffer', type=int, default=5, help='batches prepared ahead of the train step')
     # other strategies
+    p.add_argument('--use_mix_up', type=_bool, default=True)
+    p.add_argument('--augment', type=_bool, default=True,
+                   help="false: feed the training images through the validation preprocessing (plain resize, no "
+                        "augmentation, no mix-up) - not a reference option; used by the memorisation test")
     p.add_argument('--multi_scale_train', type=_bool, default=True)
     p.add_argument('--use_label_smooth', type=_bool, default=True)
     p.add_argument('--use_focal_loss', type=_bool, default=True)
@@ -98,43 +107,25 @@ def variables_to_restore(variables, include, exclude):
     return get_variables_to_restore(variables, include, exclude)
 
 
-def load_batch(lines, img_size, letterbox):
-    """Annotation lines -> (image ids, images [n,h,w,3] float32 in [0,1], boxes [n,kmax,5], labels, counts)."""
-    from eval import load_image
-    from yolov3_tensorflow_amd.utils.data_utils import parse_line
-    recs = [parse_line(l) for l in lines]
-    n, kmax = len(recs), max(len(r[3]) for r in recs)
-    images = np.zeros((n, img_size[1], img_size[0], 3), np.float32)
-    boxes = np.zeros((n, kmax, 5), np.float32)
-    labels = np.zeros((n, kmax), np.int64)
-    counts = np.zeros((n,), np.int64)
-    for i, (_, path, b, l, _, _) in enumerate(recs):
-        images[i], nb = load_image(path, b, img_size, letterbox)
-        k = len(l)
-        boxes[i, :k, :4], boxes[i, :k, 4], labels[i, :k], counts[i] = nb, 1.0, l, k       # mix-up weight 1
-    return [r[0] for r in recs], images, boxes, labels, counts
-
-
 def validate(model, y3, args, lines):
     """mAP / recall / precision / losses over the validation file (train.py:171-214), batched on the device."""
     from yolov3_tensorflow_amd.utils import eval_utils
-    from yolov3_tensorflow_amd.utils.data_utils import process_box_batch
     from yolov3_tensorflow_amd.utils.misc_utils import AverageMeter
     from yolov3_tensorflow_amd.utils.nms_utils import gpu_nms_batched
+    from yolov3_tensorflow_amd.feeder import Feeder
     meters = [AverageMeter() for _ in range(5)]
     val_preds = []
-    for s in range(0, len(lines), args.batch_size):
-        ids, images, boxes, labels, counts = load_batch(lines[s:s + args.batch_size], args.img_size,
-                                                        args.letterbox_resize)
-        y_true = process_box_batch(boxes, labels, counts, args.img_size, args.class_num, args.anchors)
+    feeder = Feeder(lines, args.batch_size, args.class_num, args.img_size, args.anchors, mode='val',
+                    letterbox_resize=args.letterbox_resize, num_threads=args.num_threads, prefetch=args.prefetech_buffer)
+    for batch in feeder.epoch(0):
         with y3.variable_scope('yolov3'):
-            fms = model.forward(images, False)
-        loss = model.compute_loss(fms, y_true)
+            fms = model.forward(batch.images, False)
+        loss = model.compute_loss(fms, batch.y_true)
         pb, _, _, ps = model.predict(fms, with_scores=True)
         dets = gpu_nms_batched(pb, ps, args.class_num, args.nms_topk, args.score_threshold, args.nms_threshold)
-        val_preds.extend(eval_utils.get_preds_batch(ids, dets))
+        val_preds.extend(eval_utils.get_preds_batch(batch.image_ids, dets))
         for m, v in zip(meters, loss):
-            m.update(float(v), len(ids))
+            m.update(float(v), len(batch.image_ids))
     eval_utils.gt_dict = {}
     gt = eval_utils.parse_gt_rec(args.val_file, args.img_size, args.letterbox_resize)
     rec_total, prec_total, ap_total = AverageMeter(), AverageMeter(), AverageMeter()
@@ -160,7 +151,6 @@ def main(argv=None):
     import torch.distributed as dist
     import yolov3_tensorflow_amd as y3
     from yolov3_tensorflow_amd import training, framework as fw
-    from yolov3_tensorflow_amd.utils.data_utils import process_box_batch
     from yolov3_tensorflow_amd.utils.eval_utils import evaluate_on_gpu
     from yolov3_tensorflow_amd.utils.misc_utils import (parse_anchors, read_class_names, AverageMeter,
                                                         config_learning_rate, config_optimizer, load_weights,
@@ -236,25 +226,18 @@ def main(argv=None):
         print('\n----------- start to train -----------\n')
     best_mAP = -np.inf
     history = {'loss': [], 'recall': [], 'mAP': [], 'global_step_start': int(trainer.global_step)}
-    size = list(args.img_size)
+    from yolov3_tensorflow_amd.feeder import Feeder
+    feeder = Feeder(train_lines, args.batch_size, args.class_num, args.img_size, args.anchors,
+                    mode='train' if args.augment else 'val', shuffle=True,
+                    multi_scale=args.multi_scale_train, use_mix_up=args.use_mix_up, letterbox_resize=args.letterbox_resize,
+                    num_threads=args.num_threads, prefetch=args.prefetech_buffer, seed=args.seed, rank=rank, world=world)
     for epoch in range(args.total_epoches):
-        order = list(range(args.train_img_cnt))
-        random.shuffle(order)                                                  # same order on every rank (seeded)
         meters = [AverageMeter() for _ in range(5)]
-        for i in range(args.train_batch_num):
-            if args.multi_scale_train and i % 10 == 0:
-                side = random.randrange(10, 20) * 32      # 320 .. 608: range(10, 20) of utils/data_utils.py:196
-                size = [side, side]
-            elif not args.multi_scale_train:
-                size = list(args.img_size)
-            idx = order[i * args.batch_size:(i + 1) * args.batch_size][rank::world]
-            if not idx:
-                idx = order[:1]
-            _, images, boxes, labels, counts = load_batch([train_lines[j] for j in idx], size, args.letterbox_resize)
-            y_true = process_box_batch(boxes, labels, counts, size, args.class_num, args.anchors)
+        for i, batch in enumerate(feeder.epoch(epoch)):
+            images, y_true = batch.images, batch.y_true
             with y3.variable_scope('yolov3'):
                 loss = trainer.step(images, y_true)
-            n = len(idx)
+            n = len(batch.image_ids)
             for m, v in zip(meters, loss):
                 m.update(float(v), n)
             fw.check_context()      # (the loss read-out synchronised) a device-side failure of this step raises here

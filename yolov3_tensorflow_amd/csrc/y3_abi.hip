@@ -425,10 +425,10 @@ struct y3_net {
         arena_bytes = (peak + 255) & ~(size_t)255;
         scratch_bytes = 0;
         for (const Layer& l : layers) {
-            if (dtype == 1) break;   // the bf16 kernels use no stream-K scratch
             y3_conv_desc d;
             d.n = n; d.h = h / tensors[l.src].sdiv; d.w = w / tensors[l.src].sdiv;
             d.cin = l.cin; d.c_up = l.c_up; d.cout = l.cout; d.k = l.k; d.stride = l.stride; d.act = l.act;
+            if (dtype == 1) break;   // the bf16 kernels use no stream-K scratch
             scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
             if (dtype == 4) scratch_bytes = std::max(scratch_bytes, y3_conv_wino_workspace_bytes_impl(&d));
         }

@@ -68,6 +68,111 @@ struct Swz {
     __device__ static __forceinline__ int f(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 };
 
+// ---- epilogue shared by the kernels of this file (as in y3_conv_bf16.hip): fp32 scale/shift, LeakyReLU, + residual, one
+// rounding to bf16; 64 output rows at a time through an fp32 staging tile in the (now idle) tile LDS ----------------------
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epilogue_x(const ConvArgsX& p, unsigned char* smem,
+                                           f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0, int wm, int wn) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+    constexpr int LDC = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    if ((p.Cout & 3) != 0) {
+        // detection convs: 3*(5+C) channels, fp32 output, rows not 16-byte aligned -> scalar stores
+        float* yf = static_cast<float*>(p.y);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * WTN + ni * 32 + col_l;
+            const bool cok = col < p.Cout;
+            const float sc = cok ? p.scale[col] : 0.f, sh = cok ? p.shift[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < p.M) {
+                        float v = acc[mi][ni][r] * sc + sh;
+                        if (p.act) v = v > 0.f ? v : 0.1f * v;
+                        const size_t o = (size_t)row * p.Cout + col;
+                        if (p.out_f32) yf[o] = v;
+                        else static_cast<bf16_t*>(p.y)[o] = f32_to_bf16(v);
+                    }
+                }
+        }
+        return;
+    }
+    float* cs = reinterpret_cast<float*>(smem);
+    constexpr int C4 = BN / 4, RPP = NT / C4, PASSES = 64 / RPP;
+    static_assert(RPP >= 1 && PASSES >= 1 && RPP * C4 == NT, "epilogue pass geometry");
+    const int tc = (tid % C4) * 4, tr = tid / C4;
+    const int col = n0 + tc;
+    const bool cok = col < p.Cout;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+        sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+    }
+#pragma unroll
+    for (int half = 0; half < BM / 64; ++half) {
+        // residual rows of this pass first: their latency overlaps the staging
+        u32x2 rv[PASSES];
+        if (p.resid) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const int row = m0 + 64 * half + tr + i * RPP;
+                rv[i] = (cok && row < p.M) ? *reinterpret_cast<const u32x2*>(p.resid + (size_t)row * p.Cout + col)
+                                           : u32x2{0u, 0u};
+            }
+        }
+        // the waves whose rows fall in [64*half, 64*half+64) stage their accumulators (fp32)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int rbase = wm * WTM + mi * 32;
+            if (rbase / 64 == half) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        cs[(rbase - 64 * half + row_l + (r & 3) + 8 * (r >> 2)) * LDC + wn * WTN + ni * 32 + col_l] =
+                            acc[mi][ni][r];
+            }
+        }
+        __syncthreads();
+        if (cok) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const int rr = tr + i * RPP;
+                const int row = m0 + 64 * half + rr;
+                if (row < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc);
+                    v = v * sc + sh;
+                    if (p.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    }
+                    const size_t o = (size_t)row * p.Cout + col;
+                    if (p.resid) {
+                        v[0] += __uint_as_float(rv[i][0] << 16);
+                        v[1] += __uint_as_float(rv[i][0] & 0xFFFF0000u);
+                        v[2] += __uint_as_float(rv[i][1] << 16);
+                        v[3] += __uint_as_float(rv[i][1] & 0xFFFF0000u);
+                    }
+                    if (p.out_f32) {
+                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + o) = v;
+                    } else {
+                        u32x2 pk;
+                        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(p.y) + o) = pk;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int KS, bool UPCAT>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_bf16x_kernel(const ConvArgsX p) {
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -231,101 +336,222 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_bf16x_kernel(const ConvA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the last, dead DMA writes zeros: let it land)
     __syncthreads();                                         // the staging below reuses the tile LDS
 
-    // ---- epilogue (as in y3_conv_bf16.hip): fp32 scale/shift, LeakyReLU, + residual, one rounding -------------------
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    if ((p.Cout & 3) != 0) {
-        // detection convs: 3*(5+C) channels, fp32 output, rows not 16-byte aligned -> scalar stores
-        float* yf = static_cast<float*>(p.y);
+    epilogue_x<BM, BN, WM, WN>(p, smem, acc, m0, n0, wm, wn);
+}
+
+// ---- the pipelined kernel: 256-row tiles, eight waves, operands of a whole K-tile held in registers ------------------
+// The two-stage kernel above drains its DMA queue and crosses a barrier every K-step; measured, that structure gives the
+// same ~600 TF/s as the register-staged kernel it replaced (profiles/r03_bf16x_tiles.txt) - the ceiling the CDNA guide
+// reports for every "wait for the stage, barrier, compute" loop.  This one never drains:
+//   * a K-tile (64 elements of K) is staged as four half-tiles - A rows [0,BM/2), A rows [BM/2,BM), B rows [0,BN/2),
+//     B rows [BN/2,BN) - into one of two LDS K-tile buffers; the DMA of a half-tile is issued 1 - 2 K-tiles before its
+//     first reader and the only wait in the loop is a COUNTED one at the end of a K-tile (`s_waitcnt vmcnt(BCH)`: the two
+//     B half-tiles issued last stay in flight across the barrier);
+//   * a wave reads its whole B operand of K-tile t (NI column tiles x 4 K-slices) into registers in the first phase and
+//     one 32-row tile of A per phase (double-buffered: the reads of phase p+1 fly under the MFMAs of phase p), so the B
+//     half-tiles of a buffer are free again after phase 0 and can be re-staged for K-tile t+2 while K-tile t is still
+//     being computed;
+//   * schedule of K-tile t (MI phases of 4*NI MFMAs per wave; buffer b = t & 1):
+//         phase 0 .. MI/2-1   : DMA A half-tile(s) of t+1 -> buffer 1-b  (free since the barrier that ended K-tile t-1)
+//         barrier X           : every wave holds B(t) in registers
+//         phase MI/2 .. MI-1  : DMA B half-tile(s) of t+2 -> buffer b
+//         s_waitcnt vmcnt(BCH); lgkmcnt(0); barrier Y : A(t+1) has landed for every wave (B(t+1) landed a K-tile ago)
+//     two raw s_barriers per K-tile and no vmcnt(0) anywhere in the loop; hipcc's __syncthreads() would drain the queue.
+template <int MI, int NI, int WM, int WN, int KS, bool UPCAT>
+__global__ void __launch_bounds__(512, 2) conv_bf16p_kernel(const ConvArgsX p) {
+    constexpr int BK = 64, ROWB = 128, RPI = 8, NW = 8;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    constexpr int ACH = BM / RPI / NW, BCH = BN / RPI / NW;           // DMA instructions per thread and K-tile (4; 4 or 2)
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int WTM = MI * 32, WTN = NI * 32;
+    constexpr int LDC = BN + 4;
+    static_assert(WM * WN == NW && (MI == 2 || MI == 4), "eight waves, two or four 32-row tiles per wave");
+    static_assert(ACH % (MI / 2) == 0 && BCH % (MI / 2) == 0, "the half-tile parts must divide the DMA instructions");
+    static_assert((size_t)64 * LDC * 4 <= (size_t)2 * STAGE, "epilogue staging must fit in the tile LDS");
+    using SW = Swz<BK>;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int kchunks = p.Cin / BK;
+    const int S = KS * KS * kchunks;
+
+    const int nt = gridDim.x;
+    const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, kk8 = blockIdx.x >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk8;
+    const int bn = tile / nbm, bm = tile - bn * nbm;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.w), 0, (unsigned)((size_t)KS * KS * p.Cout * p.Cin * 2), 0x00020000);
+    const unsigned bytes_x = (unsigned)((size_t)p.N * p.H * p.W * p.Cx * 2);
+    const unsigned bytes_u = UPCAT ? (unsigned)((size_t)p.N * (p.H >> 1) * (p.W >> 1) * p.Cu * 2) : 0u;
+
+    // DMA rows of this thread: instruction q = wave*CH + j fills rows 8q .. 8q+7 (lane -> row l/8, slot l%8)
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    int a_base[ACH], a_msk[ACH], a_base_u[UPCAT ? ACH : 1];
+    unsigned b_voff[BCH];
+    {
+        const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int col = n0 + wn * WTN + ni * 32 + col_l;
-            const bool cok = col < p.Cout;
-            const float sc = cok ? p.scale[col] : 0.f, sh = cok ? p.shift[col] : 0.f;
+        for (int j = 0; j < ACH; ++j) {
+            const int r = (wave * ACH + j) * RPI + l_row;
+            const int chunk = l_slot ^ SW::f(r);
+            const int m = m0 + r;
+            int mk = 0, base = 0, base_u = 0;
+            if (m < p.M) {
+                const int n = m / HoWo;
+                const int rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < p.M) {
-                        float v = acc[mi][ni][r] * sc + sh;
-                        if (p.act) v = v > 0.f ? v : 0.1f * v;
-                        const size_t o = (size_t)row * p.Cout + col;
-                        if (p.out_f32) yf[o] = v;
-                        else static_cast<bf16_t*>(p.y)[o] = f32_to_bf16(v);
-                    }
+                for (int t = 0; t < KS; ++t) {
+                    if ((unsigned)(iy0 + t) < (unsigned)p.H) mk |= 1 << t;
+                    if ((unsigned)(ix0 + t) < (unsigned)p.W) mk |= 1 << (4 + t);
                 }
-        }
-        return;
-    }
-    float* cs = reinterpret_cast<float*>(smem);
-    constexpr int C4 = BN / 4, RPP = NT / C4, PASSES = 64 / RPP;
-    static_assert(RPP >= 1 && PASSES >= 1 && RPP * C4 == NT, "epilogue pass geometry");
-    const int tc = (tid % C4) * 4, tr = tid / C4;
-    const int col = n0 + tc;
-    const bool cok = col < p.Cout;
-    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (cok) {
-        sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-        sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-    }
-#pragma unroll
-    for (int half = 0; half < BM / 64; ++half) {
-        // residual rows of this pass first: their latency overlaps the staging
-        u32x2 rv[PASSES];
-        if (p.resid) {
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                const int row = m0 + 64 * half + tr + i * RPP;
-                rv[i] = (cok && row < p.M) ? *reinterpret_cast<const u32x2*>(p.resid + (size_t)row * p.Cout + col)
-                                           : u32x2{0u, 0u};
+                base = ((n * p.H + iy0) * p.W + ix0) * p.Cx + chunk * 8;
+                if (UPCAT) base_u = ((n * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.Cu + chunk * 8;
             }
+            a_msk[j] = mk; a_base[j] = base;
+            if (UPCAT) a_base_u[j] = base_u;
         }
-        // the waves whose rows fall in [64*half, 64*half+64) stage their accumulators (fp32)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int rbase = wm * WTM + mi * 32;
-            if (rbase / 64 == half) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        cs[(rbase - 64 * half + row_l + (r & 3) + 8 * (r >> 2)) * LDC + wn * WTN + ni * 32 + col_l] =
-                            acc[mi][ni][r];
-            }
+        for (int j = 0; j < BCH; ++j) {
+            const int r = (wave * BCH + j) * RPI + l_row;
+            const int chunk = l_slot ^ SW::f(r);
+            const int co = n0 + r;
+            b_voff[j] = co < p.Cout ? (unsigned)(co * BK + chunk * 8) * 2u : OOB;
         }
-        __syncthreads();
-        if (cok) {
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                const int rr = tr + i * RPP;
-                const int row = m0 + 64 * half + rr;
-                if (row < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc);
-                    v = v * sc + sh;
-                    if (p.act) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
-                    }
-                    const size_t o = (size_t)row * p.Cout + col;
-                    if (p.resid) {
-                        v[0] += __uint_as_float(rv[i][0] << 16);
-                        v[1] += __uint_as_float(rv[i][0] & 0xFFFF0000u);
-                        v[2] += __uint_as_float(rv[i][1] << 16);
-                        v[3] += __uint_as_float(rv[i][1] & 0xFFFF0000u);
-                    }
-                    if (p.out_f32) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + o) = v;
-                    } else {
-                        u32x2 pk;
-                        pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                        pk[1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(p.y) + o) = pk;
-                    }
-                }
-            }
-        }
-        __syncthreads();
     }
+    // Two independent loader positions (A runs one K-tile ahead of the compute, B two): (tap, chunk) of the next K-tile
+    // each will stage; past the last K-tile the DMA is "dead" (every lane out of range: zeros into a buffer nobody reads).
+    struct Pos { int tap, cc, kt; };
+    Pos pa = {0, 0, 0}, pb = {0, 0, 0};
+    auto advance = [&](Pos& q) {
+        const bool wrap = ++q.cc == kchunks;
+        q.cc = wrap ? 0 : q.cc;
+        q.tap += wrap ? 1 : 0;
+        ++q.kt;
+    };
+    // part `part` of `parts` of the A tile of K-tile pa -> buffer `buf`
+    auto dma_a = [&](int buf, int part, int parts) {
+        const bool live = pa.kt < S;
+        const int ky = (KS == 1) ? 0 : pa.tap / KS;
+        const int kx = (KS == 1) ? 0 : pa.tap - ky * KS;
+        const int tap_off = (ky * p.W + kx) * p.Cx;
+        const int c0 = pa.cc * BK;
+        const bool from_up = UPCAT && c0 < p.Cu;
+        const unsigned soff = live ? (unsigned)(from_up ? c0 : c0 - (UPCAT ? p.Cu : 0)) * 2u : 0u;
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(from_up ? p.xu : p.x), 0, from_up ? bytes_u : bytes_x, 0x00020000);
+        unsigned char* as = smem + buf * STAGE + (wave * ACH) * (RPI * ROWB);
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            if (j * parts / ACH != part) continue;
+            const bool ok = live && ((a_msk[j] >> ky) & (a_msk[j] >> (4 + kx)) & 1) != 0;
+            unsigned voff = ok ? (unsigned)(a_base[j] + tap_off) * 2u : OOB;
+            if (UPCAT) voff = from_up ? (ok ? (unsigned)a_base_u[j] * 2u : OOB) : voff;
+            dma16(rs_a, as + j * (RPI * ROWB), voff, soff);
+        }
+    };
+    auto dma_b = [&](int buf, int part, int parts) {
+        const bool live = pb.kt < S;
+        // (the scalar offset is not range-checked: a dead K-tile must not carry one)
+        const unsigned wsoff = live ? (unsigned)((pb.tap * kchunks + pb.cc) * p.Cout) * (unsigned)(BK * 2) : 0u;
+        unsigned char* bs = smem + buf * STAGE + BM * ROWB + (wave * BCH) * (RPI * ROWB);
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            if (j * parts / BCH != part) continue;
+            dma16(rs_w, bs + j * (RPI * ROWB), live ? b_voff[j] : OOB, wsoff);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_half = lane >> 5, frag_f = SW::f(frag_row);
+    int frag_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = ((2 * kk + frag_half) ^ frag_f) << 4;
+    auto read_a = [&](int buf, int mi, u32x4 (&a)[4]) {
+        const unsigned char* as = smem + buf * STAGE + (wm * WTM + mi * 32 + frag_row) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = *reinterpret_cast<const u32x4*>(as + frag_off[kk]);
+    };
+    u32x4 breg[NI][4];
+    auto read_b = [&](int buf) {
+        const unsigned char* bs = smem + buf * STAGE + BM * ROWB + (wn * WTN + frag_row) * ROWB;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) breg[ni][kk] = *reinterpret_cast<const u32x4*>(bs + ni * 32 * ROWB + frag_off[kk]);
+    };
+    auto mfmas = [&](int mi, const u32x4 (&a)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[kk]),
+                                                                      __builtin_bit_cast(bf16x8, breg[ni][kk]),
+                                                                      acc[mi][ni], 0, 0, 0);
+    };
+
+    // ---- prologue: B(0), A(0), B(1) ------------------------------------------------------------------------------------
+    constexpr int HP = MI / 2;          // phases per half of a K-tile = DMA parts per operand
+#pragma unroll
+    for (int q = 0; q < HP; ++q) dma_b(0, q, HP);
+    advance(pb);
+#pragma unroll
+    for (int q = 0; q < HP; ++q) dma_a(0, q, HP);
+    advance(pa);
+#pragma unroll
+    for (int q = 0; q < HP; ++q) dma_b(1, q, HP);
+    advance(pb);
+    if (BCH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < S; ++t) {
+        const int b = t & 1;
+        u32x4 a0[4], a1[4];
+        read_b(b);
+        read_a(b, 0, a0);
+#pragma unroll
+        for (int ph = 0; ph < MI; ++ph) {
+            if (ph == HP) {
+                // every wave has B(t) in registers: its half-tiles may be re-staged
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (ph < HP) dma_a(b ^ 1, ph, HP);          // A(t+1) -> the other buffer
+            else dma_b(b, ph - HP, HP);                 // B(t+2) -> this buffer
+            if (ph + 1 < MI) {
+                if (ph & 1) read_a(b, ph + 1, a0);
+                else read_a(b, ph + 1, a1);
+            }
+            if (ph & 1) mfmas(ph, a1);
+            else mfmas(ph, a0);
+        }
+        advance(pa);
+        advance(pb);
+        // A(t+1) has landed for this wave (the B(t+2) DMA issued last stays in flight) ...
+        if (BCH == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // ... and for every wave; nobody still reads buffer b's A tile
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the last, dead DMAs write zeros: let them land)
+    __syncthreads();                                     // the staging below reuses the tile LDS
+
+    epilogue_x<BM, BN, WM, WN>(p, smem, acc, m0, n0, wm, wn);
 }
 
 __global__ void pack_weights_bf16x_kernel(const float* __restrict__ w_hwio, bf16_t* __restrict__ w_packed, int taps,
@@ -358,6 +584,23 @@ int launch_x(hipStream_t stream, const ConvArgsX& a) {
     return Y3_OK;
 }
 
+template <int MI, int NI, int WM, int WN, int KS, bool UPCAT>
+int launch_p(hipStream_t stream, const ConvArgsX& a) {
+    auto kern = conv_bf16p_kernel<MI, NI, WM, WN, KS, UPCAT>;
+    constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
+    static bool attr_set = false;     // per instantiation; benign race (idempotent)
+    if (!attr_set) {
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+        attr_set = true;
+    }
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(512), lds, stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
 // Tile choice.  Candidates: A = 256x256 (eight waves, one workgroup per CU), B = 256x128 (eight waves), C = 128x128
 // (four waves, two per CU), D = 128x64 / 128x32 (narrow Cout).  Y3_BF16X_TILE=A|B|C forces one where it applies
 // (experiment hook for tools/layer_profile.py); the default rule is the one measured in profiles/r03_bf16x_tiles.txt.
@@ -378,24 +621,36 @@ int dispatch_x(hipStream_t stream, const ConvArgsX& a) {
     if (a.Cout <= 64) return launch_x<128, 64, 4, 1, 64, KS, UPCAT>(stream, a);
     int t = forced_tile();
     if (t < 0) {
+        // measured at configs[4] (bs = 16, 608x608; profiles/r03_bf16x_tiles.txt): what decides is how the tile count
+        // quantises over the 256 CUs.  One round or less of 256x256 tiles -> the pipelined kernel on them (38-grid: 182
+        // tiles, 0.068 ms against 0.080 for 128x128 tiles); half a round or less -> its 256x128 form (19-grid: 184 tiles
+        // instead of 92); more than one round (76-grid: 361 tiles = 1.41 rounds) -> 128x128 tiles two per CU, which
+        // quantise 4x finer.  Cout = 128 layers: 128x128 tiles.
         const long long tilesA = (long long)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
-        const long long tilesB = (long long)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
-        if (KS == 3 && a.Cout >= 256 && tilesA >= 448) t = 0;
-        else if (KS == 3 && tilesB >= 448) t = 1;
+        if (a.Cout >= 256 && tilesA <= 128) t = 1;
+        else if (a.Cout >= 256 && tilesA <= 256) t = 0;
         else t = 2;
     }
-    if (t == 0 && a.Cout >= 256) return launch_x<256, 256, 2, 4, 64, KS, UPCAT>(stream, a);
-    if (t <= 1) return launch_x<256, 128, 4, 2, 64, KS, UPCAT>(stream, a);
+    static int pipe = -1;           // Y3_BF16X_PIPE=0: the two-stage kernel on the 256-row tiles too (A/B runs)
+    if (pipe < 0) {
+        const char* e = getenv("Y3_BF16X_PIPE");
+        pipe = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (t == 0 && a.Cout >= 256)
+        return pipe ? launch_p<4, 2, 2, 4, KS, UPCAT>(stream, a) : launch_x<256, 256, 2, 4, 64, KS, UPCAT>(stream, a);
+    if (t <= 1)
+        return pipe ? launch_p<2, 2, 4, 2, KS, UPCAT>(stream, a) : launch_x<256, 128, 4, 2, 64, KS, UPCAT>(stream, a);
     return launch_x<128, 128, 2, 2, 64, KS, UPCAT>(stream, a);
 }
 
 }  // namespace
 
-// Input-channel counts the second-generation kernel takes (64-element K-steps, or 32 for the Cin = 32 layers); decided by
-// Cin alone, because the weight packing ([tap][Cin/BK][Cout][BK]) is chosen when only the kernel's shape is known.  The
-// others (and everything with Y3_BF16X=0 in the environment: A/B runs) stay on y3_conv_bf16.hip's kernel.
-int y3_conv_bf16x_cin(int cin) {
-    if (cin != 32 && cin % 64 != 0) return 0;
+// Shapes the kernels of this file take: the 3x3 convs with Cin = 32 or a multiple of 64 (64-element K-steps; 32 for the
+// two Cin = 32 layers).  Decided by (k, Cin) alone, because the weight packing ([tap][Cin/BK][Cout][BK]) is chosen when
+// only the kernel's shape is known.  The 1x1 convs (HBM-bound: three workgroups per CU on 32-element K-steps measured
+// 10 % faster than anything here) and everything with Y3_BF16X=0 in the environment (A/B runs) stay on y3_conv_bf16.hip.
+int y3_conv_bf16x_takes(int k, int cin) {
+    if (k != 3 || (cin != 32 && cin % 64 != 0)) return 0;
     static int off = -1;
     if (off < 0) {
         const char* e = getenv("Y3_BF16X");
@@ -425,7 +680,5 @@ int y3_launch_conv_bf16x(hipStream_t stream, const y3_conv_desc* d, const void* 
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.out_f32 = out_f32; a.M = (int)M;
-    if (x_up) return dispatch_x<1, true>(stream, a);
-    if (d->k == 1) return dispatch_x<1, false>(stream, a);
-    return dispatch_x<3, false>(stream, a);
+    return dispatch_x<3, false>(stream, a);      // (the launcher in y3_conv_bf16.hip sends only 3x3 convs here)
 }

@@ -622,335 +622,6 @@ __global__ void __launch_bounds__(512, 1) conv_wino8_f32_kernel(const WinoArgs p
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Four-wave kernel, TWO workgroups per CU (round 3).  The eight-wave kernel above owns a whole CU (139 KB of LDS), so
-// nothing runs on the matrix pipe while it is in its ~26k-cycle tail (output transform, residual, stores, next block's
-// addresses): 27 % of a 52-grid launch, 58 % of the 208-grid one (profiles/r02_wino8_probes.txt, "barriers only").
-// Here a workgroup is half as large - 32 tiles x 64 channels, four waves = (position half) x (channel half), 128
-// accumulator registers each - and needs 70 KB of LDS, so two of them share a CU like the direct kernel's two
-// 128x128 workgroups do (88 % pipe occupancy there): one's tail, prologue and barrier waits run under the other's MFMAs.
-//   * activations: as in the eight-wave kernel - thread = (position half, tile, channel pair), 12 8-byte loads, the
-//     half's share of B^T d B, 8 LDS writes - into a double-buffered [16][32 tiles][32 B] image (32 KB);
-//   * weights never touch the LDS: with one 32-tile block per workgroup a weight fragment is used by exactly one wave,
-//     and lane (channel, k half) of the MFMA's operand is 16 contiguous bytes of the packed [pos][Cin/8][Cout][8] array -
-//     each wave loads its own 8 fragments per K-step (1 KB contiguous per load), re-issued for K-step ks+1 as soon as
-//     the MFMAs of ks have consumed them (one register set, a K-step of latency cover);
-//   * tail, stream-K hand-off and statistics as in the eight-wave kernel (two staging tiles, summed when read back).
-template <bool STREAMK, bool STATS = false>
-__global__ void __launch_bounds__(256, 2) conv_wino4_f32_kernel(const WinoArgs p) {
-    constexpr int BT = 32, BNW = 64, NT = 256;
-    constexpr int PLANE_V = BT * WROW;                    // 1 KB per transform position
-    constexpr int STAGE_V = 16 * PLANE_V;                 // 16 KB per K-step
-    constexpr int LDC = BNW + 4;
-    constexpr int CS_BYTES = BT * 4 * LDC * 4;            // one output staging tile (34,816 B)
-    static_assert(2 * CS_BYTES >= 2 * STAGE_V, "the tile tables sit behind the two staging tiles");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Vs = smem;                                      // [2][16][BT][32 B]
-    int* tile_pix = reinterpret_cast<int*>(smem + 2 * CS_BYTES);   // [BT]
-    int* tile_ok = tile_pix + BT;                                  // [BT]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    // the wave index as a SCALAR: it feeds the scalar offset of the weight loads (a per-lane value there makes hipcc wrap
-    // every load in a waterfall loop) and the phase branches below
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ph = wave >> 1, wn = wave & 1;
-    const int nbt = (p.T + BT - 1) / BT;
-    const int ksteps = p.Cin / WKC;
-    long long item, item_end;
-    int worker = 0, grp = 0, lw = 0;
-    const int nbn_ = (p.Cout + BNW - 1) / BNW;
-    const int nblocks = nbt * nbn_;
-    {
-        const int nt = gridDim.x;
-        const int q8 = nt >> 3, r8 = nt & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
-        const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
-        if (STREAMK) {
-            grp = xcd;
-            lw = (p.workers >> 3) - 1 - k8;
-            worker = grp * (p.workers >> 3) + lw;
-            wk_range(nblocks, ksteps, p.workers, grp, lw, 0, item, item_end);
-        } else {
-            item = (long long)id * ksteps;
-            item_end = item + ksteps;
-        }
-    }
-    if (item >= item_end) return;
-    const int first_blk = (int)(item / ksteps);
-    const int first_ks = (int)(item - (long long)first_blk * ksteps);
-
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.u), 0, (unsigned)((size_t)16 * p.Cin * p.Cout * 4), 0x00020000);
-    unsigned voff_a[12];          // byte offsets of the 3x4 patch pixels this thread loads (OOB where padded)
-    unsigned voff_u = OOB;        // byte offset of this lane's 16-byte weight fragment inside a [Cout][8] slab
-    const int a_tile = (tid & 127) >> 2, a_pair = tid & 3, a_half = tid >> 7;      // a_half == ph
-    int t0 = 0, n0 = 0;
-    auto block_origin = [&](int blk, int& t0_, int& n0_) {
-        int bn, bt;
-        if (p.bn_inner) { bt = fastdiv(blk, nbn_); bn = blk - bt * nbn_; }
-        else            { bn = fastdiv(blk, nbt); bt = blk - bn * nbt; }
-        t0_ = bt * BT;
-        n0_ = bn * BNW;
-    };
-    auto setup_tables = [&](int blk) {
-        block_origin(blk, t0, n0);
-        if (a_pair == 0 && a_half == 0) {
-            int pix, okbits, n, ty, tx;
-            wino_tile_info(p, t0 + a_tile, pix, okbits, n, ty, tx);
-            tile_pix[a_tile] = pix;
-            tile_ok[a_tile] = okbits;
-        }
-    };
-    auto setup_voff = [&](int blk) {
-        int t0_, n0_;
-        block_origin(blk, t0_, n0_);
-        const int tid = opaque(threadIdx.x);
-        const int a_tile = (tid & 127) >> 2, a_pair = tid & 3, a_half = tid >> 7;
-        int pix, okbits, n, ty, tx;
-        wino_tile_info(p, t0_ + a_tile, pix, okbits, n, ty, tx);
-        const bool tok = pix >= 0;
-        const int y0 = 2 * ty - 1 + a_half, x0 = 2 * tx - 1;       // patch rows a_half .. a_half + 2
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int yy = y0 + i, xx = x0 + j;
-                const bool ok = tok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                voff_a[i * 4 + j] = ok ? (unsigned)(((n * p.H + yy) * p.W + xx) * p.Cin + a_pair * 2) * 4u : OOB;
-            }
-        const int co = n0_ + (((tid >> 6) & 1) * 32) + (tid & 31);
-        voff_u = co < p.Cout ? (unsigned)(co * WKC + ((tid >> 5) & 1) * 4) * 4u : OOB;
-    };
-    f32x2 ra[12];
-    f32x4 ru[8];
-    auto issue_a = [&](int ks) {
-        const unsigned soff_a = (unsigned)(ks * WKC) * 4u;
-#pragma unroll
-        for (int j = 0; j < 12; ++j)
-            ra[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, voff_a[j], soff_a, 0));
-    };
-    // weight fragment of this wave's position i (of its half) for K-step ks: slab (pos, ks) = [Cout][8] floats
-    const unsigned slab = (unsigned)p.Cout * WKC * 4u;
-    auto issue_u = [&](int ks, int i) {
-        const unsigned soff = ((unsigned)(ph * 8 + i) * (unsigned)ksteps + (unsigned)ks) * slab;
-        ru[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, voff_u, soff, 0));
-    };
-    const int st_a = lds_off(a_tile, a_pair >> 1) + (a_pair & 1) * 8;
-    auto store = [&](int buf, auto half_c) {
-        constexpr int HALF = decltype(half_c)::value;
-        f32x2 x[4], y[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            x[j] = ra[0 * 4 + j] - ra[2 * 4 + j];                                   // rows 0 / 3: d0 - d2 / d1 - d3
-            y[j] = HALF ? ra[1 * 4 + j] - ra[0 * 4 + j] : ra[1 * 4 + j] + ra[2 * 4 + j];     // rows 1 / 2: d1 + d2 / d2 - d1
-        }
-        unsigned char* vx = Vs + buf * STAGE_V + st_a + (HALF ? 12 : 0) * PLANE_V;
-        unsigned char* vy = Vs + buf * STAGE_V + st_a + (HALF ? 8 : 4) * PLANE_V;
-        *reinterpret_cast<f32x2*>(vx + 0 * PLANE_V) = x[0] - x[2];
-        *reinterpret_cast<f32x2*>(vx + 1 * PLANE_V) = x[1] + x[2];
-        *reinterpret_cast<f32x2*>(vx + 2 * PLANE_V) = x[2] - x[1];
-        *reinterpret_cast<f32x2*>(vx + 3 * PLANE_V) = x[1] - x[3];
-        *reinterpret_cast<f32x2*>(vy + 0 * PLANE_V) = y[0] - y[2];
-        *reinterpret_cast<f32x2*>(vy + 1 * PLANE_V) = y[1] + y[2];
-        *reinterpret_cast<f32x2*>(vy + 2 * PLANE_V) = y[2] - y[1];
-        *reinterpret_cast<f32x2*>(vy + 3 * PLANE_V) = y[1] - y[3];
-    };
-    auto store_ph = [&](int buf) {
-        if (ph) store(buf, std::integral_constant<int, 1>());
-        else store(buf, std::integral_constant<int, 0>());
-    };
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int pos = 0; pos < 8; ++pos)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
-
-    const int frag_a = lds_off(lane & 31, lane >> 5) + ph * 8 * PLANE_V;
-    auto frags = [&](int buf, int g, f32x4 (&a)[2]) {
-        const unsigned char* vs = Vs + buf * STAGE_V + frag_a;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(vs + (g * 2 + i) * PLANE_V);
-    };
-    auto mfmas = [&](int g, const f32x4 (&a)[2]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[g * 2 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], ru[g * 2 + i][j], acc[g * 2 + i], 0, 0, 0);
-    };
-    f32x4 a0[2];
-
-    float* cs = reinterpret_cast<float*>(smem);
-    setup_voff(first_blk);
-    issue_a(first_ks);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) issue_u(first_ks, i);
-    while (item < item_end) {
-        const int blk = (int)(item / ksteps);
-        const int ks0 = (int)(item - (long long)blk * ksteps);
-        const long long blk_end = (long long)(blk + 1) * ksteps;
-        const long long seg_end = blk_end < item_end ? blk_end : item_end;
-        const int ks1 = ks0 + (int)(seg_end - item);
-        const bool has_next = seg_end < item_end;
-        const int next_blk = (int)(seg_end / ksteps);
-        const int next_ks = (int)(seg_end - (long long)next_blk * ksteps);
-        setup_tables(blk);
-        store_ph(0);
-        __syncthreads();
-        frags(0, 0, a0);
-        for (int ks = ks0; ks + 1 < ks1; ++ks) {
-            const int cur = (ks - ks0) & 1;
-            f32x4 a1[2];
-            issue_a(ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) frags(cur, g + 1, a1);
-                mfmas(g, a0);
-                issue_u(ks + 1, 2 * g);
-                issue_u(ks + 1, 2 * g + 1);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a0[i] = a1[i];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            store_ph(cur ^ 1);
-            __syncthreads();
-            frags(cur ^ 1, 0, a0);
-        }
-        {
-            const int cur = (ks1 - 1 - ks0) & 1;
-            f32x4 a1[2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) frags(cur, g + 1, a1);
-                mfmas(g, a0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a0[i] = a1[i];
-            }
-        }
-
-        // (1) this half's share of A^T M A per (tile, channel): 2x2 partial outputs -> its staging tile
-        __syncthreads();
-        const bool producer = STREAMK && ks0 > 0;
-        WinoRows<BT, BNW, NT, true> rows;
-        rows.prepare(p, tile_pix, tile_ok, n0);
-        {
-            const int col = wn * 32 + (lane & 31);
-            float* csh = cs + ph * (BT * 4 * LDC);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float m[8];
-#pragma unroll
-                for (int pos = 0; pos < 8; ++pos) m[pos] = acc[pos][r];
-                // rows 0,1 of M (ph 0): s0 = m0 + m1, s1 = m1;  rows 2,3 (ph 1): s0 = m2, s1 = -m2 - m3
-                float s0[4], s1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s0[j] = ph ? m[j] : m[j] + m[4 + j];
-                    s1[j] = ph ? -m[j] - m[4 + j] : m[4 + j];
-                }
-                float* row = csh + (tl * 4) * LDC + col;
-                row[0 * LDC] = s0[0] + s0[1] + s0[2];
-                row[1 * LDC] = s0[1] - s0[2] - s0[3];
-                row[2 * LDC] = s1[0] + s1[1] + s1[2];
-                row[3 * LDC] = s1[1] - s1[2] - s1[3];
-            }
-        }
-        __syncthreads();
-        int n_extra = 0;
-        if (STREAMK && ks1 < ksteps) {
-            const int G = p.workers >> 3;
-            for (int jj = lw + 1; jj < G; ++jj) {
-                long long b, e;
-                wk_range(nblocks, ksteps, p.workers, grp, jj, 0, b, e);
-                if (b >= blk_end) break;
-                ++n_extra;
-            }
-            if (tid == 0) {
-                for (int e = 0; e < n_extra; ++e) {
-                    gu32* flag = (gu32*)(p.flags + worker + 1 + e);
-                    unsigned spins = 0;
-                    for (; spins < p.spin_limit; ++spins) {
-                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    if (spins == p.spin_limit && p.err)
-                        __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-        }
-        if (STREAMK && has_next) {
-            // the next segment's first K-step is fetched under this block's tail (the accumulators are dead)
-            setup_voff(next_blk);
-            issue_a(next_ks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!producer) {
-            static_assert(WinoRows<BT, BNW, NT, true>::PASSES == 8, "one accumulator set is reset per store pass");
-            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-            rows.template finish<STATS>(p, cs, n0, [&](int i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-            }, n_extra, (unsigned)(worker + 1) * (unsigned)(BT * 4 * BNW * 4), &s1, &s2);
-            if (STATS) {
-                constexpr int C4 = BNW / 4, RPP = NT / C4;
-                const int tc = (tid % C4) * 4, tr = tid / C4;
-                __syncthreads();
-                float* red = cs;                           // [RPP][2][BNW]
-                *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BNW + tc) = s1;
-                *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BNW + tc) = s2;
-                __syncthreads();
-                if (tid < C4 && n0 + tc < p.Cout) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < RPP; ++k) {
-                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BNW + tc);
-                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BNW + tc);
-                    }
-                    float* st = p.stats + (size_t)(t0 / BT) * 2 * p.Cout;
-                    *reinterpret_cast<f32x4*>(st + n0 + tc) = a;
-                    *reinterpret_cast<f32x4*>(st + p.Cout + n0 + tc) = b;
-                }
-                if (!STREAMK) __syncthreads();
-            }
-        } else {
-#pragma unroll
-            for (int pos = 0; pos < 8; ++pos)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
-            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
-                p.partial, 0, (unsigned)((size_t)p.workers * BT * 4 * BNW * 4), 0x00020000);
-            const unsigned slot_off = (unsigned)worker * (unsigned)(BT * 4 * BNW * 4);
-            constexpr int C4 = BNW / 4;
-            for (int f = tid; f < BT * 4 * C4; f += NT) {
-                const int rr = f / C4, c4 = f - rr * C4;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rr * LDC + c4 * 4) +
-                                *reinterpret_cast<const f32x4*>(cs + (BT * 4 + rr) * LDC + c4 * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_part,
-                                                       slot_off + (unsigned)f * 16u, 0, 16);   // aux 16 = sc1
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && !p.fault)
-                __hip_atomic_store((gu32*)(p.flags + worker), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (STREAMK && has_next) {
-            // (the weight fragments of the next segment's first K-step go out here, once the tail's registers are free:
-            // issued with the activation loads above they cost 27 spilled registers)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) issue_u(next_ks, i);
-        }
-        if (STREAMK) __syncthreads();
-        item = seg_end;
-    }
-}
-
 // U = G g G^T for every (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; out[pos][ci/8][co][ci%8]
 // dgrad != 0: (cin, cout) are those of the GRADIENT conv (cin = dz channels, cout = the forward layer's Cin) and w is
 // the forward kernel stored [3*3][cout][cin] (= [tap][fwd Cin][dz_stride]); the gradient conv's kernel is the forward
@@ -1019,32 +690,15 @@ int y3_launch_pack_wino(hipStream_t stream, const float* w_hwio, int cin, int co
     return Y3_OK;
 }
 
-constexpr int WK_WORKERS = 256;     // eight-wave kernel: one persistent workgroup per CU (139 KB of LDS)
-constexpr int WK4_WORKERS = 512;    // four-wave kernel: two per CU (70 KB of LDS, <= 256 registers per wave)
+constexpr int WK_WORKERS = 256;     // one persistent workgroup per CU (139 KB of LDS, eight waves)
 
-// stream-K scratch: one partial-sum slot per worker (256 x 64 KB or 512 x 32 KB), then one flag word per worker
+// stream-K scratch: one partial-sum slot per worker, then one flag word per worker
 constexpr size_t WK_SLOT_BYTES = (size_t)64 * 4 * 64 * sizeof(float);
 constexpr size_t WK_FLAGS_OFFSET = (size_t)WK_WORKERS * WK_SLOT_BYTES;
-static_assert(WK_FLAGS_OFFSET == (size_t)WK4_WORKERS * 32 * 4 * 64 * sizeof(float), "both kernels share the scratch");
 
 size_t y3_conv_wino_workspace_bytes_impl(const y3_conv_desc* d) {
     if (!y3_conv_wino_eligible_impl(d)) return 0;
-    return WK_FLAGS_OFFSET + (size_t)WK4_WORKERS * sizeof(unsigned);
-}
-
-// Which of the two kernels runs a layer: Y3_WINO_KERNEL=4 / 8 forces one (experiment hook for tools/layer_profile.py);
-// otherwise the rule measured in profiles/r03_wino_kernels.txt.  The training forward's statistics epilogue (STATS)
-// stays on the eight-wave kernel (its per-block partial sums are laid out per 64-tile block: y3_conv_stats_blocks).
-static bool use_wino4(const WinoArgs& a) {
-    if (a.stats) return false;
-    static int force = -2;
-    if (force == -2) {
-        const char* e = getenv("Y3_WINO_KERNEL");
-        force = e ? atoi(e) : -1;
-    }
-    if (force == 4) return true;
-    if (force == 8) return false;
-    return false;
+    return WK_FLAGS_OFFSET + (size_t)WK_WORKERS * sizeof(unsigned);
 }
 
 int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
@@ -1090,17 +744,14 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
         }
         a.bn_inner = force >= 0 ? (force != 0) : ((size_t)16 * d->cin * d->cout * sizeof(float) <= (size_t)(1u << 20));
     }
-    const bool k4 = use_wino4(a);
-    const int BT = k4 ? 32 : 64, BNW = 64;
-    const int workers = k4 ? WK4_WORKERS : WK_WORKERS;
-    const size_t lds = (size_t)2 * BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
-    auto kern = k4 ? conv_wino4_f32_kernel<false, false>
-                   : (a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>);
-    auto kern_sk = k4 ? conv_wino4_f32_kernel<true, false>
-                      : (a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>);
+    constexpr int BT = 64, BNW = 64;
+    constexpr int workers = WK_WORKERS;
+    constexpr size_t lds = (size_t)2 * BT * 4 * (BNW + 4) * sizeof(float) + 2 * BT * sizeof(int);
+    auto kern = a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>;
+    auto kern_sk = a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>;
     {
-        static bool attr_set[3] = {false, false, false};   // per pair of instantiations; benign race (idempotent)
-        const int slot = k4 ? 2 : (a.stats ? 1 : 0);
+        static bool attr_set[2] = {false, false};   // per pair of instantiations; benign race (idempotent)
+        const int slot = a.stats ? 1 : 0;
         if (!attr_set[slot]) {
             Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1134,9 +785,9 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
             a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + WK_FLAGS_OFFSET);
             Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)workers * sizeof(unsigned), stream));
         }
-        hipLaunchKernelGGL(kern_sk, dim3(workers), dim3(k4 ? 256 : 512), lds, stream, a);
+        hipLaunchKernelGGL(kern_sk, dim3(workers), dim3(512), lds, stream, a);
     } else {
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k4 ? 256 : 512), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, stream, a);
     }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;

@@ -78,7 +78,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
                          void* workspace, size_t workspace_bytes, const y3_sk_opts* sk = nullptr);
 int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                         const float* scale, const float* shift, const void* residual, void* y, int out_f32);
-int y3_conv_bf16x_cin(int cin);
+int y3_conv_bf16x_takes(int k, int cin);
 int y3_launch_pack_bf16x(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, void* w_packed);
 int y3_launch_conv_bf16x(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                          const float* scale, const float* shift, const void* residual, void* y, int out_f32);

@@ -1,8 +1,9 @@
 # coding: utf-8
 """The slice of the reference's utils/data_utils.py / utils/data_aug.py that sits immediately either side of
 the hot path: annotation-line parsing (`parse_line`), target assignment (`process_box`,
-on the device, batched) and the OpenCV-free letterbox used by the single-image and eval paths.  Augmentation
-stays out of scope."""
+on the device, batched), the OpenCV-free resizes / letterbox used by the single-image and eval paths, and the per-image /
+per-batch feeder functions `parse_data` / `get_batch_data` (augmentations: utils/data_aug.py; the threaded, prefetching,
+device-resident form: yolov3_tensorflow_amd/feeder.py)."""
 from __future__ import division, print_function
 
 import ctypes
@@ -68,8 +69,11 @@ def process_box_batch(boxes, labels, counts, img_size, class_num, anchors):
         raise ValueError("boxes must be [N, Kmax, 5]")
     n, kmax, _ = b.shape
     dev = b.device
-    lab = torch.as_tensor(np.asarray(labels), dtype=torch.int32).reshape(n, kmax).to(dev).contiguous()
-    cnt = torch.as_tensor(np.asarray(counts), dtype=torch.int32).reshape(n).to(dev).contiguous()
+    def as_i32(v, shape):        # numpy / list / (device) tensor -> contiguous int32 tensor on `dev`
+        t = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+        return t.to(device=dev, dtype=torch.int32).reshape(shape).contiguous()
+    lab = as_i32(labels, (n, kmax))
+    cnt = as_i32(counts, (n,))
     w, h = int(img_size[0]), int(img_size[1])
     C = int(class_num)
     anc = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(9, 2))
@@ -190,3 +194,141 @@ def resize_with_bbox(img, bbox, new_width, new_height, interp=0, letterbox=False
     bbox[:, [0, 2]] = bbox[:, [0, 2]] / ori_width * new_width
     bbox[:, [1, 3]] = bbox[:, [1, 3]] / ori_height * new_height
     return img, bbox
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the per-image / per-batch feeder functions (reference utils/data_utils.py:118-224)
+# ---------------------------------------------------------------------------------------------------------------------
+iter_cnt = 0        # the reference's module-global batch counter (multi-scale: a new size every `interval` batches)
+
+
+def _read_rgb(pic_path):
+    from PIL import Image
+    return np.asarray(Image.open(pic_path).convert('RGB'))
+
+
+def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None):
+    """The image half of the reference's parse_data (utils/data_utils.py:118-172): read (PIL, RGB), mix-up when `line` is
+    a pair, the 'train' augmentation chain (colour distortion, expansion, constrained crop, resize with a random
+    interpolation, horizontal flip) or the plain 'val' resize.  Returns (img_idx, float32 RGB image in [0,1] of shape
+    [img_size[1], img_size[0], 3], boxes [K,5] with the mix-up weight in column 4, labels [>=K]: the crop may drop boxes
+    and, like the reference, does not drop their labels - see collate()).  Target assignment (process_box) is NOT done here: the feeder runs it on the device for the whole batch (process_box_batch)."""
+    from . import data_aug
+    rng = rng if rng is not None else np.random
+    if not isinstance(line, (list, tuple)):
+        img_idx, pic_path, boxes, labels, _, _ = parse_line(line)
+        img = _read_rgb(pic_path)
+        # expand the 2nd dimension, mix up weight default to 1.
+        boxes = np.concatenate((boxes, np.full(shape=(boxes.shape[0], 1), fill_value=1., dtype=np.float32)), axis=-1)
+    else:
+        # the mix up case
+        _, pic_path1, boxes1, labels1, _, _ = parse_line(line[0])
+        img_idx, pic_path2, boxes2, labels2, _, _ = parse_line(line[1])
+        img, boxes = data_aug.mix_up(_read_rgb(pic_path1), _read_rgb(pic_path2), boxes1, boxes2, rng=rng)
+        labels = np.concatenate((labels1, labels2))
+    if str(mode) == 'train':
+        img = data_aug.random_color_distort(img, rng=rng)
+        if rng.uniform(0, 1) > 0.5:                     # random expansion with prob 0.5
+            img, boxes = data_aug.random_expand(img, boxes, 4, prng=prng)
+        h, w, _ = img.shape                             # random cropping
+        boxes, crop = data_aug.random_crop_with_constraints(boxes, (w, h), rng=rng, prng=prng)
+        x0, y0, w, h = crop
+        img = img[y0: y0 + h, x0: x0 + w]
+        interp = rng.randint(0, 5)                      # resize with random interpolation
+        img, boxes = data_aug.resize_with_bbox(img, boxes, img_size[0], img_size[1], interp=interp,
+                                               letterbox=letterbox_resize)
+        img, boxes = data_aug.random_flip(img, boxes, px=0.5, rng=rng)
+    else:
+        img, boxes = resize_with_bbox(img, boxes, img_size[0], img_size[1], interp=1, letterbox=letterbox_resize)
+    # the input of yolo_v3 should be in range 0~1
+    return img_idx, np.asarray(img, np.float32) / 255., np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+
+
+def parse_data(line, class_num, img_size, anchors, mode, letterbox_resize):
+    '''
+    reference utils/data_utils.py:118-176 (same signature and returns; images are RGB from PIL instead of cv2's BGR
+    converted to RGB).
+    param:
+        line: a line from the training/test txt file (or a [line1, line2] pair: the mix up case)
+        class_num: totol class nums.
+        img_size: the size of image to be resized to. [width, height] format.
+        anchors: anchors.
+        mode: 'train' or 'val'. When set to 'train', data_augmentation will be applied.
+        letterbox_resize: whether to use the letterbox resize, i.e., keep the original aspect ratio in the resized image.
+    '''
+    img_idx, img, boxes, labels = parse_sample(line, img_size, _str(mode), letterbox_resize)
+    y_true_13, y_true_26, y_true_52 = process_box(boxes, labels, img_size, class_num, anchors)
+    return img_idx, img, y_true_13, y_true_26, y_true_52
+
+
+def _str(v):
+    return v.decode() if isinstance(v, bytes) else str(v)
+
+
+def mix_up_lines(batch_line, rng=None, prng=None):
+    """The mix-up pairing of get_batch_data (utils/data_utils.py:202-211): each line is paired, with probability 0.5,
+    with another line of the same batch."""
+    import random as _random
+    rng = rng if rng is not None else np.random
+    prng = prng if prng is not None else _random
+    batch_line = list(batch_line)
+    mix_lines = []
+    for idx, line in enumerate(batch_line):
+        others = batch_line[:idx] + batch_line[idx + 1:]
+        if rng.uniform(0, 1) < 0.5 and others:
+            mix_lines.append([line, prng.sample(others, 1)[0]])
+        else:
+            mix_lines.append(line)
+    return mix_lines
+
+
+def multi_scale_size(count, interval=10):
+    """The image size get_batch_data picks for batch number `count` when multi_scale is on
+    (utils/data_utils.py:193-197): random.seed(count // interval); one of 320 .. 608 (range(10, 20) * 32)."""
+    import random as _random
+    sizes = [[x * 32, x * 32] for x in range(10, 20)]
+    return _random.Random(count // interval).sample(sizes, 1)[0]
+
+
+def get_batch_data(batch_line, class_num, img_size, anchors, mode, multi_scale=False, mix_up=False, letterbox_resize=True,
+                   interval=10):
+    '''
+    generate a batch of imgs and labels (reference utils/data_utils.py:179-224: same signature and returns).
+    Target assignment runs on the device for the whole batch and comes back as numpy (the reference's return type); the
+    device-resident form without that round trip is yolov3_tensorflow_amd.feeder.Feeder.
+    '''
+    global iter_cnt
+    mode = _str(mode)
+    if multi_scale and mode == 'train':
+        img_size = multi_scale_size(iter_cnt, interval)
+    iter_cnt += 1
+    batch_line = [l for l in (batch_line.tolist() if hasattr(batch_line, 'tolist') else list(batch_line))]
+    if mix_up and mode == 'train':
+        batch_line = mix_up_lines(batch_line)
+    samples = [parse_sample(line, img_size, mode, letterbox_resize) for line in batch_line]
+    ids, images, boxes, labels, counts = collate(samples)
+    ys = process_box_batch(boxes, labels, counts, img_size, int(class_num), anchors)
+    return (np.asarray(ids, np.int64), images) + tuple(y.cpu().numpy() for y in ys)
+
+
+def collate(samples, out_images=None):
+    """[(img_idx, image, boxes [K,5], labels [K]), ...] -> (ids, images [n,h,w,3], boxes [n,Kmax,5], labels [n,Kmax],
+    counts [n]) padded to the largest box count (the layout y3_process_box takes)."""
+    n = len(samples)
+    kmax = max(1, max(len(s[2]) for s in samples))
+    h, w = samples[0][1].shape[:2]
+    images = out_images if out_images is not None else np.empty((n, h, w, 3), np.float32)
+    boxes = np.zeros((n, kmax, 5), np.float32)
+    labels = np.zeros((n, kmax), np.int64)
+    counts = np.zeros((n,), np.int64)
+    ids = []
+    for i, (idx, img, b, l) in enumerate(samples):
+        images[i] = img
+        # REFERENCE QUIRK kept (SURVEY B.10 "do not fix silently"): the constrained crop of the 'train' chain drops boxes
+        # (bbox_crop filters them) but parse_data never filters `labels`, and process_box labels box i with labels[i] -
+        # so after a crop that removed an earlier box the remaining boxes carry their predecessors' classes
+        # (utils/data_utils.py:150-153,105).  The pairing box i <-> labels[i] over the first len(boxes) entries is that.
+        k = len(b)
+        boxes[i, :k], labels[i, :k], counts[i] = b, l[:k], k
+        ids.append(idx)
+    return ids, images, boxes, labels, counts
