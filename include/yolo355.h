@@ -328,6 +328,54 @@ int y3_loss_layer(y3_ctx* ctx, const float* feature_map, const float* y_true, in
                   int use_focal_loss, int accumulate, float* loss4, float* grad, int grad_stride, void* scratch,
                   size_t scratch_bytes);
 
+/* ---- a14 as ONE call: the train step of train.py:72-115 on the y3_net graph ---------------------------------------
+ * The per-op entry points above, sequenced by the library over a caller-owned workspace (whole-graph entries;
+ * a host in any language trains through these without re-implementing the backward walk):
+ *   y3_net_train_forward   yolov3.forward(inputs, is_training=True) (model.py:30-80): batch-statistics BN in all 72 BN
+ *                          layers, moving statistics updated in place (decay = opts->bn_decay, unbiased variance), the
+ *                          tensors backward needs are kept in the workspace; *fm1..3 = the feature maps (inside it)
+ *   y3_net_train_loss      yolov3.compute_loss(y_pred, y_true) (model.py:348-365): loss5 (device, 5 floats) = [total, xy,
+ *                          wh, conf, class]; d total / d feature_map_i stays in the workspace
+ *   y3_net_train_backward  the gradients of loss[0] w.r.t. every variable whose g_* offset is >= 0, written to
+ *                          flat_grad + offset (train.py:112 compute_gradients; the L2 term, the per-tensor clip and the
+ *                          update are y3_clip_update_multi's).  Gradients do not flow below the first layer that holds a
+ *                          trainable variable (train.py:82 update_vars).  `ready(user, g_end)` is called right after the
+ *                          kernels that complete layer i's gradients have been enqueued (layers are visited last to
+ *                          first): the hook a data-parallel caller hangs its bucketed all-reduce on; may be NULL.
+ *                          Re-runnable from the same forward / loss state.
+ *   y3_net_train_step      forward + loss + backward in one call.
+ * The net's dtype picks the kernels: 0 direct fp32, 4 Winograd forms of the stride-1 3x3 convs (forward, data AND weight
+ * gradient), 2 / 3 products on the bf16 matrix pipe; 1 (bf16 storage) is rejected.  Variables are plain device pointers
+ * in layer order (y3_net_layer_info): HWIO kernel, BN gamma / beta / moving mean / moving variance or the bias.
+ * workspace: y3_net_train_workspace_bytes(net, vars, n, h, w) bytes (it depends on which variables are trainable),
+ * 256-byte aligned, untouched by the caller between forward and backward.  Deterministic (fixed reduction orders). */
+typedef struct y3_train_var {
+    float* weights;
+    float *gamma, *beta, *moving_mean, *moving_variance;   /* BN layers (NULL otherwise) */
+    float* biases;                                         /* detection convs (NULL otherwise) */
+    long long g_weights, g_gamma, g_beta, g_biases;        /* element offsets into flat_grad; < 0: not trainable */
+    long long g_end;                                       /* passed to `ready` once this layer's gradients are enqueued; < 0: no call */
+} y3_train_var;
+typedef struct y3_train_opts {
+    float bn_decay;                    /* model.py:36 batch_norm_decay */
+    int use_label_smooth, use_focal_loss;
+    const float* anchors;              /* HOST pointer: the 9 (w,h) anchor pairs, smallest first (utils/misc_utils.py:31-37) */
+} y3_train_opts;
+typedef void (*y3_grad_ready_fn)(void* user, long long g_end);
+size_t y3_net_train_workspace_bytes(y3_net* net, const y3_train_var* vars, int n, int h, int w);
+int y3_net_train_forward(y3_net* net, const y3_train_var* vars, const float* x, int n, int h, int w,
+                         const y3_train_opts* opts, void* workspace, size_t workspace_bytes, float** fm1, float** fm2,
+                         float** fm3);
+int y3_net_train_loss(y3_net* net, const float* y_true_1, const float* y_true_2, const float* y_true_3,
+                      const y3_train_opts* opts, float* loss5);
+int y3_net_train_backward(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_grad_ready_fn ready, void* user);
+int y3_net_train_step(y3_net* net, const y3_train_var* vars, const float* x, int n, int h, int w, const float* y_true_1,
+                      const float* y_true_2, const float* y_true_3, const y3_train_opts* opts, float* flat_grad,
+                      void* workspace, size_t workspace_bytes, float* loss5, y3_grad_ready_fn ready, void* user);
+/* test hook: byte offsets inside the last forward's workspace of layer i's raw conv output z and of its [4][cout]
+ * mean / inv_std / folded scale / folded shift (the tensors that fix the LeakyReLU branches); SIZE_MAX for non-BN layers */
+int y3_net_train_saved(const y3_net* net, int layer, size_t* z_offset, size_t* stats_offset);
+
 /* ---- next row 8(f)#1: target assignment on the device (utils/data_utils.py:51-115 `process_box`) ------------
  * boxes [n][kmax][5] = (x_min,y_min,x_max,y_max,mix_weight) in resized-image pixels, labels [n][kmax] int32,
  * counts [n] int32 (boxes actually present per image), anchors: 9 (w,h) pairs.  Writes the three y_true

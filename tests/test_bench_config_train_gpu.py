@@ -6,7 +6,8 @@ depend on the batch and the map sizes, so the bench configuration gets its own c
   * bs=64 @416: loss 5-tuple of the Winograd-mode training forward vs the fp64 CPU oracle (forward + loss only), 1e-4
     relative; the direct-kernel training forward ('f32') on the same batch: feature maps 2e-4 + 1e-4*|ref|, loss 1e-4;
   * bs=64 @416: EVERY gradient tensor of the Winograd-mode backward vs the direct-kernel backward, both run from the SAME
-    saved forward state (same z, same BN statistics, hence the same LeakyReLU branches: the comparison is between kernels,
+    saved forward state (y3_net_train_backward re-run with the net in another mode: same z, same BN statistics, hence the
+    same LeakyReLU branches: the comparison is between kernels,
     not between branch patterns — see tests/test_train_gpu.py for why that matters), 2e-4 of the tensor's max magnitude;
     run-to-run bit-exactness of the Winograd-mode backward;
   * bs=8 @416 (the 13/26/52-grid map sizes of the bench): one whole step vs the fp64 autograd oracle evaluated on the
@@ -71,14 +72,12 @@ def test_configs3_bs64_416_loss_and_every_gradient(isolated_graph):
     model.compute_dtype = 'f32_wino'
     trainer = training.Trainer(model, config_optimizer('sgd', 1e-4))
     with y3.variable_scope('yolov3'):
-        fms_w = model.forward(xd, is_training=True)
-        loss_w = [float(v) for v in training.compute_loss(model, fms_w, ytd)]
-        st = model._train
-        saved, fm_grads = st['saved'], [t.clone() for t in st['fm_grads']]
+        fms_w = [f.clone() for f in model.forward(xd, is_training=True)]       # (views of the step's workspace: keep copies)
+        loss_w = [float(v) for v in training.compute_loss(model, model._train['fms'], ytd)]
 
         def backward_with(dtype):
+            # y3_net_train_backward is re-runnable from the forward / loss state; the net's mode only selects the kernels
             model.compute_dtype = dtype
-            st['saved'], st['fm_grads'] = saved, [t.clone() for t in fm_grads]
             trainer.backward()
             torch.cuda.synchronize()
             return trainer.flat.clone()
@@ -113,7 +112,6 @@ def test_configs3_bs64_416_loss_and_every_gradient(isolated_graph):
     with y3.variable_scope('yolov3'):
         fms_d = model.forward(xd, is_training=True)
         loss_d = [float(v) for v in training.compute_loss(model, fms_d, ytd)]
-    model._train['saved'] = None
     for a, b in zip(loss_d, ref_loss):
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, ('f32 loss vs fp64 oracle', loss_d, ref_loss)
     for i, (a, r) in enumerate(zip(fms_d, ref_fms)):

@@ -80,7 +80,7 @@ def test_training_loop_reduces_the_loss_and_validates(tmp_path, capsys, isolated
         '--val_evaluation_epoch', '1000', '--save_epoch', '1000', '--batch_norm_decay', '0.9', '--optimizer_name', 'adam',
         '--learning_rate_init', '1e-3', '--lr_type', 'fixed', '--update_part', 'None', '--multi_scale_train', 'false',
         '--use_warm_up', 'false', '--warm_up_epoch', '0', '--use_label_smooth', 'false', '--use_focal_loss', 'false',
-        '--weight_decay', '0'])
+        '--weight_decay', '0', '--augment', 'false', '--num_threads', '4'])
     assert hist2['loss'][0] < 3.0 * loss[-1] and hist2['global_step_start'] == 201
     assert os.path.getsize(str(tmp_path / 'progress.log')) > 0
 

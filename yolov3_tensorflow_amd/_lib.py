@@ -22,6 +22,20 @@ class ParamDesc(ctypes.Structure):      # y3_param_desc
                 ("weight_decay", c_float), ("reserved", c_int)]
 
 
+class TrainVar(ctypes.Structure):       # y3_train_var
+    _fields_ = [("weights", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p),
+                ("moving_variance", c_void_p), ("biases", c_void_p), ("g_weights", c_longlong), ("g_gamma", c_longlong),
+                ("g_beta", c_longlong), ("g_biases", c_longlong), ("g_end", c_longlong)]
+
+
+class TrainOpts(ctypes.Structure):      # y3_train_opts
+    _fields_ = [("bn_decay", c_float), ("use_label_smooth", c_int), ("use_focal_loss", c_int),
+                ("anchors", POINTER(c_float))]
+
+
+GradReadyFn = ctypes.CFUNCTYPE(None, c_void_p, c_longlong)      # y3_grad_ready_fn
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
 PROTOTYPES = {
     "y3_last_error": (c_char_p, []),
@@ -50,6 +64,14 @@ PROTOTYPES = {
     "y3_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_conv2d_fwd_bf16": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int]),
+    "y3_net_train_workspace_bytes": (c_size_t, [c_void_p, POINTER(TrainVar), c_int, c_int, c_int]),
+    "y3_net_train_forward": (c_int, [c_void_p, POINTER(TrainVar), c_void_p, c_int, c_int, c_int, POINTER(TrainOpts),
+                                     c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "y3_net_train_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(TrainOpts), c_void_p]),
+    "y3_net_train_backward": (c_int, [c_void_p, POINTER(TrainVar), c_void_p, GradReadyFn, c_void_p]),
+    "y3_net_train_step": (c_int, [c_void_p, POINTER(TrainVar), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  POINTER(TrainOpts), c_void_p, c_void_p, c_size_t, c_void_p, GradReadyFn, c_void_p]),
+    "y3_net_train_saved": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "y3_net_set_dtype": (c_int, [c_void_p, c_int]),
     "y3_upsample_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "y3_concat_channels": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_longlong, c_void_p]),

@@ -16,6 +16,7 @@ LIB = os.path.join(CSRC, "libyolo355.so")
 # arithmetic follows the reference's operation order exactly (bit-exact NMS decisions).
 SOURCES = [
     ("y3_abi.hip", []),
+    ("y3_net_train.hip", []),
     ("y3_conv.hip", []),
     ("y3_conv_bf16.hip", []),
     ("y3_conv_bf16x.hip", []),
@@ -57,6 +58,7 @@ def needs_build():
     deps = [os.path.join(CSRC, s) for s, _ in SOURCES] + [
         os.path.join(CSRC, "y3_internal.h"),
         os.path.join(CSRC, "y3_conv_common.h"),
+        os.path.join(CSRC, "y3_net.h"),
         os.path.join(HERE, "..", "include", "yolo355.h"),
         os.path.abspath(__file__),
     ]

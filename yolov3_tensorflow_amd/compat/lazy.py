@@ -12,6 +12,7 @@ class Node(object):
         self.fn, self.args, self.name, self.index, self.empty, self._shape = fn, tuple(args), name, index, empty, shape
         self.dtype = None
         self.host = host          # pure host work (input pipeline): also evaluated in a dry run
+        self.late = False         # an update op (the train op): fetched AFTER every other fetch of the same run
 
     # the arithmetic the driver scripts apply to graph tensors (ref: test_single_image.py:55 `pred_confs * pred_probs`)
     def __mul__(self, other):
@@ -29,6 +30,14 @@ class Node(object):
 
     def __truediv__(self, other):
         return Node(lambda a, b: a / b, (self, other), name='div')
+
+    def __rsub__(self, other):
+        return Node(lambda a, b: b - a, (self, other), name='rsub')
+
+    def __rtruediv__(self, other):
+        return Node(lambda a, b: b / a, (self, other), name='rdiv')
+
+    __div__, __rdiv__ = __truediv__, __rtruediv__
 
     def __getitem__(self, key):
         return Node(lambda a: a[key], (self,), name='getitem')
@@ -49,6 +58,23 @@ class Placeholder(Node):
     def __init__(self, dtype, shape=None, name=None):
         Node.__init__(self, None, (), name=name or 'Placeholder', shape=None if shape is None else list(shape))
         self.dtype = dtype
+
+
+def find(x, pred, _seen=None):
+    """First node reachable from `x` (through node arguments and lists) that satisfies `pred`, or None."""
+    _seen = set() if _seen is None else _seen
+    if isinstance(x, (list, tuple)):
+        for v in x:
+            r = find(v, pred, _seen)
+            if r is not None:
+                return r
+        return None
+    if not isinstance(x, Node) or id(x) in _seen:
+        return None
+    _seen.add(id(x))
+    if pred(x):
+        return x
+    return find(x.args, pred, _seen)
 
 
 def is_node(x):
@@ -108,17 +134,24 @@ def evaluate(fetches, feed_dict=None, dry=False):
         memo[key] = val
         return val
 
-    def out(x):
+    done = {}
+
+    def out(x, late):
         if isinstance(x, (list, tuple)):
-            return [out(v) for v in x]
+            return [out(v, late) for v in x]
         if isinstance(x, Node):
-            if dry and not x.host:
-                return x.empty
-            return _to_numpy(ev(x))
-        if hasattr(x, 'run'):          # an assign op (utils.misc_utils.AssignOp) or a group of them
-            if not dry:
+            if x.late != late:
+                return done.get(id(x))
+            if id(x) not in done:
+                done[id(x)] = x.empty if (dry and not x.host) else _to_numpy(ev(x))
+            return done[id(x)]
+        if hasattr(x, 'run'):          # an assign op (utils.misc_utils.AssignOp), an iterator initializer, a group of them
+            if not late and (not dry or getattr(x, 'host', False)):
                 x.run()
             return None
         raise TypeError("Fetch argument %r cannot be interpreted as a graph tensor or an op" % (x,))
 
-    return out(fetches)
+    # reads first, updates second: what the other fetches of a run see (feature maps, loss, global_step) is the state
+    # BEFORE the train op of the same run changed it - and the train op may reuse the memory they live in
+    out(fetches, False)
+    return out(fetches, True)

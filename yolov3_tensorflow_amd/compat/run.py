@@ -18,6 +18,9 @@ def main(argv=None):
     sys.argv = [script] + argv[1:]
     script_dir = os.path.dirname(os.path.abspath(script))
     sys.path[:] = [p for p in sys.path if os.path.abspath(p or '.') != script_dir or p == '']
+    # ... but its sibling modules that have no shim (the reference's `args.py`, ref: train.py:10) must still resolve:
+    # the directory goes LAST, so that model / utils / tensorflow / cv2 keep resolving to the shims
+    sys.path.append(script_dir)
     code = compile(open(script, 'rb').read(), script, 'exec')
     glob = {'__name__': '__main__', '__file__': script, '__builtins__': __builtins__}
     exec(code, glob)

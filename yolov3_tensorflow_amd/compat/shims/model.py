@@ -12,11 +12,14 @@ from yolov3_tensorflow_amd.compat import lazy as _lazy
 
 class yolov3(_y3.yolov3):
 
+    def __init__(self, *args, **kwargs):
+        _y3.yolov3.__init__(self, *args, **kwargs)
+        import tensorflow as _tf            # (the shim: tf.losses.get_regularization_loss reads the model's weight decay)
+        _tf._REG['weight_decay'] = float(self.weight_decay)
+
     def forward(self, inputs, is_training=False, reuse=False):
         if not _lazy.is_node(inputs):
             return _y3.yolov3.forward(self, inputs, is_training, reuse)
-        if is_training is True:
-            raise NotImplementedError("the compat graph runs inference only; train through train.py of this package")
         scope = _fw.current_scope_name()
         shape = inputs.get_shape()
         if shape is not None and len(shape) == 4 and shape[1] and shape[2]:
@@ -26,11 +29,11 @@ class yolov3(_y3.yolov3):
                 self._get_net(_fw.default_device())            # creates the variables in the reference's order
 
         def run(x, training_flag):
-            if bool(training_flag):        # eval.py feeds its `is_training` placeholder with False (ref: eval.py:66,116)
-                raise NotImplementedError("the compat graph runs inference only (is_training was fed True)")
+            # eval.py feeds its `is_training` placeholder with False (ref: eval.py:66,116), train.py with True for the
+            # training batches and False for validation (ref: train.py:140,184)
             self.img_size = [int(x.shape[1]), int(x.shape[2])]
             with _y3.variable_scope_absolute(scope):
-                return _y3.yolov3.forward(self, x, False, reuse)
+                return _y3.yolov3.forward(self, x, bool(training_flag), reuse)
 
         det = 3 * (5 + self.class_num)
         empties = [_np.zeros((0, 0, 0, det), _np.float32)] * 3
@@ -44,8 +47,10 @@ class yolov3(_y3.yolov3):
             loss = _y3.yolov3.compute_loss(self, list(args[:3]), list(args[3:]))
             return tuple(float(v) for v in loss)
 
-        return list(_lazy.multi(run, tuple(y_pred) + tuple(y_true), 5, 'yolov3/compute_loss',
-                                [_np.float32(0.0)] * 5))
+        outs = list(_lazy.multi(run, tuple(y_pred) + tuple(y_true), 5, 'yolov3/compute_loss', [_np.float32(0.0)] * 5))
+        for o in outs:
+            o.model = self              # (the compat optimizer finds the model to train through the loss tensor)
+        return outs
 
     def predict(self, feature_maps, with_scores=False):
         if not _lazy.is_node(feature_maps):

@@ -175,7 +175,7 @@ __device__ __forceinline__ void epilogue_x(const ConvArgsX& p, unsigned char* sm
 
 template <int BM, int BN, int WM, int WN, int BK, int KS, bool UPCAT>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_bf16x_kernel(const ConvArgsX p) {
-    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int NW = WM * WN;
     constexpr int ROWB = BK * 2, LPR = ROWB / 16, RPI = 64 / LPR;     // row bytes, lanes per row, rows per DMA instruction
     constexpr int ACH = BM / RPI / NW, BCH = BN / RPI / NW;           // DMA instructions per thread and K-step
     constexpr int STAGE = (BM + BN) * ROWB;

@@ -34,7 +34,8 @@ def _worker_sample(job):
     """One sample in a worker (process or thread): job = (line or mix-up pair, [w, h], mode, letterbox, rng key)."""
     from .utils.data_utils import parse_sample
     line, size, mode, letterbox, key = job
-    return parse_sample(line, size, mode, letterbox, rng=np.random.RandomState(key % (2 ** 31)), prng=random.Random(key))
+    return parse_sample(line, size, mode, letterbox, rng=np.random.RandomState(key % (2 ** 31)), prng=random.Random(key),
+                        as_uint8=True)
 
 
 class Batch(object):

@@ -12,7 +12,6 @@ import torch
 
 from . import _lib
 from . import distributed
-from . import engine
 from . import framework as fw
 
 BN_EPS = 1e-5      # model.py:37
@@ -92,126 +91,120 @@ def _scratch(state, key, nbytes, device):
 def _train_state(model):
     st = getattr(model, '_train', None)
     if st is None:
-        st = dict(topo=_Topology(model.class_num), packed={}, consts={})
+        st = dict(topo=_Topology(model.class_num), net=None)
         model._train = st
     return st
 
 
-def _consts(st, c, device):
-    k = (c, str(device))
-    v = st['consts'].get(k)
-    if v is None:
-        v = (torch.ones(c, device=device), torch.zeros(c, device=device))
-        st['consts'][k] = v
-    return v
+# y3_net dtype codes of the compute modes the train step accepts (model.NET_DTYPES without bf16 storage)
+_TRAIN_DTYPES = {'f32': 0, 'f32_bf16x6': 2, 'f32_bf16x3': 3, 'f32_wino': 4}
 
 
-def _planes(model):
-    """3 / 2 when the model computes its convs on the bf16 matrix pipe (compute_dtype 'f32_bf16x6' / 'f32_bf16x3'):
-    the training forward and the stride-1 data gradients then use the split kernels too (weight gradients and the
-    stride-2 data gradients stay on the exact fp32 kernels)."""
-    return engine.SPLIT_PLANES.get(getattr(model, 'compute_dtype', 'f32'), 0)
+def _train_net(model, ctx):
+    """The y3_net handle the train step runs on (one per model; its dtype follows model.compute_dtype at every call: the
+    dtype only selects kernels, the state a forward leaves is the same in every mode)."""
+    st = _train_state(model)
+    L = _lib.lib()
+    if st['net'] is None or st.get('net_ctx') != ctx.value:
+        h = ctypes.c_void_p()
+        _lib.check(L.y3_net_create(ctx, int(model.class_num), ctypes.byref(h)))
+        st['net'], st['net_ctx'] = h, ctx.value
+    mode = getattr(model, 'compute_dtype', 'f32')
+    if mode not in _TRAIN_DTYPES:
+        raise ValueError("training needs compute_dtype in %s (got %r)" % (sorted(_TRAIN_DTYPES), mode))
+    if st.get('net_dtype') != mode:
+        _lib.check(L.y3_net_set_dtype(st['net'], _TRAIN_DTYPES[mode]))
+        st['net_dtype'] = mode
+    return st['net']
 
 
-def _packed_weights(st, wvar, planes=0):
-    """[tap][Cout][Cin] re-pack of the HWIO variable for the forward conv (or its split-plane packing), refreshed
-    when the variable changes."""
-    key = wvar.op_name + ('#%d' % planes if planes else '')
-    hit = st['packed'].get(key)
-    if hit is not None and hit[0] == wvar.version:
-        return hit[1]
-    k, _, cin, cout = wvar.shape
-    if cin == 3:
-        wp = wvar.tensor
-    elif planes:
-        wp = hit[1] if hit is not None else torch.empty(planes * k * k * cout * cin, dtype=torch.bfloat16,
-                                                        device=wvar.tensor.device)
-        _lib.check(_lib.lib().y3_pack_conv_weights_split(fw.context(wvar.tensor.device), fw.ptr(wvar.tensor), k, cin,
-                                                         cout, planes, fw.ptr(wp)))
-    else:
-        wp = hit[1] if hit is not None else torch.empty(k * k * cout * cin, dtype=torch.float32,
-                                                        device=wvar.tensor.device)
-        _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(wvar.tensor.device), fw.ptr(wvar.tensor), k, cin, cout,
-                                                   fw.ptr(wp)))
-    st['packed'][key] = (wvar.version, wp)
-    return wp
+def _var_table(layer_vars, offsets=None, layer_ends=None):
+    """ctypes array of y3_train_var for the 75 layers.  offsets: {op_name: element offset into the flat gradient buffer}
+    for the trainable variables (None: every trainable variable, in gradient_layout's order - used to size the workspace);
+    layer_ends: {layer index: offset just after that layer's gradients} (the `ready` hook's argument)."""
+    if offsets is None:
+        _, offsets, layer_ends, _ = gradient_layout(layer_vars)
+    arr = (_lib.TrainVar * len(layer_vars))()
+    keep = []
+    off = lambda v: int(offsets.get(v.op_name, -1)) if v is not None else -1
+    ptr = lambda v: v.tensor.data_ptr() if v is not None else None
+    for i, (wvar, bnv, bias) in enumerate(layer_vars):
+        g, b, mm, mv = bnv if bnv is not None else (None, None, None, None)
+        arr[i] = _lib.TrainVar(ptr(wvar), ptr(g), ptr(b), ptr(mm), ptr(mv), ptr(bias), off(wvar), off(g), off(b), off(bias),
+                               int((layer_ends or {}).get(i, -1)))
+        keep.append([v.tensor for v in (wvar, g, b, mm, mv, bias) if v is not None])
+    return arr, keep
+
+
+def _opts(model):
+    anc = np.ascontiguousarray(np.asarray(model.anchors, np.float32).reshape(9, 2))
+    o = _lib.TrainOpts(float(model.batch_norm_decay), 1 if model.use_label_smooth else 0, 1 if model.use_focal_loss else 0,
+                       anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return o, anc
 
 
 # --------------------------------------------------------------------------------------------------------
 # forward in training mode
 # --------------------------------------------------------------------------------------------------------
-def forward_train(model, x):
-    """yolov3.forward(inputs, is_training=True): BN normalises with batch statistics in ALL 72 BN layers and
-    updates the moving statistics (decay = model.batch_norm_decay); activations are kept for backward."""
+def _prepare(model, x):
+    """Everything a training forward needs before the library call: the train net in the model's mode, the variables (created
+    on first use, in the reference's order), their table, the workspace (sized for every variable trainable: an upper bound
+    for any update_vars subset), the options."""
     st = _train_state(model)
     topo = st['topo']
     L = _lib.lib()
     dev = x.device
-    ctx = fw.context(dev)
+    net = _train_net(model, fw.context(dev))
     scope = fw.current_scope_name()
     layer_vars = model._ensure_variables(scope, [(l['k'], l['stride'], l['cin'], l['cout'], l['bn'])
                                                  for l in topo.layers])
     n, h, w, _ = x.shape
-    tens = {0: x}
-    saved = []
-    for i, l in enumerate(topo.layers):
-        wvar, bnv, bias = layer_vars[i]
-        xin = tens[l['src']]
-        if l['up'] >= 0:   # training materialises concat([upsample(up), route]) (model.py:61-62,71-72)
-            upt = engine.upsample_nearest(tens[l['up']], xin.shape[1], xin.shape[2])
-            xin = engine.concat_channels(upt, xin)
-        cout = l['cout']
-        ones, zeros = _consts(st, cout, dev)
-        planes = _planes(model) if l['cin'] != 3 else 0
-        wino = (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and
-                engine.wino_eligible(l['k'], l['stride'], int(xin.shape[3]), cout))
-        rec = dict(xin=xin)
-        # exact-fp32 BN layers: the conv also returns the column sums of z and z^2 per row block of its output (taken in
-        # its epilogue), which saves the statistics' own pass over z; the stem and the split-precision kernels keep it
-        desc = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), int(xin.shape[3]), 0, cout, l['k'], l['stride'], 0)
-        nblk = L.y3_conv_stats_blocks(ctypes.byref(desc), 1 if wino else 0) if (l['bn'] and not planes) else 0
-        part = torch.empty((nblk, 2, cout), dtype=torch.float32, device=dev) if nblk else None
-        if wino:        # Winograd forward for the stride-1 3x3 convs
-            key = wvar.op_name + '#wino'
-            hit = st['packed'].get(key)
-            if hit is None or hit[0] != wvar.version:
-                hit = (wvar.version, engine.pack_wino(wvar.tensor))
-                st['packed'][key] = hit
-            z = engine.conv2d_fwd_wino(xin, hit[1], ones, zeros, cout, False, stats=part)
-            wp = None
-        else:
-            wp = _packed_weights(st, wvar, planes)
-        if l['bn']:
-            if not wino:
-                z = engine.conv2d_fwd(xin, wp, ones, zeros, l['k'], l['stride'], cout, False, planes=planes, stats=part)
-            rows = z.numel() // cout
-            stats = torch.empty((4, cout), dtype=torch.float32, device=dev)   # mean, inv_std, scale, shift
-            gamma, beta, mmean, mvar = bnv
-            if part is not None:
-                _lib.check(L.y3_bn_train_stats_partials(
-                    ctx, fw.ptr(part), nblk, rows, cout, fw.ptr(gamma.tensor), fw.ptr(beta.tensor),
-                    ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay), fw.ptr(stats[0]), fw.ptr(stats[1]),
-                    fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(mmean.tensor), fw.ptr(mvar.tensor)))
-            else:
-                sc = _scratch(st, 'reduce', L.y3_reduce_scratch_bytes(cout), dev)
-                _lib.check(L.y3_bn_train_stats(ctx, fw.ptr(z), rows, cout, fw.ptr(gamma.tensor), fw.ptr(beta.tensor),
-                                               ctypes.c_float(BN_EPS), ctypes.c_float(model.batch_norm_decay),
-                                               fw.ptr(stats[0]), fw.ptr(stats[1]), fw.ptr(stats[2]), fw.ptr(stats[3]),
-                                               fw.ptr(mmean.tensor), fw.ptr(mvar.tensor), fw.ptr(sc)))
-            mmean.touch()      # updated in place: the folded inference parameters must be rebuilt
-            mvar.touch()
-            y = torch.empty_like(z)
-            resid = tens[l['resid']] if l['resid'] >= 0 else None
-            _lib.check(L.y3_bn_apply_fwd(ctx, fw.ptr(z), fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(resid), rows,
-                                         cout, 1, fw.ptr(y)))
-            rec.update(z=z, stats=stats)
-        else:              # detection conv: bias, linear (model.py:55-57)
-            y = engine.conv2d_fwd(xin, wp, ones, bias.tensor, l['k'], l['stride'], cout, False, planes=planes)
-        tens[l['dst']] = y
-        saved.append(rec)
-    fms = [tens[t] for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0]
-    fms.sort(key=lambda f: f.shape[1])                          # ext slots 0,1,2 = 13-, 26-, 52-grid
-    st.update(saved=saved, tens=tens, layer_vars=layer_vars, fm_grads=None, batch=n)
+    key = tuple(t.tensor.data_ptr() for lv in layer_vars for t in ((lv[0],) + tuple(lv[1] or ()) + ((lv[2],) if lv[2] is not None else ())))
+    if st.get('vars_key') != key:
+        st['vars_all'], st['vars_keep'] = _var_table(layer_vars)
+        st['vars_key'] = key
+    if st.get('ws_shape') != (n, h, w, str(dev)):
+        need = L.y3_net_train_workspace_bytes(net, st['vars_all'], n, h, w)
+        if need == 0:
+            _lib.check(_lib.Y3_EINVAL)
+        ws = st.get('ws')
+        if ws is None or ws.numel() < need or ws.device != dev:
+            st['ws'] = None              # (free the old one first)
+            st['ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
+        st['ws_shape'] = (n, h, w, str(dev))
+    st.update(layer_vars=layer_vars, batch=n, x=x, have_loss=False)
+    return st, net, layer_vars
+
+
+def _after_forward(model, st, fm_ptrs):
+    """Bookkeeping after a training forward: the moving statistics changed in place; the feature maps are views of the
+    workspace."""
+    for wvar, bnv, bias in st['layer_vars']:
+        if bnv is not None:        # updated in place: the folded inference parameters must be rebuilt
+            bnv[2].touch()
+            bnv[3].touch()
+    ws, x = st['ws'], st['x']
+    n, h, w, _ = x.shape
+    det = 3 * (5 + model.class_num)
+    fms = []
+    for p, s in zip(fm_ptrs, (32, 16, 8)):
+        o = p - ws.data_ptr()
+        fms.append(ws[o:o + n * (h // s) * (w // s) * det * 4].view(torch.float32).view(n, h // s, w // s, det))
+    st.update(fms=fms, fm_ptrs=list(fm_ptrs))
+    return fms
+
+
+def forward_train(model, x):
+    """yolov3.forward(inputs, is_training=True): BN normalises with batch statistics in ALL 72 BN layers and
+    updates the moving statistics (decay = model.batch_norm_decay); activations are kept for backward.
+    ONE library call (y3_net_train_forward); the feature maps are views into the step's workspace."""
+    st, net, layer_vars = _prepare(model, x)
+    n, h, w, _ = x.shape
+    opts, anc = _opts(model)
+    fm = [ctypes.c_void_p() for _ in range(3)]
+    _lib.check(_lib.lib().y3_net_train_forward(net, st['vars_all'], fw.ptr(x), n, h, w, ctypes.byref(opts), fw.ptr(st['ws']),
+                                               ctypes.c_size_t(st['ws'].numel()), *[ctypes.byref(p) for p in fm]))
+    fms = _after_forward(model, st, [p.value for p in fm])
     return fms[0], fms[1], fms[2]
 
 
@@ -253,10 +246,25 @@ def loss_layer(model, feature_map_i, y_true, anchors):
 
 def compute_loss(model, y_pred, y_true):
     """reference model.py:348-365: [total, xy, wh, conf, class] over the three scales (anchors [6:9], [3:6],
-    [0:3]).  Also leaves d(total)/d(feature_map_i) in the model's train state for the backward pass."""
+    [0:3]).  When y_pred are the feature maps of the last forward(is_training=True) this is ONE library call
+    (y3_net_train_loss) that also leaves d(total)/d(feature_map_i) in the step's workspace for the backward pass; any other
+    feature maps (validation: forward(is_training=False)) take the per-scale entry point."""
+    st = _train_state(model)
+    L = _lib.lib()
+    if st.get('fm_ptrs') is not None and [fw.as_device_f32(f).data_ptr() for f in y_pred] == st['fm_ptrs']:
+        dev = st['fms'][0].device
+        yt = [fw.as_device_f32(y) for y in y_true]
+        for f, y in zip(st['fms'], yt):
+            if tuple(y.shape) != tuple(f.shape[:3]) + (3, 6 + int(model.class_num)):
+                raise ValueError("y_true shape %s does not match the feature map %s" % (tuple(y.shape), tuple(f.shape)))
+        opts, anc = _opts(model)
+        loss5 = torch.empty(5, dtype=torch.float32, device=dev)
+        _lib.check(L.y3_net_train_loss(st['net'], fw.ptr(yt[0]), fw.ptr(yt[1]), fw.ptr(yt[2]), ctypes.byref(opts),
+                                       fw.ptr(loss5)))
+        st['have_loss'] = True
+        return [loss5[0], loss5[1], loss5[2], loss5[3], loss5[4]]
     anchors = np.asarray(model.anchors, np.float32).reshape(9, 2)
     groups = [anchors[6:9], anchors[3:6], anchors[0:3]]
-    st = _train_state(model)
     dev = fw.as_device_f32(y_pred[0]).device
     loss4 = torch.zeros(4, dtype=torch.float32, device=dev)
     det_pad = ((3 * (5 + model.class_num) + 31) // 32) * 32
@@ -266,7 +274,7 @@ def compute_loss(model, y_pred, y_true):
         g = torch.zeros(tuple(fm.shape[:3]) + (det_pad,), dtype=torch.float32, device=dev)   # pad lanes stay 0
         _loss_one_scale(model, fm, y_true[i], groups[i], loss4, i > 0, g)
         grads.append(g)
-    st['fm_grads'] = grads
+    st['fm_grads'] = grads       # (test hook: d total / d feature_map_i of this stand-alone evaluation)
     total = loss4.sum()
     return [total, loss4[0], loss4[1], loss4[2], loss4[3]]
 
@@ -349,171 +357,51 @@ class Trainer(object):
         self.exchange = distributed.GradientExchange(self.flat, sorted(ends.values()) or [total], self.pg,
                                                      self.bucket_bytes)
 
-    def backward(self):
-        model = self.model
-        st = _train_state(model)
-        if st.get('fm_grads') is None or st.get('saved') is None:
-            raise RuntimeError('backward needs forward(is_training=True) and compute_loss first')
-        topo, saved, tens, layer_vars = st['topo'], st['saved'], st['tens'], st['layer_vars']
-        L = _lib.lib()
-        dev = tens[0].device
-        ctx = fw.context(dev)
+    def _vars(self, layer_vars, dev):
         self._alloc_grads(layer_vars, dev)
-        n = st['batch']
-        # earliest layer holding a trainable variable: gradients need not flow below it
-        first = None
-        for i, (wvar, bnv, bias) in enumerate(layer_vars):
-            vs = [wvar] + (list(bnv[:2]) if bnv is not None else [bias])
-            if any(self._trainable(v) for v in vs):
-                first = i
-                break
-        if first is None:
-            return
-        self.exchange.begin()
-        cap = self.capture
-        needs = lambda t: t > 0 and (t - 1) >= first         # tensor t is produced by layer t-1
-        grads, have = {}, set()
-        fm_ids = sorted([t for t in range(len(topo.tensors)) if topo.tensors[t]['ext'] >= 0],
-                        key=lambda t: topo.tensors[t]['ext'])
-        for t, g in zip(fm_ids, st['fm_grads']):
-            grads[t] = g
-            have.add(t)
-        # stream-K scratch of the data-gradient convs: the library's size for any 3x3 conv with Cout >= 128
-        sk_desc = _lib.ConvDesc(1, 8, 8, 128, 0, 128, 3, 1, 0)
-        sk_ws = _scratch(st, 'streamk', int(L.y3_conv_workspace_bytes(ctypes.byref(sk_desc))), dev)
+        key = tuple(v.tensor.data_ptr() for v in self.order) + tuple(
+            t.tensor.data_ptr() for lv in layer_vars for t in (lv[1][2:] if lv[1] is not None else ()))
+        if getattr(self, '_vars_key', None) != key:
+            self._vars_arr, self._vars_keep = _var_table(layer_vars, self.offsets, self.layer_ends)
+            self._vars_key = key
+        return self._vars_arr
 
-        def accumulate_into(t, src, src_channels, offset, c):
-            rows = src.numel() // src_channels
-            if t not in have:
-                grads[t] = torch.empty(tuple(tens[t].shape), dtype=torch.float32, device=dev)
-            _lib.check(L.y3_slice_accumulate(ctx, fw.ptr(src), src_channels, offset, rows, c, 1 if t in have else 0,
-                                             fw.ptr(grads[t])))
-            have.add(t)
+    def _ready_cb(self):
+        if getattr(self, '_cb', None) is None:
+            self._cb = _lib.GradReadyFn(lambda user, edge: self.exchange.ready(int(edge)))
+        return self._cb
 
-        for i in range(len(topo.layers) - 1, first - 1, -1):
+    def _fill_capture(self, st):
+        """Test hook: views of the tensors that fix each BN layer's LeakyReLU branch (z and the folded scale / shift)."""
+        L = _lib.lib()
+        topo, ws, n = st['topo'], st['ws'], st['batch']
+        h, w = st['x'].shape[1:3]
+        for i in range(len(topo.layers) - 1, -1, -1):
             l = topo.layers[i]
-            wvar, bnv, bias = layer_vars[i]
-            rec = saved[i]
-            dst = l['dst']
-            if dst not in have:
+            zo, so = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(L.y3_net_train_saved(st['net'], i, ctypes.byref(zo), ctypes.byref(so)))
+            if not l['bn']:
+                self.capture.append(dict(layer=i, z=None, stats=None))
                 continue
-            dy = grads[dst]
+            sd = topo.tensors[l['dst']]['sdiv']
             cout = l['cout']
-            xin = rec['xin']
-            if cap is not None:      # test hook: the tensors that fix this layer's LeakyReLU branch (z, folded scale/shift)
-                cap.append(dict(layer=i, z=rec.get('z'), stats=rec.get('stats')))
-            if l['bn']:
-                rows = dy.numel() // cout
-                dz_out = dy                       # BN backward runs in place ...
-                if l['resid'] >= 0 and needs(l['resid']):
-                    if l['resid'] in have:
-                        accumulate_into(l['resid'], dy, cout, 0, cout)
-                    else:
-                        # ... unless dy is also the first contribution to the shortcut's gradient (res_block: net +
-                        # shortcut, utils/layer_utils.py:30): then dy itself becomes that gradient (no copy) and the
-                        # BN backward writes dz elsewhere
-                        grads[l['resid']] = dy
-                        have.add(l['resid'])
-                        dz_out = torch.empty_like(dy)
-                gamma, beta = bnv[0], bnv[1]
-                stats = rec['stats']
-                tmp = torch.empty((2, cout), dtype=torch.float32, device=dev)
-                dgam = self.views.get(gamma.op_name)
-                dbet = self.views.get(beta.op_name)
-                sc = _scratch(st, 'bnbwd', L.y3_bn_bwd_scratch_bytes(cout), dev)
-                _lib.check(L.y3_bn_train_bwd(ctx, fw.ptr(rec['z']), fw.ptr(dy), fw.ptr(gamma.tensor),
-                                             fw.ptr(stats[2]), fw.ptr(stats[3]), fw.ptr(stats[0]), fw.ptr(stats[1]),
-                                             rows, cout, fw.ptr(dgam if dgam is not None else tmp[0]),
-                                             fw.ptr(dbet if dbet is not None else tmp[1]), fw.ptr(dz_out), fw.ptr(sc)))
-                dz, dz_stride, w_d = dz_out, cout, wvar.tensor
-            else:
-                dz_stride = int(dy.shape[-1])
-                rows = dy.numel() // dz_stride
-                if self._trainable(bias):
-                    tmp = torch.empty(dz_stride, dtype=torch.float32, device=dev)
-                    sc = _scratch(st, 'bias', 1024 * dz_stride * 4, dev)
-                    _lib.check(L.y3_bias_grad(ctx, fw.ptr(dy), rows, dz_stride, fw.ptr(tmp), fw.ptr(sc)))
-                    self.views[bias.op_name].copy_(tmp[:cout])
-                dz = dy
-                # the data gradient reads the kernel as [k*k][cin][dz_stride]: zero-extend its last axis
-                k, _, cin, _ = wvar.shape
-                w_d = torch.empty(k * k * cin * dz_stride, dtype=torch.float32, device=dev)
-                _lib.check(L.y3_pad_channels(ctx, fw.ptr(wvar.tensor), cout, k * k * cin, dz_stride, fw.ptr(w_d)))
-            d = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), int(xin.shape[3]), 0, cout, l['k'],
-                              l['stride'], 0)
-            if self._trainable(wvar):
-                # compute_dtype 'f32_wino': the stride-1 3x3 kernels' gradients in Winograd form too (16/36 of the MFMA work)
-                if (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and
-                        L.y3_conv_wgrad_wino_eligible(ctypes.byref(d)) == 1):
-                    sc = _scratch(st, 'wgrad_wino', L.y3_conv_wgrad_wino_scratch_bytes(ctypes.byref(d)), dev)
-                    _lib.check(L.y3_conv_wgrad_wino(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
-                                                    fw.ptr(self.views[wvar.op_name]), fw.ptr(sc),
-                                                    ctypes.c_size_t(sc.numel())))
-                else:
-                    wsb = L.y3_conv_wgrad_scratch_bytes(ctypes.byref(d))
-                    sc = _scratch(st, 'wgrad', wsb, dev)
-                    _lib.check(L.y3_conv_wgrad(ctx, ctypes.byref(d), fw.ptr(xin), fw.ptr(dz), dz_stride,
-                                               fw.ptr(self.views[wvar.op_name]), fw.ptr(sc),
-                                               ctypes.c_size_t(sc.numel())))
-            if i in self.layer_ends:      # this layer's gradients are complete: reduce every bucket below its edge
-                self.exchange.ready(self.layer_ends[i])
-            src, up = l['src'], l['up']
-            need_src = needs(src)
-            need_up = up >= 0 and needs(up)
-            if not (need_src or need_up):
-                continue
-            cin = int(xin.shape[3])
-            ones, zeros = _consts(st, cin, dev)
-            planes = _planes(model) if (l['stride'] == 1 and cin % 4 == 0 and dz_stride % 32 == 0) else 0
-            # compute_dtype 'f32_wino': the data gradient of a stride-1 3x3 conv is itself a stride-1 3x3 SAME conv
-            # (flipped, channel-swapped kernel), so it runs on the Winograd kernel too
-            wino_d = (getattr(model, 'compute_dtype', 'f32') == 'f32_wino' and up < 0 and
-                      engine.wino_eligible(l['k'], l['stride'], dz_stride, cin))
-            if wino_d:
-                w_dw = _scratch(st, 'wwino_d', 16 * cin * dz_stride * 4, dev)
-                _lib.check(L.y3_pack_conv_weights_wino_dgrad(ctx, fw.ptr(w_d), cin, dz_stride, fw.ptr(w_dw)))
-                gdesc = _lib.ConvDesc(n, int(xin.shape[1]), int(xin.shape[2]), dz_stride, 0, cin, 3, 1, 0)
-                wk_ws = _scratch(st, 'streamk_wino', int(L.y3_conv_wino_workspace_bytes(ctypes.byref(gdesc))), dev)
-            if planes:
-                k = l['k']
-                w_ds = _scratch(st, 'wsplit_d', planes * k * k * cin * dz_stride * 2, dev)
-                _lib.check(L.y3_pack_conv_weights_split_dgrad(ctx, fw.ptr(w_d), k, cin, dz_stride, planes,
-                                                              fw.ptr(w_ds)))
+            z = ws[zo.value:zo.value + n * (h // sd) * (w // sd) * cout * 4].view(torch.float32).view(n, h // sd, w // sd, cout)
+            stats = ws[so.value:so.value + 4 * cout * 4].view(torch.float32).view(4, cout)
+            self.capture.append(dict(layer=i, z=z, stats=stats))
 
-            def dgrad(accumulate, dx):
-                if wino_d:
-                    _lib.check(L.y3_conv2d_dgrad_wino(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_dw),
-                                                      fw.ptr(ones), fw.ptr(zeros), accumulate, fw.ptr(dx),
-                                                      fw.ptr(wk_ws), ctypes.c_size_t(wk_ws.numel())))
-                elif planes:
-                    _lib.check(L.y3_conv2d_dgrad_split(ctx, ctypes.byref(d), planes, fw.ptr(dz), dz_stride,
-                                                       fw.ptr(w_ds), fw.ptr(ones), fw.ptr(zeros), accumulate,
-                                                       fw.ptr(dx), fw.ptr(sk_ws), ctypes.c_size_t(sk_ws.numel())))
-                else:
-                    _lib.check(L.y3_conv2d_dgrad(ctx, ctypes.byref(d), fw.ptr(dz), dz_stride, fw.ptr(w_d),
-                                                 fw.ptr(ones), fw.ptr(zeros), accumulate, fw.ptr(dx), fw.ptr(sk_ws),
-                                                 ctypes.c_size_t(sk_ws.numel())))
-            if up >= 0:
-                dcat = torch.empty(tuple(xin.shape), dtype=torch.float32, device=dev)
-                dgrad(0, dcat)
-                cu = topo.tensors[up]['c']
-                if need_up:
-                    ut = tens[up]
-                    if up not in have:
-                        grads[up] = torch.empty(tuple(ut.shape), dtype=torch.float32, device=dev)
-                    _lib.check(L.y3_upsample2x_bwd(ctx, fw.ptr(dcat), cin, n, int(ut.shape[1]), int(ut.shape[2]), cu,
-                                                   1 if up in have else 0, fw.ptr(grads[up])))
-                    have.add(up)
-                if need_src:
-                    accumulate_into(src, dcat, cin, cu, cin - cu)
-            else:
-                if src not in have:
-                    grads[src] = torch.empty(tuple(tens[src].shape), dtype=torch.float32, device=dev)
-                dgrad(1 if src in have else 0, grads[src])
-                have.add(src)
-            grads.pop(dst, None)      # free the consumed gradient
-        st['saved'] = None
-        st['fm_grads'] = None
+    def backward(self):
+        """train.py:112 compute_gradients: ONE library call (y3_net_train_backward) walks the graph backwards and writes every
+        trainable variable's gradient into the flat buffer; the `ready` hook issues the gradient buckets as they complete."""
+        st = _train_state(self.model)
+        if not st.get('have_loss') or st.get('fms') is None:
+            raise RuntimeError('backward needs forward(is_training=True) and compute_loss first')
+        dev = st['fms'][0].device
+        net = _train_net(self.model, fw.context(dev))         # (the mode may have changed since the forward)
+        arr = self._vars(st['layer_vars'], dev)
+        self.exchange.begin()
+        _lib.check(_lib.lib().y3_net_train_backward(net, arr, fw.ptr(self.flat), self._ready_cb(), None))
+        if self.capture is not None:
+            self._fill_capture(st)
 
     def _param_descs(self):
         """Host array of y3_param_desc for self.order (rebuilt when a variable's storage or a slot changed)."""
@@ -574,9 +462,30 @@ class Trainer(object):
         self.global_step += 1.0
 
     def step(self, images, y_true):
-        """One training step on a batch; returns [total, xy, wh, conf, class] (device scalars)."""
-        fms = self.model.forward(images, is_training=True)
-        loss = compute_loss(self.model, fms, y_true)
-        self.backward()
+        """One training step on a batch; returns [total, xy, wh, conf, class] (device scalars):
+        forward(is_training=True) -> compute_loss -> backward in ONE library call (y3_net_train_step), then the
+        all-reduce join, L2, clip and update (y3_clip_update_multi)."""
+        x = fw.as_device_f32(images)
+        self.model.img_size = [int(x.shape[1]), int(x.shape[2])]
+        st, net, layer_vars = _prepare(self.model, x)
+        n, h, w, _ = x.shape
+        yt = [fw.as_device_f32(y) for y in y_true]
+        for y, s in zip(yt, (32, 16, 8)):
+            if tuple(y.shape) != (n, h // s, w // s, 3, 6 + int(self.model.class_num)):
+                raise ValueError("y_true shape %s does not match the input size" % (tuple(y.shape),))
+        arr = self._vars(layer_vars, x.device)
+        opts, anc = _opts(self.model)
+        loss5 = torch.empty(5, dtype=torch.float32, device=x.device)
+        self.exchange.begin()
+        _lib.check(_lib.lib().y3_net_train_step(net, arr, fw.ptr(x), n, h, w, fw.ptr(yt[0]), fw.ptr(yt[1]), fw.ptr(yt[2]),
+                                                ctypes.byref(opts), fw.ptr(self.flat), fw.ptr(st['ws']),
+                                                ctypes.c_size_t(st['ws'].numel()), fw.ptr(loss5), self._ready_cb(), None))
+        st.update(have_loss=True, fms=None, fm_ptrs=None)
+        for wvar, bnv, bias in layer_vars:
+            if bnv is not None:
+                bnv[2].touch()
+                bnv[3].touch()
+        if self.capture is not None:
+            self._fill_capture(st)
         self.apply_gradients()
-        return loss
+        return [loss5[0], loss5[1], loss5[2], loss5[3], loss5[4]]

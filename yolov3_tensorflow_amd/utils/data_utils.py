@@ -207,7 +207,7 @@ def _read_rgb(pic_path):
     return np.asarray(Image.open(pic_path).convert('RGB'))
 
 
-def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None):
+def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False):
     """The image half of the reference's parse_data (utils/data_utils.py:118-172): read (PIL, RGB), mix-up when `line` is
     a pair, the 'train' augmentation chain (colour distortion, expansion, constrained crop, resize with a random
     interpolation, horizontal flip) or the plain 'val' resize.  Returns (img_idx, float32 RGB image in [0,1] of shape
@@ -240,8 +240,10 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None):
         img, boxes = data_aug.random_flip(img, boxes, px=0.5, rng=rng)
     else:
         img, boxes = resize_with_bbox(img, boxes, img_size[0], img_size[1], interp=1, letterbox=letterbox_resize)
-    # the input of yolo_v3 should be in range 0~1
-    return img_idx, np.asarray(img, np.float32) / 255., np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+    # the input of yolo_v3 should be in range 0~1 (as_uint8: the caller divides - the feeder's workers hand the 8-bit
+    # image to the parent, a quarter of the bytes to pickle, and the parent divides straight into its pinned buffer)
+    img = np.ascontiguousarray(img, np.uint8) if as_uint8 else np.asarray(img, np.float32) / 255.
+    return img_idx, img, np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
 
 
 def parse_data(line, class_num, img_size, anchors, mode, letterbox_resize):
@@ -323,7 +325,10 @@ def collate(samples, out_images=None):
     counts = np.zeros((n,), np.int64)
     ids = []
     for i, (idx, img, b, l) in enumerate(samples):
-        images[i] = img
+        if img.dtype == np.uint8:        # img.astype(float32) / 255. of parse_data, written in place (no temporaries)
+            np.true_divide(img, np.float32(255.), out=images[i], dtype=np.float32)
+        else:
+            images[i] = img
         # REFERENCE QUIRK kept (SURVEY B.10 "do not fix silently"): the constrained crop of the 'train' chain drops boxes
         # (bbox_crop filters them) but parse_data never filters `labels`, and process_box labels box i with labels[i] -
         # so after a crop that removed an earlier box the remaining boxes carry their predecessors' classes

@@ -11,6 +11,31 @@ import math
 import numpy as np
 
 
+def make_summary(name, val):
+    """reference utils/misc_utils.py:10-11 builds a TensorBoard Summary proto; without TensorFlow the (tag, value) pair is
+    what there is to record (the compat layer's FileWriter keeps them, train.py of this package logs them)."""
+    return (name, float(val))
+
+
+def shuffle_and_overwrite(file_name):
+    """reference utils/misc_utils.py:48-53."""
+    import random
+    content = open(file_name, 'r').readlines()
+    random.shuffle(content)
+    with open(file_name, 'w') as f:
+        for line in content:
+            f.write(line)
+
+
+def update_dict(ori_dict, new_dict):
+    """reference utils/misc_utils.py:56-61."""
+    if not ori_dict:
+        return new_dict
+    for key in ori_dict:
+        ori_dict[key] += new_dict[key]
+    return ori_dict
+
+
 class AverageMeter(object):
     """Running mean with the attribute names the training/eval loops read (utils/misc_utils.py:14-28)."""
 
