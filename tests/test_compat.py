@@ -86,6 +86,86 @@ def test_reference_eval_script_runs_unchanged_in_dry_run(tmp_path):
     assert 'final mAP: 0.0000' in out and 'total_loss: 0.000' in out
 
 
+def _train_dir(root, train_count=7, val_count=2):
+    """The working directory the reference's args.py expects (ref: args.py:10-17): ./data/my_data/{train,val}.txt,
+    ./data/yolo_anchors.txt, ./data/coco.names."""
+    import shutil
+    os.makedirs(os.path.join(root, 'data', 'my_data'))
+    for f in ('yolo_anchors.txt', 'coco.names'):
+        shutil.copy(os.path.join(ROOT, 'data', f), os.path.join(root, 'data', f))
+    ann = _tiny_eval_set(root, count=train_count, seed=3)
+    lines = open(ann).read().splitlines()
+    with open(os.path.join(root, 'data', 'my_data', 'train.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    with open(os.path.join(root, 'data', 'my_data', 'val.txt'), 'w') as f:
+        f.write('\n'.join(lines[:val_count]) + '\n')
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='the reference checkout is not on this machine')
+def test_reference_train_script_runs_unchanged_in_dry_run(tmp_path):
+    """The reference's train.py AND args.py, byte-unchanged, for their full 100 epochs on a 7-image set without a device:
+    the re-initialisable iterator over the train / val pipelines (the feeder really reads, mixes up, augments and resizes
+    at the multi-scale sizes), the loss / regulariser / summary graph, the warm-up tf.cond around the piecewise
+    schedule, compute_gradients -> clip_by_norm -> apply_gradients, the 49 validation passes with the mAP report and the
+    checkpoint calls."""
+    _train_dir(str(tmp_path))
+    rc, out = _run(os.path.join(REF, 'train.py'), [], str(tmp_path), {'Y3_COMPAT_DRY_RUN': '1'})
+    assert rc == 0, out[-3000:]
+    assert 'start to train' in out
+    assert out.count('EVAL: Recall:') == 48            # epochs 4, 6, ..., 98 (ref: train.py:174, args.py:25,68)
+    log = open(tmp_path / 'data' / 'progress.log').read()
+    assert log.count('======> Epoch:') == 48
+
+
+def test_tf1_style_training_twin_in_dry_run(tmp_path):
+    _train_dir(str(tmp_path))
+    out_npz = str(tmp_path / 'steps.npz')
+    rc, out = _run(os.path.join(HERE, 'compat_scripts', 'tf1_train.py'),
+                   ['--train_file', str(tmp_path / 'data' / 'my_data' / 'train.txt'), '--restore_path', 'none.weights',
+                    '--anchor_path', ANCHORS_TXT, '--out', out_npz], str(tmp_path), {'Y3_COMPAT_DRY_RUN': '1'})
+    assert rc == 0, out[-3000:]
+    d = np.load(out_npz)
+    assert d['loss'].shape == (6, 5) and d['lr'].shape == (6,)
+    # (no train op runs without a device: the step stays 0 and the warm-up branch of the tf.cond yields 0)
+    assert (d['step'] == 0).all() and (d['lr'] == 0).all()
+
+
+def test_training_graph_symbols():
+    """tf.Variable / tf.less / tf.cond / the Node-aware learning-rate schedule / reads-before-updates in one run."""
+    from yolov3_tensorflow_amd import compat
+    compat.install()
+    import tensorflow as tf
+    from utils.misc_utils import config_learning_rate
+    from yolov3_tensorflow_amd.compat import lazy
+
+    class A(object):
+        lr_type, learning_rate_init, pw_boundaries, pw_values = 'piecewise', 1e-2, [5.0], [1e-2, 1e-3]
+    step = tf.Variable(0.0, trainable=False, collections=[tf.GraphKeys.LOCAL_VARIABLES])
+    rate = tf.cond(tf.less(step, 4), lambda: A.learning_rate_init * step / 4, lambda: config_learning_rate(A, step - 4))
+    seen = []
+
+    def bump(r):
+        seen.append(float(r))
+        step.assign_add(1)
+    op = lazy.Node(bump, (rate,), name='train_op')
+    op.late = True
+    got = []
+    with tf.Session() as sess:
+        for _ in range(12):
+            _, s, r = sess.run([op, step, rate])          # the op is listed first and still runs last
+            got.append((float(s), float(r)))
+    assert [g[0] for g in got] == [float(i) for i in range(12)]
+    want = [1e-2 * i / 4 for i in range(4)] + [1e-2] * 6 + [1e-3] * 2        # piecewise: step - 4 <= 5 -> first value
+    assert np.allclose([g[1] for g in got], want) and np.allclose(seen, want)
+    with pytest.raises(ValueError):
+        A.lr_type = 'nope'
+        config_learning_rate(A, step)
+    with pytest.raises(NotImplementedError):
+        tf.data.TextLineDataset(__file__).map(lambda x: x).batch(2)           # wrong order: refused, not mis-run
+    assert tf.get_collection(tf.GraphKeys.UPDATE_OPS) == []
+    assert -np.Inf == -np.inf                              # NumPy-1 spelling the reference's train.py uses
+
+
 def test_tf_data_pipeline_and_py_func(tmp_path):
     from yolov3_tensorflow_amd import compat
     from yolov3_tensorflow_amd.compat import lazy
@@ -240,3 +320,63 @@ def test_tf1_style_eval_matches_the_native_eval_script(tmp_path):
     assert per_class, native[-2000:]
     assert abs(got['loss'][0] - total) <= 1e-3 * max(total, 1.0) + 6e-4, (got, total)      # the report prints 3 decimals
     assert got['detections'] > 0
+
+
+@pytest.mark.gpu
+def test_tf1_style_training_twin_matches_the_native_trainer(tmp_path):
+    """Six training steps through the compat training graph (tf.data feeder -> forward(is_training) -> loss ->
+    compute_gradients / clip_by_norm / apply_gradients with a warm-up tf.cond) against the same six steps through
+    yolov3_tensorflow_amd.training.Trainer on the same batches and weights: same losses, same learning rates, same
+    updated variables and moving statistics (the two run the same library calls: tolerance = atomics' ordering)."""
+    import torch
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils import misc_utils, data_utils
+    from oracle import yolo_ref
+    params = yolo_ref.synthetic_params(80, seed=1)
+    weights = str(tmp_path / 'synthetic.weights')
+    yolo_ref.write_darknet(params, weights)
+    _train_dir(str(tmp_path), train_count=8)
+    train_file = str(tmp_path / 'data' / 'my_data' / 'train.txt')
+    out_npz = str(tmp_path / 'steps.npz')
+    rc, out = _run(os.path.join(HERE, 'compat_scripts', 'tf1_train.py'),
+                   ['--train_file', train_file, '--restore_path', weights, '--anchor_path', ANCHORS_TXT, '--out', out_npz],
+                   str(tmp_path))
+    assert rc == 0, out[-3000:]
+    got = np.load(out_npz)
+    assert list(got['step']) == [0., 1., 2., 3., 4., 5.]
+    want_lr = [0.0, 5e-4, 1e-3, 1e-3, 1e-3, 1e-3]          # warm-up over 2 steps, then piecewise (boundary at 4 + 2)
+    assert np.allclose(got['lr'], want_lr)
+    assert list(got['boxes_shape']) == [4, 3 * (8 * 8 + 16 * 16 + 32 * 32), 4]
+
+    # the native replay
+    y3.reset_default_graph()
+    anchors = misc_utils.parse_anchors(ANCHORS_TXT)
+    model = y3.yolov3(80, anchors, True, True, 0.9, 5e-4, use_static_shape=False)
+    with y3.variable_scope('yolov3'):
+        model.forward(torch.zeros(1, 32, 32, 3))
+    misc_utils.run_ops(misc_utils.load_weights(y3.global_variables(scope='yolov3'), weights))
+    upd = [v for v in y3.global_variables(scope='yolov3') if v.op_name.startswith('yolov3/yolov3_head/')]
+    opt = training.Optimizer('momentum', 0.0, momentum=0.9)
+    trainer = training.Trainer(model, opt, update_vars=upd, clip_norm=100.)
+    lines = open(train_file).read().splitlines()
+    batches = [lines[0:4], lines[4:8]]
+    losses = []
+    for i in range(6):
+        _, img, y13, y26, y52 = data_utils.get_batch_data(np.asarray(batches[i % 2], dtype=object), 80, [256, 256], anchors,
+                                                          'val', False, False, False)
+        opt.learning_rate = want_lr[i]
+        with y3.variable_scope('yolov3'):
+            losses.append([float(v) for v in trainer.step(img, [y13, y26, y52])])
+    np.testing.assert_allclose(got['loss'], np.array(losses), rtol=2e-5, atol=1e-6)
+    by_name = dict((v.op_name, v) for v in y3.global_variables(scope='yolov3'))
+    for key in got.files:
+        if not key.startswith('yolov3.'):
+            continue
+        mine = by_name[key.replace('.', '/')].tensor.cpu().numpy()
+        np.testing.assert_allclose(got[key], mine, rtol=2e-5, atol=1e-6, err_msg=key)
+    # the body was not in update_part: its kernel still equals the checkpoint's, its moving statistics moved
+    assert np.array_equal(got['yolov3.darknet53_body.Conv.weights'], params['yolov3/darknet53_body/Conv/weights'])
+    assert not np.allclose(got['yolov3.darknet53_body.Conv.BatchNorm.moving_variance'],
+                           params['yolov3/darknet53_body/Conv/BatchNorm/moving_variance'])
+    assert got['reg'][0] > 0 and np.isfinite(got['val_loss']).all()

@@ -36,6 +36,11 @@ def install():
         if SHIM_DIR in sys.path:
             sys.path.remove(SHIM_DIR)
         sys.path.insert(0, SHIM_DIR)
+    # NumPy-1 spellings the TF-1 era scripts use and NumPy 2 removed (ref: train.py:130 `-np.Inf`)
+    import numpy
+    for old, new in (('Inf', 'inf'), ('NaN', 'nan'), ('float_', 'float64')):
+        if old not in numpy.__dict__:
+            setattr(numpy, old, getattr(numpy, new))
     return SHIM_DIR
 
 

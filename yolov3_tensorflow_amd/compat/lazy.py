@@ -145,6 +145,10 @@ def evaluate(fetches, feed_dict=None, dry=False):
             if id(x) not in done:
                 done[id(x)] = x.empty if (dry and not x.host) else _to_numpy(ev(x))
             return done[id(x)]
+        if hasattr(x, 'op_name') and hasattr(x, 'tensor'):       # a model variable: its current value
+            if id(x) not in done:
+                done[id(x)] = None if dry else _to_numpy(x.tensor)
+            return done[id(x)]
         if hasattr(x, 'run'):          # an assign op (utils.misc_utils.AssignOp), an iterator initializer, a group of them
             if not late and (not dry or getattr(x, 'host', False)):
                 x.run()

@@ -6,11 +6,9 @@ import sys
 from . import install
 
 
-def main(argv=None):
-    argv = list(sys.argv[1:] if argv is None else argv)
-    if not argv:
-        sys.stderr.write(__doc__ + "\n")
-        return 2
+def run_script(argv):
+    """Execute `argv[0]` as __main__ with the shims installed and sys.argv = argv; returns the script's globals (what a
+    harness inspects afterwards: the reference's scripts keep their results in module-level names)."""
     script = argv[0]
     install()
     # the script's own directory must NOT shadow the shims (the reference keeps its model.py / utils/ next to its
@@ -24,6 +22,15 @@ def main(argv=None):
     code = compile(open(script, 'rb').read(), script, 'exec')
     glob = {'__name__': '__main__', '__file__': script, '__builtins__': __builtins__}
     exec(code, glob)
+    return glob
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        sys.stderr.write(__doc__ + "\n")
+        return 2
+    run_script(argv)
     return 0
 
 

@@ -62,6 +62,7 @@ class Session(object):
 
     def __init__(self, target='', graph=None, config=None):
         self._closed = False
+        self.graph = graph           # (only handed to tf.summary.FileWriter, ref: train.py:126)
 
     def __enter__(self):
         return self
