@@ -643,7 +643,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
         barrier()
         elapsed = time.perf_counter() - t0
         fw.check_context()      # a stream-K hand-off that timed out inside the timed region would raise here
-        layer_ms, table, main_ms, is_sk = model.read_layer_ms(with_main=True, shape=(BATCH, SIZE, SIZE))
+        layer_ms, table = model.read_layer_ms()
+        is_sk = model.layer_is_streamk(BATCH, SIZE, SIZE)
         model.set_layer_profiling(False)
         # p50 of single-step latency (separate short loop; each step synchronised)
         lat = []

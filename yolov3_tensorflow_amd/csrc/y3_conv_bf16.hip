@@ -14,8 +14,10 @@
 //   * epilogue in fp32 (scale/shift, LeakyReLU, residual), ONE rounding to bf16 (round-to-nearest-even) at the
 //     store; the detection convs (linear, 3*(5+C) channels) write fp32 so that decode/NMS are unchanged.
 // Data-parallel schedule with XCD-contiguous tile ids (no stream-K: the kernel is not matrix-pipe bound).
+#include <cstdlib>
 #include <type_traits>
 #include "y3_internal.h"
+#include "y3_conv_stem.h"
 
 namespace {
 
@@ -339,22 +341,26 @@ __global__ void __launch_bounds__(256) conv_stem_bf16_kernel(const float* __rest
             }
         }
     }
-    float acc[COUT];
+    // the layer is bound by these 27 x COUT multiply-adds per pixel: packed (two channels per v_pk_fma_f32)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t acc2[COUT / 2];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    for (int c = 0; c < COUT / 2; ++c) acc2[c] = f32x2_t{0.f, 0.f};
 #pragma unroll 3
     for (int t = 0; t < 27; ++t) {
         const float xv = xs[t * 256 + threadIdx.x];
+        const f32x2_t x2 = {xv, xv};
         const float* wr = ws + t * COUT;
 #pragma unroll
         for (int c = 0; c < COUT; c += 4) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            acc[c + 0] = fmaf(xv, wv[0], acc[c + 0]);
-            acc[c + 1] = fmaf(xv, wv[1], acc[c + 1]);
-            acc[c + 2] = fmaf(xv, wv[2], acc[c + 2]);
-            acc[c + 3] = fmaf(xv, wv[3], acc[c + 3]);
+            acc2[c / 2] = __builtin_elementwise_fma(x2, f32x2_t{wv[0], wv[1]}, acc2[c / 2]);
+            acc2[c / 2 + 1] = __builtin_elementwise_fma(x2, f32x2_t{wv[2], wv[3]}, acc2[c / 2 + 1]);
         }
     }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = acc2[c / 2][c & 1];
     unsigned pk[COUT / 2];
 #pragma unroll
     for (int c = 0; c < COUT; c += 2) {
@@ -430,6 +436,10 @@ int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && !x_up && !residual && !out_f32,
                      "y3_conv2d_fwd_bf16: Cin=3 is supported only as the 3x3 3->32 stem conv (fp32 image in)");
+        static const bool mfma_stem = getenv("Y3_STEM_MFMA") != nullptr;    // A/B hook (tools/layer_profile.py)
+        if (mfma_stem)                                                        // the matrix-pipe form (y3_conv_stem.h)
+            return y3stem::launch_stem<true>(stream, static_cast<const float*>(x), static_cast<const float*>(w), scale, shift,
+                                             y, d->n, d->h, d->w, d->act);
         hipLaunchKernelGGL(conv_stem_bf16_kernel, dim3((int)((M + 255) / 256)), dim3(256), 0, stream,
                            static_cast<const float*>(x), static_cast<const float*>(w), scale, shift,
                            static_cast<bf16_t*>(y), d->n, d->h, d->w, (int)M, d->act);

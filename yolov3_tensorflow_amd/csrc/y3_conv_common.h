@@ -367,22 +367,26 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
             }
         }
     }
-    float acc[COUT];
+    // the layer is bound by these 27 x COUT multiply-adds per pixel: packed (two channels per v_pk_fma_f32)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t acc2[COUT / 2];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+    for (int c = 0; c < COUT / 2; ++c) acc2[c] = f32x2_t{0.f, 0.f};
 #pragma unroll 3
     for (int t = 0; t < 27; ++t) {
-        const float x = xs[t * 256 + threadIdx.x];
+        const float xv = xs[t * 256 + threadIdx.x];
+        const f32x2_t x2 = {xv, xv};
         const float* wr = ws + t * COUT;
 #pragma unroll
         for (int c = 0; c < COUT; c += 4) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            acc[c + 0] = fmaf(x, wv[0], acc[c + 0]);
-            acc[c + 1] = fmaf(x, wv[1], acc[c + 1]);
-            acc[c + 2] = fmaf(x, wv[2], acc[c + 2]);
-            acc[c + 3] = fmaf(x, wv[3], acc[c + 3]);
+            acc2[c / 2] = __builtin_elementwise_fma(x2, f32x2_t{wv[0], wv[1]}, acc2[c / 2]);
+            acc2[c / 2 + 1] = __builtin_elementwise_fma(x2, f32x2_t{wv[2], wv[3]}, acc2[c / 2 + 1]);
         }
     }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = acc2[c / 2][c & 1];
     // Store through the LDS: a thread owns one pixel = COUT contiguous floats, so direct stores would touch 64 cache
     // lines per wave instruction; staged, each store instruction writes 1 KB contiguous.
     static_assert(COUT == 32, "staging layout below assumes 32 output channels");

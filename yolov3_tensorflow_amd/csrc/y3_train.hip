@@ -279,12 +279,19 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x
 // tf.nn.sigmoid_cross_entropy_with_logits: max(x,0) - x*z + log(1 + exp(-|x|))
 __device__ __forceinline__ float bce_(float z, float x) { return fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x))); }
 
-// One WAVE per (cell, anchor) record: the 5+C logits and 6+C targets of a record are contiguous, so lanes
-// read/write them coalesced (lane f handles fields f, f+64, ...); the ignore-mask IoU loop runs with one
-// ground-truth box per lane and a wave max-reduction.
+// A wave owns 64 consecutive (cell, anchor) records of one image.
+//   phase 1, one LANE per record: box decode, ignore mask (best IoU over the image's ground-truth boxes of this scale, read
+//            as LDS broadcasts), xy / wh / conf terms and their five gradients, parked in the LDS;
+//   phase 2, lanes over the 64 x (5+C) contiguous logits of the chunk: the class terms - only where the record holds an
+//            object (object_mask is 0 for all but a few records, whose class logits and targets are then never read) -
+//            and ALL the chunk's gradients written out contiguously.
+// (The form this replaces ran one wave per record with the box / conf arithmetic on lane 0 alone: 0.84 ms for the
+// 52-grid of a bs=64 batch, 530 MB; profiles/r02_train_c4_kernel_stats.csv.)
 __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
     extern __shared__ float gts[];                         // [V][4] of this image
     __shared__ float red[4][4];
+    __shared__ float rec_g[4][64][5];                      // per wave: the five box / conf gradients of its records
+    __shared__ float rec_m[4][64], rec_w[4][64];           // object_mask, mix-up weight
     const int n = blockIdx.y;
     const int cells = a.gh * a.gw * 3;
     const int F = 5 + a.C, T = 6 + a.C;
@@ -292,46 +299,50 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
     for (int i = threadIdx.x; i < V * 4; i += 256) gts[i] = a.gt_boxes[(size_t)n * a.cap * 4 + i];
     __syncthreads();
     const float invN = 1.f / (float)a.N;
+    const float invF = 1.f / (float)F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float l_xy = 0.f, l_wh = 0.f, l_conf = 0.f, l_cls = 0.f;   // lane-partial sums
-    for (int i = blockIdx.x * 4 + wave; i < cells; i += gridDim.x * 4) {
-        const int anc = i % 3;
-        const int cell = i / 3;
-        const int gy = cell / a.gw, gx = cell - gy * a.gw;
-        const float* f = a.fm + ((size_t)n * cells + i) * F;
-        const float* yt = a.y_true + ((size_t)n * cells + i) * T;
-        float* g = a.grad + ((size_t)n * (cells / 3) + cell) * a.grad_stride + anc * F;
-        // every lane decodes the box (same addresses: broadcast loads) — reorg_layer (model.py:96-126)
-        const float sx = sigmoid_(f[0]), sy = sigmoid_(f[1]);
-        const float ex = expf(f[2]), ey = expf(f[3]);
-        const float px = (sx + (float)gx) * a.ratio_w, py = (sy + (float)gy) * a.ratio_h;
-        const float pw = (ex * a.ra_w[anc]) * a.ratio_w, ph = (ey * a.ra_h[anc]) * a.ratio_h;
-        // ignore mask (model.py:220-237): best IoU with this image's GT boxes of THIS scale < 0.5
-        float best = -INFINITY;
-        for (int v = lane; v < V; v += 64) {
-            const float tx = gts[4 * v], ty = gts[4 * v + 1], tw = gts[4 * v + 2], th = gts[4 * v + 3];
-            const float iw = fmaxf(fminf(px + pw / 2.f, tx + tw / 2.f) - fmaxf(px - pw / 2.f, tx - tw / 2.f), 0.f);
-            const float ih = fmaxf(fminf(py + ph / 2.f, ty + th / 2.f) - fmaxf(py - ph / 2.f, ty - th / 2.f), 0.f);
-            const float inter = iw * ih;
-            best = fmaxf(best, inter / (pw * ph + tw * th - inter + 1e-10f));
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
-        const float ignore = best < 0.5f ? 1.f : 0.f;
-        const float m = yt[4];                       // object_mask
-        const float mixw = yt[T - 1];
-        if (lane == 0) {
-            const float bls = 2.f - (yt[2] / a.img_w) * (yt[3] / a.img_h);
+    for (int i0 = (blockIdx.x * 4 + wave) * 64; i0 < cells; i0 += gridDim.x * 256) {
+        // ---- phase 1 ------------------------------------------------------------------------------------------
+        const int i = i0 + lane;
+        const bool valid = i < cells;
+        float m = 0.f, mixw = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+        if (valid) {
+            const int anc = i % 3;
+            const int cell = i / 3;
+            const int gy = cell / a.gw, gx = cell - gy * a.gw;
+            const float* f = a.fm + ((size_t)n * cells + i) * F;
+            const float* yt = a.y_true + ((size_t)n * cells + i) * T;
+            const float f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3], xc = f[4];
+            const float y0 = yt[0], y1 = yt[1], y2 = yt[2], y3 = yt[3];
+            m = yt[4];                                   // object_mask
+            mixw = yt[T - 1];
+            // reorg_layer (model.py:96-126)
+            const float sx = sigmoid_(f0), sy = sigmoid_(f1);
+            const float ex = expf(f2), ey = expf(f3);
+            const float px = (sx + (float)gx) * a.ratio_w, py = (sy + (float)gy) * a.ratio_h;
+            const float pw = (ex * a.ra_w[anc]) * a.ratio_w, ph = (ey * a.ra_h[anc]) * a.ratio_h;
+            // ignore mask (model.py:220-237): best IoU with this image's GT boxes of THIS scale < 0.5
+            float best = -INFINITY;
+            for (int v = 0; v < V; ++v) {
+                const float tx = gts[4 * v], ty = gts[4 * v + 1], tw = gts[4 * v + 2], th = gts[4 * v + 3];
+                const float iw = fmaxf(fminf(px + pw / 2.f, tx + tw / 2.f) - fmaxf(px - pw / 2.f, tx - tw / 2.f), 0.f);
+                const float ih = fmaxf(fminf(py + ph / 2.f, ty + th / 2.f) - fmaxf(py - ph / 2.f, ty - th / 2.f), 0.f);
+                const float inter = iw * ih;
+                best = fmaxf(best, inter / (pw * ph + tw * th - inter + 1e-10f));
+            }
+            const float ignore = best < 0.5f ? 1.f : 0.f;
+            const float bls = 2.f - (y2 / a.img_w) * (y3 / a.img_h);
             const float wgt = m * bls * mixw;
             // xy (model.py:248-249,276)
-            const float txy0 = yt[0] / a.ratio_w - (float)gx, txy1 = yt[1] / a.ratio_h - (float)gy;
+            const float txy0 = y0 / a.ratio_w - (float)gx, txy1 = y1 / a.ratio_h - (float)gy;
             const float pxy0 = px / a.ratio_w - (float)gx, pxy1 = py / a.ratio_h - (float)gy;
             const float d0 = txy0 - pxy0, d1 = txy1 - pxy1;
             l_xy += (d0 * d0 + d1 * d1) * wgt;
-            g[0] = -2.f * d0 * wgt * sx * (1.f - sx) * invN;
-            g[1] = -2.f * d1 * wgt * sy * (1.f - sy) * invN;
+            g0 = -2.f * d0 * wgt * sx * (1.f - sx) * invN;
+            g1 = -2.f * d1 * wgt * sy * (1.f - sy) * invN;
             // wh (model.py:254-262,277)
-            float tt0 = yt[2] / a.anc_w[anc], tt1 = yt[3] / a.anc_h[anc];
+            float tt0 = y2 / a.anc_w[anc], tt1 = y3 / a.anc_h[anc];
             float pt0 = pw / a.anc_w[anc], pt1 = ph / a.anc_h[anc];
             tt0 = tt0 == 0.f ? 1.f : tt0; tt1 = tt1 == 0.f ? 1.f : tt1;
             const bool pz0 = pt0 == 0.f, pz1 = pt1 == 0.f;
@@ -340,10 +351,9 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
             const float e0 = logf(fminf(fmaxf(tt0, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt0, 1e-9f), 1e9f));
             const float e1 = logf(fminf(fmaxf(tt1, 1e-9f), 1e9f)) - logf(fminf(fmaxf(pt1, 1e-9f), 1e9f));
             l_wh += (e0 * e0 + e1 * e1) * wgt;
-            g[2] = in0 ? -2.f * e0 * wgt * invN : 0.f;   // d log(exp(t)*const)/dt = 1 inside the clip range
-            g[3] = in1 ? -2.f * e1 * wgt * invN : 0.f;
+            g2 = in0 ? -2.f * e0 * wgt * invN : 0.f;     // d log(exp(t)*const)/dt = 1 inside the clip range
+            g3 = in1 ? -2.f * e1 * wgt * invN : 0.f;
             // conf (model.py:280-292)
-            const float xc = f[4];
             const float pc = sigmoid_(xc);
             const float cmask = m + (1.f - m) * ignore;
             const float b = bce_(m, xc);
@@ -356,17 +366,45 @@ __global__ void __launch_bounds__(256) loss_kernel(const LossArgs a) {
                 lc *= fo;
             }
             l_conf += lc * mixw;
-            g[4] = gc * mixw * invN;
+            g4 = gc * mixw * invN;
         }
-        // class (model.py:296-302): lanes over the classes
+        rec_g[wave][lane][0] = g0; rec_g[wave][lane][1] = g1; rec_g[wave][lane][2] = g2;
+        rec_g[wave][lane][3] = g3; rec_g[wave][lane][4] = g4;
+        rec_m[wave][lane] = m; rec_w[wave][lane] = mixw;
+        // (a wave reads back only what it wrote itself: no workgroup barrier, the LDS counter wait orders it)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- phase 2 ------------------------------------------------------------------------------------------
+        const int nrec = min(64, cells - i0);
+        const float* fchunk = a.fm + ((size_t)n * cells + i0) * F;
+        const float* ychunk = a.y_true + ((size_t)n * cells + i0) * T;
         const float delta = 0.01f;
-        for (int c = lane; c < a.C; c += 64) {
-            float tgt = yt[5 + c];
-            if (a.label_smooth) tgt = (1.f - delta) * tgt + delta * 1.f / (float)a.C;
-            const float x = f[5 + c];
-            l_cls += m * bce_(tgt, x) * mixw;
-            g[5 + c] = m * mixw * (sigmoid_(x) - tgt) * invN;
+        for (int e = lane; e < nrec * F; e += 64) {
+            const int r = (int)(((float)e + 0.5f) * invF);       // e / F (e < 64 * F: the product is exact enough)
+            const int field = e - r * F;
+            const int rec = i0 + r;
+            const int cell = rec / 3, anc = rec - cell * 3;
+            float gv;
+            if (field < 5) {
+                gv = rec_g[wave][r][field];
+            } else {
+                // class (model.py:296-302)
+                const float mr = rec_m[wave][r];
+                gv = 0.f;
+                if (mr != 0.f) {
+                    const float wr = rec_w[wave][r];
+                    float tgt = ychunk[(size_t)r * T + field];
+                    if (a.label_smooth) tgt = (1.f - delta) * tgt + delta * 1.f / (float)a.C;
+                    const float x = fchunk[e];
+                    l_cls += mr * bce_(tgt, x) * wr;
+                    gv = mr * wr * (sigmoid_(x) - tgt) * invN;
+                }
+            }
+            a.grad[((size_t)n * (cells / 3) + cell) * a.grad_stride + anc * F + field] = gv;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // the next chunk overwrites the wave's LDS rows
     }
     // wave reduction, then the four waves, in a fixed order
     float vals[4] = {l_xy, l_wh, l_conf, l_cls};

@@ -175,22 +175,20 @@ class yolov3(object):
         ent = self._get_net(device if device is not None else fw.default_device())
         _lib.check(_lib.lib().y3_net_set_profiling(ent['handle'], 1 if enabled else 0))
 
-    def read_layer_ms(self, device=None, with_main=False, shape=None):
+    def read_layer_ms(self, device=None):
         """Per-layer ms averaged over the forwards recorded since the last read (synchronises), plus the
-        layer table [(k, stride, cin, cout, has_bn)].  with_main=True also returns the same per-layer times once
-        more (every layer is ONE kernel; kept for callers written when a stream-K layer had a fix-up launch) and the
-        stream-K flags; needs shape=(n, h, w)."""
+        layer table [(k, stride, cin, cout, has_bn)].  Every layer is ONE kernel launch."""
         ent = self._get_net(device if device is not None else fw.default_device())
         nl = len(ent['table'])
-        L = _lib.lib()
         buf = (ctypes.c_float * nl)()
-        _lib.check(L.y3_net_get_layer_ms(ent['handle'], buf, nl))
-        ms = np.array(buf[:], dtype=np.float64)
-        if not with_main:
-            return ms, ent['table']
-        n, h, w = shape
-        sk = np.array([L.y3_net_layer_is_streamk(ent['handle'], i, n, h, w) for i in range(nl)], bool)
-        return ms, ent['table'], ms.copy(), sk
+        _lib.check(_lib.lib().y3_net_get_layer_ms(ent['handle'], buf, nl))
+        return np.array(buf[:], dtype=np.float64), ent['table']
+
+    def layer_is_streamk(self, n, h, w, device=None):
+        """Per layer: does the launch plan run it on the persistent stream-K schedule at this input shape."""
+        ent = self._get_net(device if device is not None else fw.default_device())
+        L = _lib.lib()
+        return np.array([L.y3_net_layer_is_streamk(ent['handle'], i, n, h, w) for i in range(len(ent['table']))], bool)
 
     def layer_times_ms(self, inputs, iters=5):
         """Per-layer hipEvent timing of the fused plan (for profiles/ and DESIGN.md tables)."""
