@@ -443,7 +443,8 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
     """yolov3.detect() on the c2 batch (416x416, bs=32): y3_net_forward -> y3_decode (+ fused conf*prob) -> y3_nms for all
     images, everything resident on the device.  Two reference parameter sets: test_single_image.py:55 (max_boxes 200,
     score 0.3, IoU 0.45) and eval.py:47-54 (400, 0.01, 0.45); two score regimes: 'detector' = the random head with the
-    objectness biases shifted by -4.6 (a 1 % objectness prior, so candidates are sparse as for a trained detector) and
+    objectness biases shifted by -4.6 and the class biases by -3 (a 1 % objectness and a 5 % class prior, so the candidates
+    above either score threshold are sparse, as for a trained detector) and
     'dense' = the unshifted random head (conf ~ prob ~ 0.5: nearly every one of the 10,647 x 80 scores passes 0.01 - the
     worst case of the greedy per-class NMS)."""
     from yolov3_tensorflow_amd import framework as fw
@@ -463,6 +464,7 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
                 for v in heads:
                     t = v.tensor.clone().view(3, 5 + CLASS_NUM)
                     t[:, 4] -= 4.6
+                    t[:, 5:] -= 3.0
                     v.assign(t.view(-1))
             try:
                 for name, max_boxes, score_t, iou_t in params:
@@ -698,10 +700,11 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                                                 'f32_bf16x6': PEAK_BF16_MFMA_TFLOPS / 6,
                                                 'f32_bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
     bound_ms = np.maximum(nbytes / (PEAK_HBM_TBPS * 1e12), issued / (peak * 1e12)) * 1e3      # per layer
-    traffic, traffic_src = (None, None) if (bf16 or split) else traffic_from_profile(
+    traffic, traffic_src = (None, None) if split else traffic_from_profile(
+        ['r03_pmc_traffic_bf16.json'] if bf16 else
         ['r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
-    kernel = ("conv_mfma_bf16_kernel<128,128,2,2,3,false> (3x3 implicit-GEMM conv, bf16 storage; staging-bound, see "
-              "DESIGN.md)" if bf16 else
+    kernel = ("conv_bf16x_kernel / conv_bf16p_kernel (3x3 implicit-GEMM convs with Cout > 64 on LDS-DMA staged 128x128 / "
+              "256x128 / 256x256 tiles, bf16 storage; see DESIGN.md)" if bf16 else
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else

@@ -12,7 +12,8 @@ import json
 import sys
 from collections import OrderedDict, defaultdict
 
-CONV = ('conv_wino', 'conv_mfma_f32_kernel', 'conv_stem_kernel')
+CONV = ('conv_wino', 'conv_mfma_f32_kernel', 'conv_stem_kernel', 'conv_mfma_bf16_kernel', 'conv_bf16x_kernel',
+        'conv_bf16p_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel')
 
 
 def load(path):

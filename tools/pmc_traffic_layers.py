@@ -27,7 +27,7 @@ def main():
     rows = []
     for i, l in enumerate(d['layers']):
         rows.append(dict(layer=i, kernel=l['kernel'], read_bytes=int(l[R] * 32 * fr), write_bytes=int(l[W] * 32 * fw)))
-    sel = [r for r in rows if needle in r['kernel']]
+    sel = [r for r in rows if any(n in r['kernel'] for n in needle.split(','))]       # (a comma-separated list of substrings)
     assert sel, sorted(set(r['kernel'] for r in rows))
     rd = float(np.mean([r['read_bytes'] for r in sel]))
     wr = float(np.mean([r['write_bytes'] for r in sel]))
@@ -41,7 +41,7 @@ def main():
         "counters": [R, W],
         "calibration": {"copy_bytes": 1 << 30, "read_counter_x32": int(cal[R] * 32), "write_counter_x32": int(cal[W] * 32),
                         "read_factor": round(fr, 5), "write_factor": round(fw, 5)},
-        "note": "fabric-side (L2 miss) traffic of one forward at bs=32 416x416 (tools/pmc_layers.py), mean over the "
+        "note": "fabric-side (L2 miss) traffic of one forward at the bench configuration (tools/pmc_layers.py), mean over the "
                 "launches of the kernel; Infinity-Cache hits are included, so this bounds HBM bytes from above.",
         "per_layer": rows,
     }

@@ -59,7 +59,6 @@ def needs_build():
         os.path.join(CSRC, "y3_internal.h"),
         os.path.join(CSRC, "y3_conv_common.h"),
         os.path.join(CSRC, "y3_net.h"),
-        os.path.join(CSRC, "y3_conv_stem.h"),
         os.path.join(HERE, "..", "include", "yolo355.h"),
         os.path.abspath(__file__),
     ]

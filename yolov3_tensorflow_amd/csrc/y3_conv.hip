@@ -27,7 +27,6 @@
 //     combined in a fixed order by a second small kernel, so results are deterministic.
 #include <cstdlib>
 #include "y3_conv_common.h"
-#include "y3_conv_stem.h"
 
 namespace {
 using namespace y3conv;
@@ -419,9 +418,6 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && !x_up && !residual,
                      "y3_conv2d_fwd: Cin=3 is supported only as the 3x3 3->32 stem conv");
-        static const bool mfma_stem = getenv("Y3_STEM_MFMA") != nullptr;    // A/B hook (tools/layer_profile.py)
-        if (d->stride == 1 && mfma_stem)                                      // the matrix-pipe form (y3_conv_stem.h)
-            return y3stem::launch_stem<false>(stream, a.x, a.w, a.scale, a.shift, a.y, a.N, a.H, a.W, a.act);
         auto stem = conv_stem_kernel<32>;
         hipLaunchKernelGGL(stem, dim3((a.M + 255) / 256), dim3(256), 0, stream, a);
         Y3_CHECK_HIP(hipGetLastError());

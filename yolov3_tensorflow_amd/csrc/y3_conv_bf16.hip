@@ -17,7 +17,6 @@
 #include <cstdlib>
 #include <type_traits>
 #include "y3_internal.h"
-#include "y3_conv_stem.h"
 
 namespace {
 
@@ -314,10 +313,8 @@ __global__ void __launch_bounds__(256) conv_stem_bf16_kernel(const float* __rest
                                                              const float* __restrict__ shift, bf16_t* __restrict__ y,
                                                              int N, int H, int W, int M, int act) {
     constexpr int COUT = 32;
-    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
     __shared__ float ssc[COUT], ssh[COUT];
     __shared__ __attribute__((aligned(16))) float xs[27 * 256];      // [tap*3+ci][thread]; later the output staging
-    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = w[i];
     for (int i = threadIdx.x; i < COUT; i += 256) { ssc[i] = scale[i]; ssh[i] = shift[i]; }
     __syncthreads();
     const int m_raw = blockIdx.x * 256 + threadIdx.x;
@@ -350,13 +347,12 @@ __global__ void __launch_bounds__(256) conv_stem_bf16_kernel(const float* __rest
     for (int t = 0; t < 27; ++t) {
         const float xv = xs[t * 256 + threadIdx.x];
         const f32x2_t x2 = {xv, xv};
-        const float* wr = ws + t * COUT;
+        // the tap's 32 weights: wave-uniform addresses -> scalar loads, the FMAs take them as SGPR operands (read as
+        // broadcasts from the LDS they cost one 16-byte LDS read per two packed FMAs and bound the kernel)
+        const float* wr = w + t * COUT;
 #pragma unroll
-        for (int c = 0; c < COUT; c += 4) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            acc2[c / 2] = __builtin_elementwise_fma(x2, f32x2_t{wv[0], wv[1]}, acc2[c / 2]);
-            acc2[c / 2 + 1] = __builtin_elementwise_fma(x2, f32x2_t{wv[2], wv[3]}, acc2[c / 2 + 1]);
-        }
+        for (int c = 0; c < COUT; c += 2)
+            acc2[c / 2] = __builtin_elementwise_fma(x2, f32x2_t{wr[c], wr[c + 1]}, acc2[c / 2]);
     }
     float acc[COUT];
 #pragma unroll
@@ -436,10 +432,6 @@ int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && !x_up && !residual && !out_f32,
                      "y3_conv2d_fwd_bf16: Cin=3 is supported only as the 3x3 3->32 stem conv (fp32 image in)");
-        static const bool mfma_stem = getenv("Y3_STEM_MFMA") != nullptr;    // A/B hook (tools/layer_profile.py)
-        if (mfma_stem)                                                        // the matrix-pipe form (y3_conv_stem.h)
-            return y3stem::launch_stem<true>(stream, static_cast<const float*>(x), static_cast<const float*>(w), scale, shift,
-                                             y, d->n, d->h, d->w, d->act);
         hipLaunchKernelGGL(conv_stem_bf16_kernel, dim3((int)((M + 255) / 256)), dim3(256), 0, stream,
                            static_cast<const float*>(x), static_cast<const float*>(w), scale, shift,
                            static_cast<bf16_t*>(y), d->n, d->h, d->w, (int)M, d->act);

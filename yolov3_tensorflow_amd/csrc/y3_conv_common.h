@@ -329,15 +329,17 @@ __device__ __forceinline__ void sk_consume(const ConvArgs& p, const SkWorker& w,
 }
 
 // ---- stem conv: 3x3, Cin = 3 -> COUT (=32), stride 1 ------------------------------------------------
-// K = 27 is too short for the implicit-GEMM tile and the layer is HBM-write bound (709 MB out per
-// bs=32 batch vs 9.6 GFLOP): one thread per output pixel, weights HWIO [27][COUT] broadcast from LDS.
+// K = 27 is too short for the implicit-GEMM tile and the layer is HBM-write bound (709 MB out per bs=32 batch vs
+// 9.6 GFLOP): one thread per output pixel.  Its 27 x COUT multiply-adds per pixel are packed (v_pk_fma_f32, two
+// channels each) and take the weights as SGPR operands - a tap's 32 weights are wave-uniform scalar loads of the HWIO
+// kernel [27][COUT].  (Round-3 measurements, profiles/r03_stem.txt: plain FMAs with the weights broadcast from the LDS
+// 0.222 ms; packed FMAs alone 0.222 - the 216 16-byte LDS reads per pixel were the second bound; scalar weights 0.197;
+// the same conv as 14 v_mfma_f32_32x32x2_f32 per 32 pixels with per-lane 4-byte patch loads 0.30-0.31.)
 template <int COUT>
 __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) float ws[27 * COUT];
     __shared__ float ssc[COUT], ssh[COUT];
     __shared__ __attribute__((aligned(16))) float xs[4 * 64 * (COUT + 4)];   // inputs [tap*3+ci][thread] (27*256
                                                                               // floats), later the output staging
-    for (int i = threadIdx.x; i < 27 * COUT; i += 256) ws[i] = p.w[i];
     for (int i = threadIdx.x; i < COUT; i += 256) {
         ssc[i] = p.scale[i];
         ssh[i] = p.shift[i];
@@ -376,13 +378,12 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(const ConvArgs p) {
     for (int t = 0; t < 27; ++t) {
         const float xv = xs[t * 256 + threadIdx.x];
         const f32x2_t x2 = {xv, xv};
-        const float* wr = ws + t * COUT;
+        // the tap's 32 weights: wave-uniform addresses -> scalar loads, the FMAs take them as SGPR operands (read as
+        // broadcasts from the LDS they cost one 16-byte LDS read per two packed FMAs and bound the kernel)
+        const float* wr = p.w + t * COUT;
 #pragma unroll
-        for (int c = 0; c < COUT; c += 4) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            acc2[c / 2] = __builtin_elementwise_fma(x2, f32x2_t{wv[0], wv[1]}, acc2[c / 2]);
-            acc2[c / 2 + 1] = __builtin_elementwise_fma(x2, f32x2_t{wv[2], wv[3]}, acc2[c / 2 + 1]);
-        }
+        for (int c = 0; c < COUT; c += 2)
+            acc2[c / 2] = __builtin_elementwise_fma(x2, f32x2_t{wr[c], wr[c + 1]}, acc2[c / 2]);
     }
     float acc[COUT];
 #pragma unroll
