@@ -57,6 +57,9 @@ ANCHORS = np.array([10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 15
                    np.float32).reshape(9, 2)
 
 
+SECONDARY_BUDGET_S = 420      # wall-clock allowance for the detect / c5 / c4 secondaries of the default line (measured: ~70 s at N = 1)
+
+
 def random_init(seed):
     """Random weights of the reference architecture with tame activations: He-normal kernels, BN close to
     identity, residual-branch gamma damped (so 23 residual adds do not blow the scale up)."""
@@ -406,6 +409,19 @@ def main(argv=None):
         # configs[4] (608x608 bf16 bs=16), c4 = configs[3] (train step, bs=64 per GPU, RCCL all-reduce when N > 1).
         # Every rank runs them (c4 has a collective); a failure costs only that object.
         import copy
+        import threading
+        # Watchdog: the secondaries run collectives at N > 1 (barriers, the c4 gradient all-reduce); should one of them
+        # ever stall (a rank that failed alone leaves the others waiting), the primary line must still come out: after
+        # SECONDARY_BUDGET_S rank 0 prints what it has and every rank leaves with status 0.
+        def give_up():
+            if rank == 0 and out is not None:
+                for name in ('detect', 'c5', 'c4'):
+                    out.setdefault(name, {"error": "not finished within %d s (watchdog)" % SECONDARY_BUDGET_S})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(SECONDARY_BUDGET_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for name, fn in (('detect', run_detect), ('c5', run_forward), ('c4', run_train)):
             sub = copy.copy(args)
             sub.workload = name if name != 'detect' else 'c2'
@@ -419,6 +435,7 @@ def main(argv=None):
                 res = {"error": "%s: %s" % (type(e).__name__, e)}
             if rank == 0 and out is not None:
                 out[name] = slim(res)
+        watchdog.cancel()
         set_workload(args.workload, args.batch)
     if rank == 0:
         print(json.dumps(out), flush=True)
