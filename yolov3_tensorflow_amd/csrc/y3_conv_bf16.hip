@@ -412,6 +412,13 @@ template <int KS, bool UPCAT>
 int dispatch_b(hipStream_t stream, const ConvArgsB& a) {
     if (a.Cout <= 32) return launch_b<128, 32, 4, 1, KS, UPCAT>(stream, a);
     if (a.Cout <= 64) return launch_b<128, 64, 4, 1, KS, UPCAT>(stream, a);
+    if (KS == 1) {
+        // 1x1 convs whose 128x128 tiles would not fill two rounds of the 256 CUs (the 19-grid layers and the two route
+        // convs at bs=16, 608x608: 184 / 46 tiles): 64x64 tiles, three workgroups per CU - 26.5 -> 21.9 us and 18.9 ->
+        // 12.0 us per launch; from 512 tiles up the wide tile wins again (measured, tools/layer_profile.py)
+        const long long tiles = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+        if (tiles < 512) return launch_b<64, 64, 2, 2, KS, UPCAT>(stream, a);
+    }
     return launch_b<128, 128, 2, 2, KS, UPCAT>(stream, a);
 }
 
