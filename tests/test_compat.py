@@ -323,7 +323,7 @@ def test_tf1_style_eval_matches_the_native_eval_script(tmp_path):
 
 
 @pytest.mark.gpu
-def test_tf1_style_training_twin_matches_the_native_trainer(tmp_path):
+def test_tf1_style_training_twin_matches_the_native_trainer(tmp_path, isolated_graph):
     """Six training steps through the compat training graph (tf.data feeder -> forward(is_training) -> loss ->
     compute_gradients / clip_by_norm / apply_gradients with a warm-up tf.cond) against the same six steps through
     yolov3_tensorflow_amd.training.Trainer on the same batches and weights: same losses, same learning rates, same
