@@ -126,3 +126,27 @@ def test_feeder_plan_is_deterministic_sharded_and_paired(tmp_path):
     assert all(s[0] % 32 == 0 and 320 <= s[0] <= 608 for s in sizes)
     v = Feeder(lines, 4, 3, [64, 64], anchors, mode='val')._plan(0)
     assert [l for _, _, ls in v for l in ls] == lines             # validation: file order, no pairing, fixed size
+
+
+def test_worker_pool_is_shared_started_from_a_forkserver_and_reproducible(tmp_path):
+    """The decode / augment workers come from ONE forkserver pool per worker count (a fork of the training process copies
+    its pinned pages: 93 s for four workers at 8 GB pinned, tools/feeder_diag.py); what they return equals the in-process
+    call with the same random key."""
+    from yolov3_tensorflow_amd import feeder
+    lines = _write_set(tmp_path)
+    pool = feeder._shared_process_pool(3)
+    assert feeder._shared_process_pool(3) is pool
+    assert pool._mp_context.get_start_method() == 'forkserver'
+    jobs = [(line, [96, 64], 'train', True, 1000 + j) for j, line in enumerate(lines)] + \
+           [([lines[0], lines[1]], [96, 64], 'train', False, 77)]
+    got = [f.result(timeout=120) for f in [pool.submit(feeder._worker_sample, job) for job in jobs]]
+    for job, g in zip(jobs, got):
+        want = feeder._worker_sample(job)
+        assert g[0] == want[0] and g[1].dtype == np.uint8
+        for a, b in zip(g[1:], want[1:]):
+            np.testing.assert_array_equal(a, b)
+    f1 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), num_threads=3)
+    f2 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), mode='val', num_threads=3)
+    assert f1._executor() is pool and f2._executor() is pool
+    f1.close()
+    assert feeder._shared_process_pool(3) is pool          # closing a feeder leaves the shared workers alone

@@ -6,9 +6,14 @@
 rebuilt for one process per GPU with the device-resident target assignment of this package:
 
   * `num_threads` workers (reference: args.num_threads = 10) decode, augment and resize ONE image each
-    (utils.data_utils.parse_sample).  They are forked PROCESSES by default: the numpy restatements of the OpenCV
+    (utils.data_utils.parse_sample).  They are worker PROCESSES by default: the numpy restatements of the OpenCV
     resizes and of the colour jitter hold the GIL for much of their time, and 16 threads measured 274 images/s where the
-    train step wants 530 (tests/test_feeder_gpu.py); the children never touch the device.  A coordinator thread assembles
+    train step wants 530 (tests/test_feeder_gpu.py); the children never touch the device.  The workers come from a
+    `forkserver` (one pool per process and worker count, shared by the training and the validation feeder): forking the
+    training process itself copies every PINNED host page eagerly - measured 93 s for four workers once 8 GB were
+    pinned, against 0.4 s in a fresh process (tools/feeder_diag.py) - and the feeder is what pins them.  (As with any
+    multiprocessing start method but fork, a SCRIPT that builds a Feeder needs the usual `if __name__ == '__main__':`
+    guard: the workers import the main module.)  A coordinator thread assembles
     whole batches in PINNED host buffers and copies them to the device on a SIDE stream; a bounded queue of `prefetch` batches
     (reference: prefetech_buffer = 5) decouples it from the train step, so decode / resize / H2D of batch i+1.. overlap the
     step on batch i;
@@ -36,6 +41,32 @@ def _worker_sample(job):
     line, size, mode, letterbox, key = job
     return parse_sample(line, size, mode, letterbox, rng=np.random.RandomState(key % (2 ** 31)), prng=random.Random(key),
                         as_uint8=True)
+
+
+_POOLS = {}
+_POOLS_LOCK = threading.Lock()
+
+
+def _shared_process_pool(workers):
+    import atexit
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    with _POOLS_LOCK:
+        pool = _POOLS.get(workers)
+        if pool is None:
+            ctx = multiprocessing.get_context('forkserver')
+            ctx.set_forkserver_preload(['yolov3_tensorflow_amd.utils.data_utils', 'yolov3_tensorflow_amd.utils.data_aug'])
+            pool = _POOLS[workers] = ProcessPoolExecutor(workers, mp_context=ctx)
+            if len(_POOLS) == 1:
+                atexit.register(_shutdown_pools)
+        return pool
+
+
+def _shutdown_pools():
+    with _POOLS_LOCK:
+        for pool in _POOLS.values():
+            pool.shutdown(wait=False, cancel_futures=True)
+        _POOLS.clear()
 
 
 class Batch(object):
@@ -66,18 +97,16 @@ class Feeder(object):
         self._pool = None
 
     def _executor(self):
-        """The worker pool, created on first use and kept across epochs (forking 16 processes per epoch is not free)."""
-        if self._pool is None:
-            if self.backend == 'process':
-                import multiprocessing
-                from concurrent.futures import ProcessPoolExecutor
-                self._pool = ProcessPoolExecutor(self.num_threads, mp_context=multiprocessing.get_context('fork'))
-            else:
+        """The worker pool: one per process and worker count, created on first use and shared by every Feeder (see the
+        module docstring for why the workers are not forked from this process)."""
+        if self.backend == 'thread':
+            if self._pool is None:
                 self._pool = ThreadPoolExecutor(self.num_threads)
-        return self._pool
+            return self._pool
+        return _shared_process_pool(self.num_threads)
 
     def close(self):
-        if self._pool is not None:
+        if self._pool is not None:          # (only thread pools are owned by the feeder)
             self._pool.shutdown(wait=False, cancel_futures=True)
             self._pool = None
 
@@ -128,7 +157,7 @@ class Feeder(object):
         stop = threading.Event()
         copy_stream = torch.cuda.Stream(device=dev)
 
-        pool = self._executor()          # (created here, on the caller's thread: forking from a helper thread is fragile)
+        pool = self._executor()
 
         def produce():
             try:
