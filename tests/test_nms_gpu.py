@@ -54,7 +54,7 @@ def test_cpu_nms_reference_goldens(golden):
 
 @pytest.mark.parametrize('max_boxes,score_thresh,iou_thresh', [
     (200, 0.3, 0.45),    # test_single_image.py:57
-    (400, 0.01, 0.45),   # eval.py:47-54 (thousands of candidates per class: the > KCAP global path)
+    (400, 0.01, 0.45),   # eval.py:47-54 (~10,000 candidates per class: the register-resident kernel, K > KCAP)
     (150, 0.9, 0.45),    # sparse candidates: the LDS path
     (50, 0.5, 0.5),      # the function defaults
 ])
@@ -74,6 +74,30 @@ def test_full_size_matches_c_oracle(mode, max_boxes, score_thresh, iou_thresh):
     np.testing.assert_array_equal(gi[0, :k].cpu().numpy(), oi)      # bit-exact index selection
     np.testing.assert_array_equal(gl[0, :k].cpu().numpy(), ol)
     np.testing.assert_array_equal(gb[0, :k].cpu().numpy(), ob)
+    np.testing.assert_array_equal(gs[0, :k].cpu().numpy(), osc)
+
+
+@pytest.mark.parametrize('mode', ['tf', 'py'])
+def test_more_candidates_than_the_register_kernel_holds(mode):
+    """Three tiers of candidate storage per (image, class): LDS (K <= 1,536), registers of a twelve-wave workgroup
+    (K <= 10,752), global memory beyond (a 608x608 image has 22,743 boxes).  One call with all three: class 0 keeps every
+    one of 12,000 boxes, class 1 about 4,000, class 2 about 120 - bit-exact against the C oracle."""
+    from yolov3_tensorflow_amd.utils import nms_utils
+    from yolov3_tensorflow_amd import _lib
+    from oracle import nms_ref
+    boxes, scores = stress_inputs(seed=7, B=12000, C=3)
+    scores[:, 0] = 0.5 + 0.5 * scores[:, 0]            # all above the threshold
+    scores[:, 2] *= 0.25                                # ~1 % above it
+    ob, osc, ol, oi = nms_ref.c_per_class(mode, boxes, scores, 3, 300, 0.2, 0.45)
+    counts = [(scores[:, c] >= 0.2).sum() for c in range(3)]
+    assert counts[0] > 10752 >= counts[1] > 1536 >= counts[2] > 0, counts
+    m = _lib.Y3_NMS_TF if mode == 'tf' else _lib.Y3_NMS_PY
+    gb, gs, gl, gi, cnt = nms_utils._run_nms(m, torch.from_numpy(boxes).cuda()[None], torch.from_numpy(scores).cuda()[None],
+                                             3, 300, 0.2, 0.45)
+    k = int(cnt[0])
+    assert k == len(ob), 'selected %d, oracle %d' % (k, len(ob))
+    np.testing.assert_array_equal(gi[0, :k].cpu().numpy(), oi)
+    np.testing.assert_array_equal(gl[0, :k].cpu().numpy(), ol)
     np.testing.assert_array_equal(gs[0, :k].cpu().numpy(), osc)
 
 
