@@ -426,7 +426,7 @@ def main(argv=None):
             sub = copy.copy(args)
             sub.workload = name if name != 'detect' else 'c2'
             sub.no_secondary, sub.no_cpu_baseline, sub.secondary = True, True, True
-            sub.steps, sub.warmup = (5, 2) if name == 'c4' else (10, 3)
+            sub.steps, sub.warmup = (8, 3) if name == 'c4' else (10, 3)
             set_workload(sub.workload)
             try:
                 torch.cuda.empty_cache()
