@@ -119,7 +119,10 @@ def variable_scope(name):
 @contextlib.contextmanager
 def variable_scope_absolute(name):
     """Run the block under exactly the scope `name` ('' = the root), whatever scopes are open around it: deferred
-    graph pieces (compat layer) are evaluated long after their `with variable_scope(...)` block was left."""
+    graph pieces (compat layer) are evaluated long after their `with variable_scope(...)` block was left.
+    Like a fresh `with variable_scope(name):` at the root, the block starts with NEW auto-naming counters (the first conv
+    is 'Conv' again): variables are created-or-reused by name (get_variable), so re-entering a scope re-finds the same
+    variables; the surrounding scopes and their counters come back untouched afterwards."""
     stack = _scope_stack()
     saved = list(stack)
     stack[:] = [(name, {})] if name else []
