@@ -241,6 +241,52 @@ def test_winograd_conv_matches_fp64(n, h, w, cin, cout, act, resid):
     assert torch.equal(again, got)
 
 
+WINO44_CASES = [
+    # n, h, w, cin, cout, act, resid
+    (3, 20, 28, 64, 128, True, True),      # whole 4x4 tiles, ragged last tile block
+    (2, 13, 13, 512, 1024, True, True),    # odd map: 4x4 tiles of 4x4, the last row / column of tiles 3/4 outside
+    (1, 26, 26, 256, 512, True, False),    # 7x7 tiles, the last half outside
+    (2, 52, 52, 128, 256, True, True),     # true-size 52x52 residual-stage conv
+    (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear
+    (1, 2, 2, 96, 64, True, False),        # one tile per image, mostly padding; Cin not a power of two
+    (2, 40, 36, 32, 64, True, True),       # the 208x208 stage's shape class: 4 K-steps per block
+    (1, 9, 130, 32, 192, True, True),      # wide and flat, Cout = 3 column blocks
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,act,resid', WINO44_CASES)
+def test_winograd_f4x4_conv_matches_fp64(n, h, w, cin, cout, act, resid):
+    """y3_conv2d_fwd_wino44 (F(4x4,3x3), fp32 arithmetic) against the fp64 reference at the direct kernel's tolerance."""
+    from yolov3_tensorflow_amd import engine, framework as fw, _lib
+    dev = fw.default_device()
+    rng = np.random.RandomState(n * 100 + h + cin)
+    x, wt, scale, shift = make_case(rng, n, h, w, 3, cin, cout)
+    r = rng.standard_normal((n, h, w, cout)).astype(np.float32) if resid else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    assert engine.wino44_eligible(3, 1, cin, cout)
+    wu = engine.pack_wino44(t(wt))
+    got = engine.conv2d_fwd_wino44(t(x), wu, t(scale), t(shift), cout, act, residual=t(r))
+    torch.cuda.synchronize()
+    want = ref_conv(x, wt, scale, shift, 3, 1, act, r)
+    err = np.abs(got.cpu().numpy() - want)
+    print('F(4x4,3x3) %dx%dx%d %d->%d: max err %.3e (max |ref| %.2f)' % (n, h, w, cin, cout, err.max(), np.abs(want).max()))
+    check(got.cpu().numpy(), want, 'winograd F(4x4) %dx%dx%d %d->%d' % (n, h, w, cin, cout))
+    again = engine.conv2d_fwd_wino44(t(x), wu, t(scale), t(shift), cout, act, residual=t(r))
+    assert torch.equal(again, got)
+
+
+def test_winograd_f4x4_eligibility_and_errors():
+    from yolov3_tensorflow_amd import engine, framework as fw
+    dev = fw.default_device()
+    for args, ok in [((3, 1, 64, 64), True), ((3, 1, 32, 128), True), ((3, 2, 64, 64), False), ((1, 1, 64, 64), False),
+                     ((3, 1, 48, 64), False), ((3, 1, 64, 32), False), ((3, 1, 64, 255), False)]:
+        assert engine.wino44_eligible(*args) == ok, args
+    x = torch.zeros((1, 8, 8, 64), device=dev)
+    with pytest.raises(ValueError):
+        engine.conv2d_fwd_wino44(x, torch.zeros(36 * 64 * 32, device=dev), torch.ones(32, device=dev),
+                                 torch.zeros(32, device=dev), 32, True)
+
+
 def test_winograd_eligibility_and_errors():
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
     L = _lib.lib()

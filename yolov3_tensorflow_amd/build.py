@@ -22,6 +22,7 @@ SOURCES = [
     ("y3_conv_bf16x.hip", []),
     ("y3_conv_split.hip", []),
     ("y3_conv_wino.hip", []),
+    ("y3_conv_wino44.hip", []),
     ("y3_decode.hip", ["-ffp-contract=off"]),
     ("y3_nms.hip", ["-ffp-contract=off"]),
     ("y3_ops.hip", ["-ffp-contract=off"]),

@@ -188,6 +188,20 @@ extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const floa
     return y3_launch_conv_wino(ctx->stream, d, x, w_wino, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
+extern "C" int y3_conv_wino44_eligible(const y3_conv_desc* d) { return y3_conv_wino44_eligible_impl(d); }
+
+extern "C" int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino44) {
+    Y3_CHECK_ARG(ctx && w_hwio && w_wino44, "y3_pack_conv_weights_wino44: null argument");
+    Y3_CHECK_ARG(cin > 0 && cout > 0 && cin % 8 == 0, "y3_pack_conv_weights_wino44: cin must be a positive multiple of 8");
+    return y3_launch_pack_wino44(ctx->stream, w_hwio, cin, cout, w_wino44);
+}
+
+extern "C" int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44,
+                                    const float* scale, const float* shift, const float* residual, float* y) {
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_wino44");
+    return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, residual, y);
+}
+
 // Data gradient of a stride-1 3x3 conv in its Winograd form: dx (+)= conv_same(dz, flipped / channel-swapped kernel) is
 // itself a stride-1 3x3 SAME conv [n,h,w,dz_stride] -> [n,h,w,cin], so the forward Winograd kernel runs it unchanged.
 static int wino_dgrad_desc(const y3_conv_desc* fwd, int dz_stride, y3_conv_desc* g) {

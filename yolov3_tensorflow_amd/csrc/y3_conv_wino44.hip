@@ -1,0 +1,376 @@
+// Winograd F(4x4, 3x3) form of the stride-1 3x3 conv (+ folded BN + LeakyReLU + residual) for INFERENCE, exact fp32
+// arithmetic on v_mfma_f32_16x16x4_f32.  Replaces the same reference code as y3_conv.hip / y3_conv_wino.hip
+// (utils/layer_utils.py:9-22,25-32): 36 multiplies per 4x4 output tile and channel pair instead of 144 (direct) or 64
+// (F(2x2,3x3)) - 1.78x less MFMA work than y3_conv_wino.hip.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 4x4 output tile (6x6 input patch), summed over input channels,
+//   interpolation points 0, +-1, +-2, inf (Lavin & Gray).  Numerics on THIS network (tests/probes/winograd_numerics.py, fp32
+//   restatement of the whole forward against the fp64 oracle): boxes 1.0e-5 of the box scale against 7.5e-6 for F(2x2,3x3)
+//   and 6.3e-6 for the direct sum - a hundred times inside the 1e-3 of the north star.
+//
+//   * weights U = G g G^T transformed once at load time and packed [36][Cin/8][Cout][8] (y3_pack_conv_weights_wino44);
+//   * a workgroup = eight waves owns 32 tiles x 64 output channels for ALL 36 transform positions; wave (wm, wn) holds
+//     16 tiles x 16 channels of every position as v_mfma_f32_16x16x4_f32 accumulators (36 x 4 = 144 registers, two waves
+//     per SIMD), so the 36 position sums of one (tile, channel) sit in ONE lane and A^T M A needs no exchange between
+//     waves at all;
+//   * K-step = 8 input channels = 72 MFMAs per wave.  The B^T d B tile of the NEXT K-step is staged through the LDS
+//     ([2][36][32 tiles][32 B], 72 KB): thread (tile, channel pair, job) loads the patch rows its job needs as 8-byte
+//     bounds-checked loads (padding = out of range = 0), transforms them on float2s and writes one or two rows of the 6x6
+//     result (jobs: row 0 | rows 1,2 | rows 3,4 | row 5 - the paired rows share their first pass).  Weight fragments never
+//     touch the LDS: a lane's 8 bytes of U[pos][cout][2 channels] come straight from global memory (512 contiguous bytes
+//     per wave load) through a rolling window of registers that runs ahead across K-step boundaries;
+//   * channel k of the 8 plays "k" in MFMA (k / 2 % ... ) as both operands agree: lane quarter q = lane / 16 reads channels
+//     2q, 2q+1 (one ds_read_b64 / one 8-byte load) and MFMA m = 0, 1 consumes channel 2q + m;
+//   * epilogue: A^T M A per accumulator register in registers (120 adds / multiplies by 2, 4, 8 per 4x4 tile), scale /
+//     shift, LeakyReLU, residual, stores.
+// One block per workgroup, no stream-K: inference layers of the network give 256-5,408 blocks.
+#include <cstdlib>
+#include "y3_internal.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct W44Args {
+    const float* x;      // [N,H,W,Cin]
+    const float* u;      // packed [36][Cin/8][Cout][8]
+    const float* scale;  // [Cout]
+    const float* shift;  // [Cout]
+    const float* resid;  // [N,H,W,Cout] or nullptr
+    float* y;            // [N,H,W,Cout]
+    int N, H, W, Cin, Cout, act;
+    int TH, TW, T;       // 4x4 output tiles per image column / row, and in total
+};
+
+constexpr int BT = 32, BNC = 64, NTH = 512;
+constexpr int KC = 8;                          // input channels per K-step
+constexpr int ROWB = KC * 4;                   // LDS bytes per (position, tile) row
+constexpr int PLANE = BT * ROWB;               // one position's tiles
+constexpr int STAGE = 36 * PLANE;              // 36,864 B
+constexpr unsigned OOB = 0x80000000u;
+constexpr int BDEPTH = 9;                      // weight fragments in flight per wave (divides 36: the window runs on across K-steps)
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// 16 bytes per lane, global -> LDS without a register round trip: lane l's bytes land at lds_base + 16*l (lds_base is
+// wave-uniform), an out-of-range `voff` writes zeros (see y3_conv_bf16x.hip; the builtin exists in the device pass only).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_base, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
+
+// 1-D input transform B^T v for the 6-point rule; rows 1,2 and 3,4 share their sums
+template <typename V> __device__ __forceinline__ V bt0(const V& v0, const V& v2, const V& v4) { return 4.f * v0 - 5.f * v2 + v4; }
+template <typename V> __device__ __forceinline__ V bt5(const V& v1, const V& v3, const V& v5) { return 4.f * v1 - 5.f * v3 + v5; }
+
+// all six outputs of B^T applied along a 6-vector, written as row i of V = B^T d B (6 position planes)
+__device__ __forceinline__ void put_row(const f32x2 (&e)[6], unsigned char* vs, int i) {
+    f32x2 o[6];
+    o[0] = bt0(e[0], e[2], e[4]);
+    const f32x2 p = e[4] - 4.f * e[2], q = e[3] - 4.f * e[1];
+    o[1] = p + q;
+    o[2] = p - q;
+    const f32x2 p2 = e[4] - e[2], q2 = 2.f * (e[3] - e[1]);
+    o[3] = p2 + q2;
+    o[4] = p2 - q2;
+    o[5] = bt5(e[1], e[3], e[5]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vs + (i * 6 + j) * PLANE) = o[j];
+}
+
+// One staging job: rs / vs point at this thread's (tile, channel pair) inside the raw patch planes [k*6+l] and the V planes.
+// JOB 0: row 0 of V (patch rows 0,2,4) | 1: rows 1,2 (patch rows 1..4) | 2: rows 3,4 (patch rows 1..4) | 3: row 5 (1,3,5)
+template <int JOB>
+__device__ __forceinline__ void transform_job(const unsigned char* rs, unsigned char* vs) {
+    auto ld = [&](int k, int l) { return *reinterpret_cast<const f32x2*>(rs + (k * 6 + l) * PLANE); };
+    f32x2 e[6];
+    if (JOB == 0) {
+#pragma unroll
+        for (int l = 0; l < 6; ++l) e[l] = bt0(ld(0, l), ld(2, l), ld(4, l));
+        put_row(e, vs, 0);
+    } else if (JOB == 3) {
+#pragma unroll
+        for (int l = 0; l < 6; ++l) e[l] = bt5(ld(1, l), ld(3, l), ld(5, l));
+        put_row(e, vs, 5);
+    } else {
+        f32x2 f[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            const f32x2 d1 = ld(1, l), d2 = ld(2, l), d3 = ld(3, l), d4 = ld(4, l);
+            const f32x2 pq = JOB == 1 ? d4 - 4.f * d2 : d4 - d2;
+            const f32x2 qq = JOB == 1 ? d3 - 4.f * d1 : 2.f * (d3 - d1);
+            e[l] = pq + qq;
+            f[l] = pq - qq;
+        }
+        put_row(e, vs, JOB == 1 ? 1 : 3);
+        put_row(f, vs, JOB == 1 ? 2 : 4);
+    }
+}
+
+__global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // V: [2][36][BT][32 B], then raw patches: the same shape
+    constexpr int RAW_OFF = 2 * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves: 16 tiles x 16 channels each
+    const int nbn = p.Cout / BNC;
+    const int bt = blockIdx.x / nbn, bn = blockIdx.x - bt * nbn;     // the Cout/64 blocks of one tile block are neighbours
+    const int t0 = bt * BT, n0 = bn * BNC;
+    const int ksteps = p.Cin / KC;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.u), 0, (unsigned)((size_t)36 * p.Cin * p.Cout * 4), 0x00020000);
+
+    // ---- raw patches, global -> LDS by DMA: plane i = patch pixel (k, l) = (i / 6, i % 6) holds [32 tiles][8 channels];
+    //      wave w moves planes w, w + 8, ...: lane = (tile, 16-byte half) -> 1 KB contiguous in the LDS per instruction
+    unsigned dvoff[5];
+    {
+        const int t = t0 + (lane >> 1);
+        const bool tok = t < p.T;
+        const int n = t / (p.TH * p.TW);
+        const int r = t - n * p.TH * p.TW;
+        const int ty = r / p.TW, tx = r - ty * p.TW;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = wave + 8 * j;
+            const int k = i / 6, l = i - 6 * k;
+            const int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + l;
+            const bool ok = tok && i < 36 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            dvoff[j] = ok ? (unsigned)((((n * p.H + yy) * p.W + xx) * p.Cin) * 4 + (lane & 1) * 16) : OOB;
+        }
+    }
+    auto dma_raw = [&](int ks, int buf) {
+        const unsigned so = (unsigned)(ks * KC) * 4u;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (wave + 8 * j < 36) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + 8 * j) * PLANE, dvoff[j], so);
+    };
+
+    // ---- staging job of this thread: (tile, channel pair) x job ----------------------------------------------------
+    const int unit = tid & 127, job = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int st_off = (unit >> 2) * ROWB + (unit & 3) * 8;          // inside a plane
+    auto transform = [&](int bufr, int bufv) {
+        const unsigned char* rs = smem + RAW_OFF + bufr * STAGE + st_off;
+        unsigned char* vs = smem + bufv * STAGE + st_off;
+        if (job == 0) transform_job<0>(rs, vs);
+        else if (job == 1) transform_job<1>(rs, vs);
+        else if (job == 2) transform_job<2>(rs, vs);
+        else transform_job<3>(rs, vs);
+    };
+
+    // ---- MFMA operands ----------------------------------------------------------------------------------------------
+    f32x4 acc[36];
+#pragma unroll
+    for (int pos = 0; pos < 36; ++pos) acc[pos] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row16 = lane & 15, quart = lane >> 4;
+    const int a_off = (wm * 16 + row16) * ROWB + quart * 8;                                   // inside a position plane
+    const unsigned b_voff = (n0 + wn * 16 + row16 < p.Cout)
+        ? (unsigned)(((n0 + wn * 16 + row16) * KC + quart * 2) * 4) : OOB;
+    const unsigned b_pos_stride = (unsigned)((size_t)ksteps * p.Cout * KC * 4);             // bytes between positions
+    const unsigned b_ks_stride = (unsigned)(p.Cout * KC * 4);
+    f32x2 bq[BDEPTH];
+    auto issue_b = [&](int slot, int pos, int ks) {
+        bq[slot] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+            rs_u, b_voff, (unsigned)pos * b_pos_stride + (unsigned)ks * b_ks_stride, 0));
+    };
+
+    // ---- prologue: raw(0), raw(1) by DMA; V(0) = transform(raw(0)); the first weight fragments --------------------------
+    dma_raw(0, 0);
+    if (ksteps > 1) dma_raw(1, 1);
+#pragma unroll
+    for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, 0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // the DMAs are older than the fragment loads
+    __builtin_amdgcn_s_barrier();
+    transform(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < ksteps;
+        if (ks + 2 < ksteps) dma_raw(ks + 2, cur);          // raw[cur] held raw(ks): consumed a K-step ago
+        // V(ks+1) from raw(ks+1) - it landed before the last barrier - next to the MFMAs on V(ks) (on the last K-step it
+        // transforms stale data into a buffer nobody reads: keeps the K-step one basic block)
+        transform(cur ^ 1, cur ^ 1);
+        const unsigned char* vs = smem + cur * STAGE + a_off;
+        constexpr int AD = 3;                                  // activation fragments read ahead
+        f32x2 aq[AD];
+#pragma unroll
+        for (int s = 0; s < AD; ++s) aq[s] = *reinterpret_cast<const f32x2*>(vs + s * PLANE);
+#pragma unroll
+        for (int pos = 0; pos < 36; ++pos) {
+            const f32x2 a = aq[pos % AD];
+            const f32x2 b = bq[pos % BDEPTH];
+            if (pos + AD < 36) aq[pos % AD] = *reinterpret_cast<const f32x2*>(vs + (pos + AD) * PLANE);
+            // refill the slot with the fragment BDEPTH positions ahead (it runs on into the next K-step; past the last
+            // K-step it re-reads a valid address and is never used)
+            {
+                const int np = pos + BDEPTH;
+                if (np < 36) issue_b(pos % BDEPTH, np, ks);
+                else issue_b(pos % BDEPTH, np - 36, more ? ks + 1 : ks);
+            }
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[pos], 0, 0, 0);
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[pos], 0, 0, 0);
+            // keep the software pipeline as written: left alone, hipcc's scheduler moves every fragment read right in front
+            // of its MFMAs (lgkmcnt(0) / vmcnt(1..3) ahead of each pair: the LDS and L2 latencies in full, 72 times)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // this K-step's DMA has landed (older than the window)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: A^T M A in registers -> LDS ([tile][pixel][64 channels] per 16-tile half: the K-loop's buffers are
+    //      free now) -> scale / shift / LeakyReLU / residual on 16-byte pieces, 256 contiguous bytes per output pixel ------
+    constexpr int RS = BNC + 4;                            // staged row stride in floats
+    float* cs = reinterpret_cast<float*>(smem) + wm * (16 * 16 * RS);
+    int* tinfo = reinterpret_cast<int*>(smem + 2 * 16 * 16 * RS * 4);     // [BT][2]: pixel index of the tile's corner, valid rows | cols << 8
+    if (tid < BT) {
+        const int t = t0 + tid;
+        int pix = 0, vv = 0;
+        if (t < p.T) {
+            const int n = t / (p.TH * p.TW);
+            const int r = t - n * p.TH * p.TW;
+            const int ty = r / p.TW, tx = r - ty * p.TW;
+            pix = (n * p.H + 4 * ty) * p.W + 4 * tx;
+            vv = min(4, p.H - 4 * ty) | (min(4, p.W - 4 * tx) << 8);
+        }
+        tinfo[2 * tid] = pix;
+        tinfo[2 * tid + 1] = vv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // 16x16 accumulator: row (tile) = 4 * (lane / 16) + r, column (channel) = lane % 16
+        float tq[6][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float m0 = acc[i * 6 + 0][r], m1 = acc[i * 6 + 1][r], m2 = acc[i * 6 + 2][r], m3 = acc[i * 6 + 3][r],
+                        m4 = acc[i * 6 + 4][r], m5 = acc[i * 6 + 5][r];
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            tq[i][0] = m0 + s1 + s2;
+            tq[i][1] = d1 + 2.f * d2;
+            tq[i][2] = s1 + 4.f * s2;
+            tq[i][3] = d1 + 8.f * d2 + m5;
+        }
+        float* row = cs + ((quart * 4 + r) * 16) * RS + wn * 16 + row16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float s1 = tq[1][q] + tq[2][q], d1 = tq[1][q] - tq[2][q], s2 = tq[3][q] + tq[4][q], d2 = tq[3][q] - tq[4][q];
+            row[(0 * 4 + q) * RS] = tq[0][q] + s1 + s2;
+            row[(1 * 4 + q) * RS] = d1 + 2.f * d2;
+            row[(2 * 4 + q) * RS] = s1 + 4.f * s2;
+            row[(3 * 4 + q) * RS] = d1 + 8.f * d2 + tq[5][q];
+        }
+    }
+    __syncthreads();
+    {
+        const int gt = tid & 255;                          // thread inside the 16-tile half (four waves)
+        const int c4 = (gt & 15) * 4;
+        const int co = n0 + c4;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (co < p.Cout) {
+            sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+            sh = *reinterpret_cast<const f32x4*>(p.shift + co);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int rowi = it * 16 + (gt >> 4);            // (tile, pixel) row of this half: 256 rows
+            const int tl = rowi >> 4, px = rowi & 15;
+            const int pix = tinfo[2 * (wm * 16 + tl)], vv = tinfo[2 * (wm * 16 + tl) + 1];
+            const int py = px >> 2, pxx = px & 3;
+            if (py < (vv & 0xff) && pxx < (vv >> 8) && co < p.Cout) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(cs + rowi * RS + c4);
+                v = v * sc + sh;
+                if (p.act) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                }
+                const size_t o = (size_t)(pix + py * p.W + pxx) * p.Cout + co;
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                *reinterpret_cast<f32x4*>(p.y + o) = v;
+            }
+        }
+    }
+}
+
+// U = G g G^T for every (ci, co), G the 6x3 matrix of F(4x4,3x3); out[pos][ci/8][co][ci%8]
+__global__ void __launch_bounds__(256) pack_weights_wino44_kernel(const float* __restrict__ w_hwio, float* __restrict__ out,
+                                                                  int cin, int cout) {
+    const long long total = (long long)cin * cout;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int cil = (int)(e % KC);
+        const long long r = e / KC;
+        const int co = (int)(r % cout);
+        const int kb = (int)(r / cout);
+        const int ci = kb * KC + cil;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
+        // rows of G: [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]
+        float t[6][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float g0 = g[0][b], g1 = g[1][b], g2 = g[2][b];
+            t[0][b] = g0 * (1.f / 4.f);
+            t[1][b] = -(g0 + g1 + g2) * (1.f / 6.f);
+            t[2][b] = -(g0 - g1 + g2) * (1.f / 6.f);
+            t[3][b] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+            t[4][b] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
+            t[5][b] = g2;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const float t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+            const float u[6] = {t0 * (1.f / 4.f), -(t0 + t1 + t2) * (1.f / 6.f), -(t0 - t1 + t2) * (1.f / 6.f),
+                                t0 * (1.f / 24.f) + t1 * (1.f / 12.f) + t2 * (1.f / 6.f),
+                                t0 * (1.f / 24.f) - t1 * (1.f / 12.f) + t2 * (1.f / 6.f), t2};
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                out[(((size_t)(a * 6 + b) * (cin / KC) + kb) * cout + co) * KC + cil] = u[b];
+        }
+    }
+}
+
+}  // namespace
+
+int y3_conv_wino44_eligible_impl(const y3_conv_desc* d) {
+    return d && d->k == 3 && d->stride == 1 && d->c_up == 0 && d->cin % 32 == 0 && d->cout % 64 == 0 &&
+           d->n > 0 && d->h > 1 && d->w > 1;
+}
+
+int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {
+    const long long total = (long long)cin * cout;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_weights_wino44_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
+int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
+                          const float* shift, const float* residual, float* y) {
+    Y3_CHECK_ARG(d && x && u && scale && shift && y, "y3_conv2d_fwd_wino44: null pointer argument");
+    Y3_CHECK_ARG(y3_conv_wino44_eligible_impl(d),
+                 "y3_conv2d_fwd_wino44: needs a 3x3 stride-1 conv with Cin %% 32 == 0 and Cout %% 64 == 0, no fused upsample input");
+    Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 29) && (long long)d->n * d->h * d->w * d->cout < (1LL << 29) &&
+                     (long long)36 * d->cin * d->cout < (1LL << 29),
+                 "y3_conv2d_fwd_wino44: tensor exceeds 2^29 elements (32-bit byte offsets)");
+    W44Args a;
+    a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
+    a.TH = (d->h + 3) / 4; a.TW = (d->w + 3) / 4; a.T = d->n * a.TH * a.TW;
+    static bool attr_set = false;      // benign race (idempotent)
+    if (!attr_set) {
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino44_f32_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE));
+        attr_set = true;
+    }
+    const int nbt = (a.T + BT - 1) / BT, nbn = d->cout / BNC;
+    hipLaunchKernelGGL(conv_wino44_f32_kernel, dim3(nbt * nbn), dim3(NTH), 4 * STAGE, stream, a);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}

@@ -186,6 +186,30 @@ def pack_wino(w_hwio):
     return out
 
 
+def wino44_eligible(k, stride, cin, cout, c_up=0):
+    """True for the convs the F(4x4,3x3) inference kernel takes (y3_conv_wino44_eligible)."""
+    d = _lib.ConvDesc(1, 8, 8, cin, c_up, cout, k, stride, 0)
+    return _lib.lib().y3_conv_wino44_eligible(ctypes.byref(d)) == 1
+
+
+def pack_wino44(w_hwio):
+    """HWIO [3,3,cin,cout] fp32 device tensor -> the F(4x4,3x3) packing [36][cin/8][cout][8] (y3_pack_conv_weights_wino44)."""
+    _, _, cin, cout = w_hwio.shape
+    out = torch.empty(36 * cin * cout, dtype=torch.float32, device=w_hwio.device)
+    _lib.check(_lib.lib().y3_pack_conv_weights_wino44(fw.context(w_hwio.device), fw.ptr(w_hwio), cin, cout, fw.ptr(out)))
+    return out
+
+
+def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None):
+    """3x3 stride-1 conv in its Winograd F(4x4,3x3) form (y3_conv2d_fwd_wino44, inference); w_wino44 from pack_wino44."""
+    n, h, w, cin = x.shape
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 1 if act else 0)
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().y3_conv2d_fwd_wino44(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44),
+                                               fw.ptr(scale), fw.ptr(shift), fw.ptr(residual), fw.ptr(y)))
+    return y
+
+
 def upsample_nearest(x, out_h, out_w):
     n, h, w, c = x.shape
     y = torch.empty((n, out_h, out_w, c), dtype=torch.float32, device=x.device)
