@@ -246,7 +246,8 @@ def box_delta_vs_oracle(model, y3, x, fms, n_check=None, chunk=4):
 
 
 PRECISION_TEXT = {
-    "f32_wino": "exact fp32 MFMA arithmetic; Winograd F(2x2,3x3) kernel for the stride-1 3x3 convs, direct kernel elsewhere",
+    "f32_wino": "fp32 MFMA arithmetic throughout; Winograd kernels for the stride-1 3x3 convs (F(4x4,3x3) for the 128->256 and "
+                "512->1024 convs, F(2x2,3x3) for the others), direct kernel elsewhere",
     "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), direct implicit-GEMM kernels only",
     "f32_bf16x6": "fp32 tensors; each product = 6 bf16 plane products, fp32 accumulate (dropped terms <= 2^-23 relative)",
     "f32_bf16x3": "fp32 tensors; each product = 3 bf16 plane products, fp32 accumulate (dropped terms <= 2^-15 relative)",
@@ -338,8 +339,9 @@ def parse_args(argv):
                     help="c2 (default, the BASELINE metric): fp32 forward 416x416 bs=32; c4: train step 416x416 bs=64 "
                          "per GPU, SGD, RCCL gradient all-reduce; c5: bf16-storage forward 608x608 bs=16")
     ap.add_argument('--precision', choices=['f32_wino', 'f32', 'f32_bf16x6', 'f32_bf16x3'], default='f32_wino',
-                    help="c2/c4. f32_wino (default): exact fp32 MFMA arithmetic, Winograd F(2x2,3x3) kernel for the "
-                         "stride-1 3x3 convs, direct kernel elsewhere; f32: direct kernels only; f32_bf16x6 / "
+                    help="c2/c4. f32_wino (default): fp32 MFMA arithmetic, Winograd kernels for the stride-1 3x3 convs "
+                         "(forward: F(4x4,3x3) where the library prefers it, F(2x2,3x3) elsewhere; train step: F(2x2,3x3)), "
+                         "direct kernel elsewhere; f32: direct kernels only; f32_bf16x6 / "
                          "f32_bf16x3: fp32 tensors, every product rebuilt from 6 / 3 bf16 plane products with fp32 "
                          "accumulation")
     ap.add_argument('--batch', type=int, default=None, help="per-GPU batch (default: the workload's BASELINE value)")
@@ -517,8 +519,8 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
     table = [tuple(t) for t in model._get_net(x.device)['table']]
     flops = conv_flops(table, BATCH, SIZE, SIZE)
     nbytes = conv_bytes(table, BATCH, SIZE, SIZE, 4)
-    is_wino = np.array([args.precision == 'f32_wino' and engine_wino(k, s, cin, cout) for (k, s, cin, cout, bn) in table])
-    issued = np.where(is_wino, flops * (16.0 / 36.0), flops)
+    is_wino, fac = winograd_issue_factors(table, args.precision, SIZE)
+    issued = flops * fac
     fwd_bound = float(np.maximum(nbytes / (PEAK_HBM_TBPS * 1e12), issued / (PEAK_FP32_MFMA_TFLOPS * 1e12)).sum()) * 1e3
     nbox = 3 * sum((SIZE // s) ** 2 for s in (32, 16, 8))
     post_bytes = BATCH * nbox * (5 + CLASS_NUM) * 4 * 2 + BATCH * nbox * CLASS_NUM * 4 * 2   # decode in/out, scores w + r
@@ -539,6 +541,31 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
                                    "157.3 TF/s) + one pass over the feature maps, decoded tensors and scores at 8 TB/s "
                                    "(%.3f + %.3f ms) over the measured ms per batch" % (fwd_bound, post_bound)},
             "regimes": regimes}
+
+
+def winograd_issue_factors(table, precision, size):
+    """Per layer: (is_winograd, MFMA work ISSUED / direct-convolution FLOPs) for the kernel the library runs in `precision`.
+    F(2x2,3x3) layers issue 16/36 of the direct count; the layers y3_conv_wino44_preferred names run F(4x4,3x3) in the
+    inference forward: 36/144, times the padding of their 4x4 tiles on this grid (a 13-grid is covered by 4x4 tiles of 4x4:
+    256/169).  The factor follows the library's own choice, so `achieved` never counts work a kernel did not issue."""
+    from yolov3_tensorflow_amd import engine
+    is_w, fac = [], []
+    grid = size
+    for (k, s, cin, cout, bn) in table:
+        g_in = grid
+        if s == 2:
+            grid //= 2
+        w = precision == 'f32_wino' and bool(engine.wino_eligible(k, s, cin, cout))
+        f = 1.0
+        if w:
+            if engine.wino44_preferred(k, s, cin, cout):
+                t = -(-g_in // 4) * 4
+                f = (36.0 / 144.0) * (t * t) / float(g_in * g_in)
+            else:
+                f = 16.0 / 36.0
+        is_w.append(w)
+        fac.append(f)
+    return np.array(is_w, bool), np.array(fac)
 
 
 def engine_wino(k, s, cin, cout):
@@ -600,7 +627,10 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
         "metric": "images/sec, train step at 416x416 bs=%d per GPU (forward + loss + backward + gradient all-reduce + clip + SGD)" % BATCH,
         "value": round(world * BATCH * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "precision": PRECISION_TEXT[args.precision],
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "precision": ("fp32 MFMA arithmetic; Winograd F(2x2,3x3) forms of the forward, the data gradient and the weight "
+                      "gradient of the stride-1 3x3 convs, direct kernels elsewhere" if args.precision == 'f32_wino'
+                      else PRECISION_TEXT[args.precision]),
         "data": "synthetic",
         "config": {"workload": "configs[3]: train step, synthetic COCO-80 batches, 416x416 bs=%d per GPU, SGD, %s, "
                                "RCCL gradient all-reduce (bucketed, overlapped with backward)" %
@@ -700,8 +730,9 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
     flops = conv_flops(table, BATCH, SIZE, SIZE)
     nbytes = conv_bytes(table, BATCH, SIZE, SIZE, 2 if bf16 else 4)
     is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
-    is_wino = np.array([wino and engine.wino_eligible(k, s, cin, cout) for (k, s, cin, cout, bn) in table])
-    issued = np.where(is_wino, flops * (16.0 / 36.0), flops)       # MFMA work the kernels actually issue
+    is_wino, fac = winograd_issue_factors(table, args.precision if wino else 'f32', SIZE)
+    issued = flops * fac                                           # MFMA work the kernels actually issue
+    n_f44 = int(np.sum(is_wino & (fac < 16.0 / 36.0 - 1e-9)))      # layers on the F(4x4,3x3) kernel
     if wino:        # dominant family: the Winograd kernel (every stride-1 3x3 conv but the stem)
         dom = is_wino
     elif bf16:      # the 3x3 convs on 128x128 tiles (conv_mfma_bf16_kernel<128,128,2,2,3,false>)
@@ -725,8 +756,11 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else
-              "conv_wino8_f32_kernel (Winograd F(2x2,3x3) conv, fp32 MFMA, two waves per SIMD): `achieved` = MFMA work ISSUED (16/36 of the "
-              "direct-convolution FLOPs) per second; `achieved_algorithmic` counts the direct-convolution FLOPs" if wino else
+              "the Winograd kernels of the stride-1 3x3 convs: conv_wino8_f32_kernel (F(2x2,3x3), %d launches) and "
+              "conv_wino44_f32_kernel (F(4x4,3x3), %d launches: the 128->256 and 512->1024 convs); `achieved` = MFMA work "
+              "ISSUED per second (16/36 resp. 36/144 x tile padding of the direct-convolution FLOPs, per layer by the kernel the "
+              "library picked); `achieved_algorithmic` counts the direct-convolution FLOPs" % (int(is_wino.sum()) - n_f44, n_f44)
+              if wino else
               "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, stream-K schedule)")
     out = {
         "metric": ("images/sec at 608x608 bs=16 bf16 (Darknet-53 + 3-scale head forward)" if bf16 else

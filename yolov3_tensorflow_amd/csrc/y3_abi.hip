@@ -189,6 +189,7 @@ extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const floa
 }
 
 extern "C" int y3_conv_wino44_eligible(const y3_conv_desc* d) { return y3_conv_wino44_eligible_impl(d); }
+extern "C" int y3_conv_wino44_preferred(const y3_conv_desc* d) { return y3_conv_wino44_preferred_impl(d); }
 
 extern "C" int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino44) {
     Y3_CHECK_ARG(ctx && w_hwio && w_wino44, "y3_pack_conv_weights_wino44: null argument");
@@ -413,6 +414,8 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         const int rc = net->dtype == 1
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
+            : (net->dtype == 4 && y3_conv_wino44_preferred_impl(&d))
+            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst))
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
             ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   base + net->arena_bytes, net->scratch_bytes, &o)

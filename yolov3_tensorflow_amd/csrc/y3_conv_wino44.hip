@@ -343,6 +343,18 @@ int y3_conv_wino44_eligible_impl(const y3_conv_desc* d) {
            d->n > 0 && d->h > 1 && d->w > 1;
 }
 
+// The layers y3_net_forward (dtype 4) runs on this kernel instead of the F(2x2,3x3) one: where it measured faster inside the
+// bs=32 416x416 forward (tools/layer_profile.py, profiles/r03_wino44.txt) - the 128->256 convs (52-grid: 0.245 -> 0.205 ms)
+// and the 512->1024 convs (13-grid: 0.241 -> 0.234 ms).  The 256->512 convs lose to block-count quantisation (392 blocks
+// on 256 CUs), the 32->64 / 64->128 ones to their 4-8 K-step blocks.  Y3_WINO44=0 turns the kernel off, =2 takes every
+// eligible layer (A/B runs).
+int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
+    static const int mode = getenv("Y3_WINO44") ? atoi(getenv("Y3_WINO44")) : 1;
+    if (mode == 0 || !y3_conv_wino44_eligible_impl(d)) return 0;
+    if (mode == 2) return 1;
+    return (d->cin == 128 && d->cout == 256) || (d->cin == 512 && d->cout == 1024);
+}
+
 int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {
     const long long total = (long long)cin * cout;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);

@@ -62,11 +62,12 @@ def prepare_conv_params_wino(w_var, bn_vars=None, bias_var=None, stride=1):
     k, _, cin, cout = w_var.shape
     if not wino_eligible(k, stride, cin, cout):
         return w32, scale, shift
-    key = w_var.op_name + '#wino'
+    f44 = wino44_preferred(k, stride, cin, cout)       # the layers y3_net_forward runs on the F(4x4,3x3) kernel
+    key = w_var.op_name + ('#wino44' if f44 else '#wino')
     hit = _param_cache.get(key)
     if hit is not None and hit[0] == w_var.version:
         return hit[1], scale, shift
-    wu = pack_wino(w_var.tensor)
+    wu = pack_wino44(w_var.tensor) if f44 else pack_wino(w_var.tensor)
     _param_cache[key] = (w_var.version, wu)
     return wu, scale, shift
 
@@ -190,6 +191,12 @@ def wino44_eligible(k, stride, cin, cout, c_up=0):
     """True for the convs the F(4x4,3x3) inference kernel takes (y3_conv_wino44_eligible)."""
     d = _lib.ConvDesc(1, 8, 8, cin, c_up, cout, k, stride, 0)
     return _lib.lib().y3_conv_wino44_eligible(ctypes.byref(d)) == 1
+
+
+def wino44_preferred(k, stride, cin, cout, c_up=0):
+    """True for the convs y3_net_forward gives to the F(4x4,3x3) kernel in 'f32_wino' mode (y3_conv_wino44_preferred)."""
+    d = _lib.ConvDesc(1, 8, 8, cin, c_up, cout, k, stride, 0)
+    return _lib.lib().y3_conv_wino44_preferred(ctypes.byref(d)) == 1
 
 
 def pack_wino44(w_hwio):
