@@ -145,7 +145,9 @@ size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d);   /* stream-K scratc
 int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino, const float* scale,
                        const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
 /* The same conv in its Winograd F(4x4,3x3) form (36 multiplies per 4x4 output tile and channel pair: 1.78x less
- * matrix-pipe work again; inference only: no statistics output, no stream-K scratch).  y3_conv_wino44_eligible accepts
+ * matrix-pipe work again; inference only: no statistics output).  With a workspace, block counts that do not fill the last
+ * round of the 256 resident workgroups run a persistent schedule: whole rounds of blocks first, the remaining blocks cut
+ * along K and finished inside the kernel (same hand-off protocol and failure reporting as y3_conv2d_fwd_wino).  y3_conv_wino44_eligible accepts
  * (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cout %% 64 == 0).  w_wino44 = G g G^T with the 6x3 G of the
  * interpolation points 0, +-1, +-2, inf, packed [36][cin/8][cout][8] fp32 (36*cin*cout floats) by
  * y3_pack_conv_weights_wino44.  Results differ from the direct kernel by fp32 roundings of the transforms (measured on the
@@ -153,8 +155,9 @@ int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const
 int y3_conv_wino44_eligible(const y3_conv_desc* d);
 int y3_conv_wino44_preferred(const y3_conv_desc* d);   /* the layers y3_net_forward (dtype 4) gives to this kernel */
 int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino44);
+size_t y3_conv_wino44_workspace_bytes(const y3_conv_desc* d);   /* scratch of the persistent schedule; workspace = NULL is allowed */
 int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44, const float* scale,
-                         const float* shift, const float* residual, float* y);
+                         const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
 
 /* ---- fp32 on the bf16 matrix pipe ----------------------------------------------------------------------------
  * Same contract and tensors as y3_conv2d_fwd (fp32 NHWC in, fp32 out, same epilogue, same workspace rule); every

@@ -251,6 +251,10 @@ WINO44_CASES = [
     (1, 2, 2, 96, 64, True, False),        # one tile per image, mostly padding; Cin not a power of two
     (2, 40, 36, 32, 64, True, True),       # the 208x208 stage's shape class: 4 K-steps per block
     (1, 9, 130, 32, 192, True, True),      # wide and flat, Cout = 3 column blocks
+    (32, 26, 26, 64, 512, True, True),     # 49 x 8 = 392 blocks on 256 workers: persistent schedule, 136 blocks cut along K
+    (10, 52, 52, 32, 128, True, False),    # 53 x 2 = 106 blocks (one round) ... and with Cout 640 below: 530 blocks, 4 K-steps
+    (10, 52, 52, 32, 640, False, True),    # 530 blocks: two whole rounds + 18 cut blocks of 4 K-steps (rem * ksteps < 2 W: data parallel)
+    (24, 26, 26, 128, 512, True, True),    # 37 x 8 = 296 blocks: 40 cut blocks x 16 K-steps, pieces of 2-3 K-steps
 ]
 
 
@@ -272,7 +276,10 @@ def test_winograd_f4x4_conv_matches_fp64(n, h, w, cin, cout, act, resid):
     print('F(4x4,3x3) %dx%dx%d %d->%d: max err %.3e (max |ref| %.2f)' % (n, h, w, cin, cout, err.max(), np.abs(want).max()))
     check(got.cpu().numpy(), want, 'winograd F(4x4) %dx%dx%d %d->%d' % (n, h, w, cin, cout))
     again = engine.conv2d_fwd_wino44(t(x), wu, t(scale), t(shift), cout, act, residual=t(r))
-    assert torch.equal(again, got)
+    assert torch.equal(again, got)                    # run-to-run bit-exact (partial sums are added in worker order)
+    # the one-workgroup-per-block schedule against the same reference (the persistent one splits some sums along K)
+    plain = engine.conv2d_fwd_wino44(t(x), wu, t(scale), t(shift), cout, act, residual=t(r), use_workspace=False)
+    check(plain.cpu().numpy(), want, 'winograd F(4x4), no workspace %dx%dx%d %d->%d' % (n, h, w, cin, cout))
 
 
 def test_winograd_f4x4_eligibility_and_errors():

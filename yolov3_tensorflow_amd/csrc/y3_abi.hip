@@ -197,10 +197,15 @@ extern "C" int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int
     return y3_launch_pack_wino44(ctx->stream, w_hwio, cin, cout, w_wino44);
 }
 
+extern "C" size_t y3_conv_wino44_workspace_bytes(const y3_conv_desc* d) { return y3_conv_wino44_workspace_bytes_impl(d); }
+
 extern "C" int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44,
-                                    const float* scale, const float* shift, const float* residual, float* y) {
+                                    const float* scale, const float* shift, const float* residual, float* y,
+                                    void* workspace, size_t workspace_bytes) {
     Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_wino44");
-    return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, residual, y);
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
 // Data gradient of a stride-1 3x3 conv in its Winograd form: dx (+)= conv_same(dz, flipped / channel-swapped kernel) is
@@ -415,7 +420,8 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
             : (net->dtype == 4 && y3_conv_wino44_preferred_impl(&d))
-            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst))
+            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
+                                    base + net->arena_bytes, net->scratch_bytes, &o)
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
             ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   base + net->arena_bytes, net->scratch_bytes, &o)

@@ -41,6 +41,13 @@ struct W44Args {
     float* y;            // [N,H,W,Cout]
     int N, H, W, Cin, Cout, act;
     int TH, TW, T;       // 4x4 output tiles per image column / row, and in total
+    // persistent schedule (workers > 0): whole rounds of blocks first, the remaining < workers blocks cut along K
+    float* partial;      // [workers][2 * 256 rows][64] output-space partial sums (pre scale / shift) of the cut blocks' later K-ranges
+    unsigned* flags;     // [workers] "partial published" words, zeroed ahead of every launch
+    unsigned* err;       // device-visible error word (a consumer whose poll expires ORs a code into it) or null
+    unsigned spin_limit; // polls per awaited flag before giving up
+    int workers;         // grid size of the persistent schedule (0 = one workgroup per block)
+    int fault;           // test hook: producers skip raising their flag
 };
 
 constexpr int BT = 32, BNC = 64, NTH = 512;
@@ -52,6 +59,15 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int BDEPTH = 9;                      // weight fragments in flight per wave (divides 36: the window runs on across K-steps)
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) unsigned gu32;   // flags are only ever touched by agent-scope global atomics
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int SLOT_FLOATS = BT * 16 * BNC;      // one partial-sum slot: 32 tiles x 16 pixels x 64 channels
+
+// Balanced contiguous partition of `items` over `parts`
+__device__ __host__ __forceinline__ long long part_begin(long long items, int parts, int i) {
+    const long long q = items / parts, r = items % parts;
+    return (long long)i * q + (i < r ? i : r);
+}
 
 // 16 bytes per lane, global -> LDS without a register round trip: lane l's bytes land at lds_base + 16*l (lds_base is
 // wave-uniform), an out-of-range `voff` writes zeros (see y3_conv_bf16x.hip; the builtin exists in the device pass only).
@@ -115,8 +131,7 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;             // 2 x 4 waves: 16 tiles x 16 channels each
     const int nbn = p.Cout / BNC;
-    const int bt = blockIdx.x / nbn, bn = blockIdx.x - bt * nbn;     // the Cout/64 blocks of one tile block are neighbours
-    const int t0 = bt * BT, n0 = bn * BNC;
+    const int nbt = (p.T + BT - 1) / BT;
     const int ksteps = p.Cin / KC;
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -124,175 +139,264 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.u), 0, (unsigned)((size_t)36 * p.Cin * p.Cout * 4), 0x00020000);
 
-    // ---- raw patches, global -> LDS by DMA: plane i = patch pixel (k, l) = (i / 6, i % 6) holds [32 tiles][8 channels];
-    //      wave w moves planes w, w + 8, ...: lane = (tile, 16-byte half) -> 1 KB contiguous in the LDS per instruction
-    unsigned dvoff[5];
-    {
-        const int t = t0 + (lane >> 1);
-        const bool tok = t < p.T;
-        const int n = t / (p.TH * p.TW);
-        const int r = t - n * p.TH * p.TW;
-        const int ty = r / p.TW, tx = r - ty * p.TW;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = wave + 8 * j;
-            const int k = i / 6, l = i - 6 * k;
-            const int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + l;
-            const bool ok = tok && i < 36 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            dvoff[j] = ok ? (unsigned)((((n * p.H + yy) * p.W + xx) * p.Cin) * 4 + (lane & 1) * 16) : OOB;
-        }
+    // ---- schedule ---------------------------------------------------------------------------------------------------
+    // workers == 0: workgroup b owns block b.  Persistent schedule: worker w runs the blocks w, w + W, ... of the R whole
+    // rounds start to end; the remaining < W blocks are divided into W equal ranges of (block, K-step) items.  Range index
+    // W-1-w goes to worker w, so the piece holding a block's K-step 0 - its OWNER, which adds the others' output-space
+    // partial sums and runs the tail - has the highest workgroup id of the block's pieces: it waits only for workgroups
+    // dispatched before it, and every worker meets its producer piece (the tail of a block) before its owner piece.
+    const int W = p.workers;
+    const int nblocks = nbt * nbn;
+    int whole_left = 1, whole_blk = blockIdx.x;
+    long long lo = 0, hi = 0;
+    int rem0 = 0;
+    if (W > 0) {
+        const int R = nblocks / W;
+        whole_left = R;
+        rem0 = R * W;
+        const long long items = (long long)(nblocks - rem0) * ksteps;
+        const int ri = W - 1 - (int)blockIdx.x;
+        lo = part_begin(items, W, ri);
+        hi = part_begin(items, W, ri + 1);
     }
-    auto dma_raw = [&](int ks, int buf) {
-        const unsigned so = (unsigned)(ks * KC) * 4u;
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if (wave + 8 * j < 36) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + 8 * j) * PLANE, dvoff[j], so);
-    };
 
-    // ---- staging job of this thread: (tile, channel pair) x job ----------------------------------------------------
+    // ---- per-thread constants ---------------------------------------------------------------------------------------
     const int unit = tid & 127, job = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int st_off = (unit >> 2) * ROWB + (unit & 3) * 8;          // inside a plane
-    auto transform = [&](int bufr, int bufv) {
-        const unsigned char* rs = smem + RAW_OFF + bufr * STAGE + st_off;
-        unsigned char* vs = smem + bufv * STAGE + st_off;
-        if (job == 0) transform_job<0>(rs, vs);
-        else if (job == 1) transform_job<1>(rs, vs);
-        else if (job == 2) transform_job<2>(rs, vs);
-        else transform_job<3>(rs, vs);
-    };
-
-    // ---- MFMA operands ----------------------------------------------------------------------------------------------
-    f32x4 acc[36];
-#pragma unroll
-    for (int pos = 0; pos < 36; ++pos) acc[pos] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int st_off = (unit >> 2) * ROWB + (unit & 3) * 8;          // staging job: (tile, channel pair) inside a plane
     const int row16 = lane & 15, quart = lane >> 4;
-    const int a_off = (wm * 16 + row16) * ROWB + quart * 8;                                   // inside a position plane
-    const unsigned b_voff = (n0 + wn * 16 + row16 < p.Cout)
-        ? (unsigned)(((n0 + wn * 16 + row16) * KC + quart * 2) * 4) : OOB;
+    const int a_off = (wm * 16 + row16) * ROWB + quart * 8;          // activation fragment inside a position plane
     const unsigned b_pos_stride = (unsigned)((size_t)ksteps * p.Cout * KC * 4);             // bytes between positions
     const unsigned b_ks_stride = (unsigned)(p.Cout * KC * 4);
-    f32x2 bq[BDEPTH];
-    auto issue_b = [&](int slot, int pos, int ks) {
-        bq[slot] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
-            rs_u, b_voff, (unsigned)pos * b_pos_stride + (unsigned)ks * b_ks_stride, 0));
-    };
-
-    // ---- prologue: raw(0), raw(1) by DMA; V(0) = transform(raw(0)); the first weight fragments --------------------------
-    dma_raw(0, 0);
-    if (ksteps > 1) dma_raw(1, 1);
-#pragma unroll
-    for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, 0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // the DMAs are older than the fragment loads
-    __builtin_amdgcn_s_barrier();
-    transform(0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < ksteps;
-        if (ks + 2 < ksteps) dma_raw(ks + 2, cur);          // raw[cur] held raw(ks): consumed a K-step ago
-        // V(ks+1) from raw(ks+1) - it landed before the last barrier - next to the MFMAs on V(ks) (on the last K-step it
-        // transforms stale data into a buffer nobody reads: keeps the K-step one basic block)
-        transform(cur ^ 1, cur ^ 1);
-        const unsigned char* vs = smem + cur * STAGE + a_off;
-        constexpr int AD = 3;                                  // activation fragments read ahead
-        f32x2 aq[AD];
-#pragma unroll
-        for (int s = 0; s < AD; ++s) aq[s] = *reinterpret_cast<const f32x2*>(vs + s * PLANE);
-#pragma unroll
-        for (int pos = 0; pos < 36; ++pos) {
-            const f32x2 a = aq[pos % AD];
-            const f32x2 b = bq[pos % BDEPTH];
-            if (pos + AD < 36) aq[pos % AD] = *reinterpret_cast<const f32x2*>(vs + (pos + AD) * PLANE);
-            // refill the slot with the fragment BDEPTH positions ahead (it runs on into the next K-step; past the last
-            // K-step it re-reads a valid address and is never used)
-            {
-                const int np = pos + BDEPTH;
-                if (np < 36) issue_b(pos % BDEPTH, np, ks);
-                else issue_b(pos % BDEPTH, np - 36, more ? ks + 1 : ks);
-            }
-            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[pos], 0, 0, 0);
-            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[pos], 0, 0, 0);
-            // keep the software pipeline as written: left alone, hipcc's scheduler moves every fragment read right in front
-            // of its MFMAs (lgkmcnt(0) / vmcnt(1..3) ahead of each pair: the LDS and L2 latencies in full, 72 times)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // this K-step's DMA has landed (older than the window)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // ---- epilogue: A^T M A in registers -> LDS ([tile][pixel][64 channels] per 16-tile half: the K-loop's buffers are
-    //      free now) -> scale / shift / LeakyReLU / residual on 16-byte pieces, 256 contiguous bytes per output pixel ------
-    constexpr int RS = BNC + 4;                            // staged row stride in floats
+    constexpr int RS = BNC + 4;                                      // staged output row stride in floats
     float* cs = reinterpret_cast<float*>(smem) + wm * (16 * 16 * RS);
     int* tinfo = reinterpret_cast<int*>(smem + 2 * 16 * 16 * RS * 4);     // [BT][2]: pixel index of the tile's corner, valid rows | cols << 8
-    if (tid < BT) {
-        const int t = t0 + tid;
-        int pix = 0, vv = 0;
-        if (t < p.T) {
+
+    while (whole_left > 0 || lo < hi) {
+        // ---- this segment: block, K-range, role ------------------------------------------------------------------------
+        int blk, ks0, ks1;
+        if (whole_left > 0) {
+            blk = whole_blk; ks0 = 0; ks1 = ksteps;
+            --whole_left; whole_blk += W;
+        } else {
+            const int br = (int)(lo / ksteps);
+            ks0 = (int)(lo - (long long)br * ksteps);
+            const long long left = hi - lo;
+            ks1 = (ksteps - ks0 < left) ? ksteps : ks0 + (int)left;
+            blk = rem0 + br;
+            lo += ks1 - ks0;
+        }
+        const bool producer = ks0 > 0;
+        int n_extra = 0;                                 // pieces of this block other workers publish (owner of a cut block)
+        if (W > 0 && !producer && ks1 < ksteps) {
+            const long long items = (long long)(nblocks - rem0) * ksteps;
+            const long long blk_end = (long long)(blk - rem0 + 1) * ksteps;
+            for (int jj = W - (int)blockIdx.x; jj < W; ++jj) {          // range indices after this worker's
+                if (part_begin(items, W, jj) >= blk_end) break;
+                ++n_extra;
+            }
+        }
+        const int bt = blk / nbn, bn = blk - bt * nbn;     // the Cout/64 blocks of one tile block are neighbours
+        const int t0 = bt * BT, n0 = bn * BNC;
+
+        // raw patches, global -> LDS by DMA: plane i = patch pixel (k, l) = (i / 6, i % 6) holds [32 tiles][8 channels];
+        // wave w moves planes w, w + 8, ...: lane = (tile, 16-byte half) -> 1 KB contiguous in the LDS per instruction
+        unsigned dvoff[5];
+        {
+            const int t = t0 + (lane >> 1);
+            const bool tok = t < p.T;
             const int n = t / (p.TH * p.TW);
             const int r = t - n * p.TH * p.TW;
             const int ty = r / p.TW, tx = r - ty * p.TW;
-            pix = (n * p.H + 4 * ty) * p.W + 4 * tx;
-            vv = min(4, p.H - 4 * ty) | (min(4, p.W - 4 * tx) << 8);
-        }
-        tinfo[2 * tid] = pix;
-        tinfo[2 * tid + 1] = vv;
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        // 16x16 accumulator: row (tile) = 4 * (lane / 16) + r, column (channel) = lane % 16
-        float tq[6][4];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float m0 = acc[i * 6 + 0][r], m1 = acc[i * 6 + 1][r], m2 = acc[i * 6 + 2][r], m3 = acc[i * 6 + 3][r],
-                        m4 = acc[i * 6 + 4][r], m5 = acc[i * 6 + 5][r];
-            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-            tq[i][0] = m0 + s1 + s2;
-            tq[i][1] = d1 + 2.f * d2;
-            tq[i][2] = s1 + 4.f * s2;
-            tq[i][3] = d1 + 8.f * d2 + m5;
-        }
-        float* row = cs + ((quart * 4 + r) * 16) * RS + wn * 16 + row16;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float s1 = tq[1][q] + tq[2][q], d1 = tq[1][q] - tq[2][q], s2 = tq[3][q] + tq[4][q], d2 = tq[3][q] - tq[4][q];
-            row[(0 * 4 + q) * RS] = tq[0][q] + s1 + s2;
-            row[(1 * 4 + q) * RS] = d1 + 2.f * d2;
-            row[(2 * 4 + q) * RS] = s1 + 4.f * s2;
-            row[(3 * 4 + q) * RS] = d1 + 8.f * d2 + tq[5][q];
-        }
-    }
-    __syncthreads();
-    {
-        const int gt = tid & 255;                          // thread inside the 16-tile half (four waves)
-        const int c4 = (gt & 15) * 4;
-        const int co = n0 + c4;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (co < p.Cout) {
-            sc = *reinterpret_cast<const f32x4*>(p.scale + co);
-            sh = *reinterpret_cast<const f32x4*>(p.shift + co);
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int rowi = it * 16 + (gt >> 4);            // (tile, pixel) row of this half: 256 rows
-            const int tl = rowi >> 4, px = rowi & 15;
-            const int pix = tinfo[2 * (wm * 16 + tl)], vv = tinfo[2 * (wm * 16 + tl) + 1];
-            const int py = px >> 2, pxx = px & 3;
-            if (py < (vv & 0xff) && pxx < (vv >> 8) && co < p.Cout) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(cs + rowi * RS + c4);
-                v = v * sc + sh;
-                if (p.act) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
-                }
-                const size_t o = (size_t)(pix + py * p.W + pxx) * p.Cout + co;
-                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
-                *reinterpret_cast<f32x4*>(p.y + o) = v;
+            for (int j = 0; j < 5; ++j) {
+                const int i = wave + 8 * j;
+                const int k = i / 6, l = i - 6 * k;
+                const int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + l;
+                const bool ok = tok && i < 36 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                dvoff[j] = ok ? (unsigned)((((n * p.H + yy) * p.W + xx) * p.Cin) * 4 + (lane & 1) * 16) : OOB;
             }
         }
+        auto dma_raw = [&](int ks, int buf) {
+            const unsigned so = (unsigned)(ks * KC) * 4u;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (wave + 8 * j < 36) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + 8 * j) * PLANE, dvoff[j], so);
+        };
+        auto transform = [&](int bufr, int bufv) {
+            const unsigned char* rs = smem + RAW_OFF + bufr * STAGE + st_off;
+            unsigned char* vs = smem + bufv * STAGE + st_off;
+            if (job == 0) transform_job<0>(rs, vs);
+            else if (job == 1) transform_job<1>(rs, vs);
+            else if (job == 2) transform_job<2>(rs, vs);
+            else transform_job<3>(rs, vs);
+        };
+
+        f32x4 acc[36];
+#pragma unroll
+        for (int pos = 0; pos < 36; ++pos) acc[pos] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned b_voff = (n0 + wn * 16 + row16 < p.Cout)
+            ? (unsigned)(((n0 + wn * 16 + row16) * KC + quart * 2) * 4) : OOB;
+        f32x2 bq[BDEPTH];
+        auto issue_b = [&](int slot, int pos, int ks) {
+            bq[slot] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                rs_u, b_voff, (unsigned)pos * b_pos_stride + (unsigned)ks * b_ks_stride, 0));
+        };
+
+        // ---- prologue: raw(ks0), raw(ks0+1) by DMA; V(ks0) = transform(raw(ks0)); the first weight fragments ---------------
+        dma_raw(ks0, 0);
+        if (ks0 + 1 < ks1) dma_raw(ks0 + 1, 1);
+#pragma unroll
+        for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, ks0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // the DMAs are older than the fragment loads
+        __builtin_amdgcn_s_barrier();
+        transform(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int cur = (ks - ks0) & 1;
+            const bool more = ks + 1 < ks1;
+            if (ks + 2 < ks1) dma_raw(ks + 2, cur);            // raw[cur] held raw(ks): consumed a K-step ago
+            // V(ks+1) from raw(ks+1) - it landed before the last barrier - next to the MFMAs on V(ks) (on the last K-step it
+            // transforms stale data into a buffer nobody reads: keeps the K-step's shape)
+            transform(cur ^ 1, cur ^ 1);
+            const unsigned char* vs = smem + cur * STAGE + a_off;
+            constexpr int AD = 3;                                  // activation fragments read ahead
+            f32x2 aq[AD];
+#pragma unroll
+            for (int s = 0; s < AD; ++s) aq[s] = *reinterpret_cast<const f32x2*>(vs + s * PLANE);
+#pragma unroll
+            for (int pos = 0; pos < 36; ++pos) {
+                const f32x2 a = aq[pos % AD];
+                const f32x2 b = bq[pos % BDEPTH];
+                if (pos + AD < 36) aq[pos % AD] = *reinterpret_cast<const f32x2*>(vs + (pos + AD) * PLANE);
+                // refill the slot with the fragment BDEPTH positions ahead (it runs on into the next K-step; past the last
+                // K-step it re-reads a valid address and is never used)
+                {
+                    const int np = pos + BDEPTH;
+                    if (np < 36) issue_b(pos % BDEPTH, np, ks);
+                    else issue_b(pos % BDEPTH, np - 36, more ? ks + 1 : ks);
+                }
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[pos], 0, 0, 0);
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[pos], 0, 0, 0);
+                // keep the software pipeline as written: left alone, hipcc's scheduler moves every fragment read right in
+                // front of its MFMAs (lgkmcnt(0) / vmcnt(1..3) ahead of each pair: the LDS and L2 latencies in full, 72 times)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // this K-step's DMA has landed (older than the window)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the window's last, unused fragments: their registers are reused)
+
+        // ---- tail: A^T M A in registers -> LDS ([tile][pixel][64 channels] per 16-tile half: the K-loop's buffers are free
+        //      now) -> either the partial-sum slot (producer) or (+ the other pieces' sums) scale / shift / LeakyReLU /
+        //      residual on 16-byte pieces, 256 contiguous bytes per output pixel ------------------------------------------
+        if (tid < BT) {
+            const int t = t0 + tid;
+            int pix = 0, vv = 0;
+            if (t < p.T) {
+                const int n = t / (p.TH * p.TW);
+                const int r = t - n * p.TH * p.TW;
+                const int ty = r / p.TW, tx = r - ty * p.TW;
+                pix = (n * p.H + 4 * ty) * p.W + 4 * tx;
+                vv = min(4, p.H - 4 * ty) | (min(4, p.W - 4 * tx) << 8);
+            }
+            tinfo[2 * tid] = pix;
+            tinfo[2 * tid + 1] = vv;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // 16x16 accumulator: row (tile) = 4 * (lane / 16) + r, column (channel) = lane % 16
+            float tq[6][4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float m0 = acc[i * 6 + 0][r], m1 = acc[i * 6 + 1][r], m2 = acc[i * 6 + 2][r], m3 = acc[i * 6 + 3][r],
+                            m4 = acc[i * 6 + 4][r], m5 = acc[i * 6 + 5][r];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                tq[i][0] = m0 + s1 + s2;
+                tq[i][1] = d1 + 2.f * d2;
+                tq[i][2] = s1 + 4.f * s2;
+                tq[i][3] = d1 + 8.f * d2 + m5;
+            }
+            float* row = cs + ((quart * 4 + r) * 16) * RS + wn * 16 + row16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s1 = tq[1][q] + tq[2][q], d1 = tq[1][q] - tq[2][q], s2 = tq[3][q] + tq[4][q], d2 = tq[3][q] - tq[4][q];
+                row[(0 * 4 + q) * RS] = tq[0][q] + s1 + s2;
+                row[(1 * 4 + q) * RS] = d1 + 2.f * d2;
+                row[(2 * 4 + q) * RS] = s1 + 4.f * s2;
+                row[(3 * 4 + q) * RS] = d1 + 8.f * d2 + tq[5][q];
+            }
+        }
+        __syncthreads();
+        const int gt = tid & 255;                          // thread inside the 16-tile half (four waves)
+        const int c4 = (gt & 15) * 4;
+        if (producer) {
+            // later K-steps of a cut block: publish the output-space sums, write-through, then the flag
+            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial, 0, (unsigned)((size_t)W * SLOT_FLOATS * 4), 0x00020000);
+            const unsigned slot_off = (unsigned)blockIdx.x * (unsigned)(SLOT_FLOATS * 4);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int rowi = it * 16 + (gt >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + rowi * RS + c4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_part,
+                                                       slot_off + (unsigned)(((wm * 256 + rowi) * BNC + c4) * 4), 0, 16);   // aux 16 = sc1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && !p.fault)
+                __hip_atomic_store((gu32*)(p.flags + blockIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (n_extra > 0) {
+                if (tid == 0) {
+                    for (int e = 1; e <= n_extra; ++e) {
+                        gu32* flag = (gu32*)(p.flags + blockIdx.x - e);
+                        unsigned spins = 0;
+                        for (; spins < p.spin_limit; ++spins) {
+                            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (spins == p.spin_limit && p.err)
+                            __hip_atomic_fetch_or(p.err, Y3_ERR_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+            }
+            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+                p.partial, 0, n_extra ? (unsigned)((size_t)W * SLOT_FLOATS * 4) : 0u, 0x00020000);
+            const int co = n0 + c4;
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (co < p.Cout) {
+                sc = *reinterpret_cast<const f32x4*>(p.scale + co);
+                sh = *reinterpret_cast<const f32x4*>(p.shift + co);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int rowi = it * 16 + (gt >> 4);            // (tile, pixel) row of this half: 256 rows
+                const int tl = rowi >> 4, px = rowi & 15;
+                const int pix = tinfo[2 * (wm * 16 + tl)], vv = tinfo[2 * (wm * 16 + tl) + 1];
+                const int py = px >> 2, pxx = px & 3;
+                f32x4 v = *reinterpret_cast<const f32x4*>(cs + rowi * RS + c4);
+                for (int e = 1; e <= n_extra; ++e)               // the other pieces, in worker order (deterministic)
+                    v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                             rs_part, (unsigned)(((wm * 256 + rowi) * BNC + c4) * 4),
+                             (unsigned)(blockIdx.x - e) * (unsigned)(SLOT_FLOATS * 4), 17));   // aux 17 = sc0 sc1 (see y3_conv_wino.hip)
+                if (py < (vv & 0xff) && pxx < (vv >> 8) && co < p.Cout) {
+                    v = v * sc + sh;
+                    if (p.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    }
+                    const size_t o = (size_t)(pix + py * p.W + pxx) * p.Cout + co;
+                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    *reinterpret_cast<f32x4*>(p.y + o) = v;
+                }
+            }
+        }
+        __syncthreads();          // the next segment's DMA overwrites the staging tile
     }
 }
 
@@ -363,8 +467,17 @@ int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int 
     return Y3_OK;
 }
 
+constexpr int W44_WORKERS = 256;     // one persistent workgroup per CU (147 KB of LDS, eight waves)
+constexpr size_t W44_FLAGS_OFFSET = (size_t)W44_WORKERS * SLOT_FLOATS * sizeof(float);
+
+size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d) {
+    if (!y3_conv_wino44_eligible_impl(d)) return 0;
+    return W44_FLAGS_OFFSET + (size_t)W44_WORKERS * sizeof(unsigned);
+}
+
 int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
-                          const float* shift, const float* residual, float* y) {
+                          const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes,
+                          const y3_sk_opts* sk) {
     Y3_CHECK_ARG(d && x && u && scale && shift && y, "y3_conv2d_fwd_wino44: null pointer argument");
     Y3_CHECK_ARG(y3_conv_wino44_eligible_impl(d),
                  "y3_conv2d_fwd_wino44: needs a 3x3 stride-1 conv with Cin %% 32 == 0 and Cout %% 64 == 0, no fused upsample input");
@@ -375,6 +488,7 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
     a.TH = (d->h + 3) / 4; a.TW = (d->w + 3) / 4; a.T = d->n * a.TH * a.TW;
+    a.partial = nullptr; a.flags = nullptr; a.err = nullptr; a.spin_limit = 0; a.workers = 0; a.fault = 0;
     static bool attr_set = false;      // benign race (idempotent)
     if (!attr_set) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino44_f32_kernel),
@@ -382,7 +496,31 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
         attr_set = true;
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = d->cout / BNC;
-    hipLaunchKernelGGL(conv_wino44_f32_kernel, dim3(nbt * nbn), dim3(NTH), 4 * STAGE, stream, a);
+    const int blocks = nbt * nbn, ksteps = d->cin / KC;
+    // Persistent schedule when the last round of blocks would run partly empty and every worker gets at least two K-steps
+    // of the cut blocks; Y3_CONV_WINO44_STREAMK=0/1 overrides (experiment hook)
+    static const int force = getenv("Y3_CONV_WINO44_STREAMK") ? atoi(getenv("Y3_CONV_WINO44_STREAMK")) : -1;
+    const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino44_workspace_bytes_impl(d) &&
+                        ((uintptr_t)workspace & 15) == 0;
+    const int rem = blocks % W44_WORKERS;
+    bool use_sk = has_ws && blocks > W44_WORKERS && rem != 0 && (long long)rem * ksteps >= 2LL * W44_WORKERS;
+    if (force == 0) use_sk = false;
+    if (force == 1) use_sk = has_ws && blocks >= W44_WORKERS && (long long)rem * ksteps >= W44_WORKERS;
+    if (use_sk) {
+        a.partial = static_cast<float*>(workspace);
+        a.workers = W44_WORKERS;
+        a.err = sk ? sk->err : nullptr;
+        y3_sk_debug_env(&a.spin_limit, &a.fault);
+        if (sk && sk->flags) {
+            a.flags = sk->flags;       // pre-zeroed by the caller (y3_net_forward: one memset per forward)
+        } else {
+            a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + W44_FLAGS_OFFSET);
+            Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)W44_WORKERS * sizeof(unsigned), stream));
+        }
+        hipLaunchKernelGGL(conv_wino44_f32_kernel, dim3(W44_WORKERS), dim3(NTH), 4 * STAGE, stream, a);
+    } else {
+        hipLaunchKernelGGL(conv_wino44_f32_kernel, dim3(blocks), dim3(NTH), 4 * STAGE, stream, a);
+    }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

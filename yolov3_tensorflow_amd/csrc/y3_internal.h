@@ -95,8 +95,10 @@ int y3_conv_wino_eligible_impl(const y3_conv_desc* d);
 int y3_conv_wino44_eligible_impl(const y3_conv_desc* d);
 int y3_conv_wino44_preferred_impl(const y3_conv_desc* d);
 int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out);
+size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d);
 int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
-                          const float* shift, const float* residual, float* y);
+                          const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes,
+                          const y3_sk_opts* sk);
 int y3_conv_wgrad_wino_eligible_impl(const y3_conv_desc* d);
 size_t y3_conv_wgrad_wino_scratch_bytes_impl(const y3_conv_desc* d);
 int y3_launch_conv_wgrad_wino(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* dz, int dz_stride,

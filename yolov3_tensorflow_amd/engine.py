@@ -207,13 +207,19 @@ def pack_wino44(w_hwio):
     return out
 
 
-def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None):
-    """3x3 stride-1 conv in its Winograd F(4x4,3x3) form (y3_conv2d_fwd_wino44, inference); w_wino44 from pack_wino44."""
+def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None, use_workspace=True):
+    """3x3 stride-1 conv in its Winograd F(4x4,3x3) form (y3_conv2d_fwd_wino44, inference); w_wino44 from pack_wino44.
+    use_workspace=False forces the one-workgroup-per-block schedule."""
     n, h, w, cin = x.shape
     d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 1 if act else 0)
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().y3_conv2d_fwd_wino44(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44),
-                                               fw.ptr(scale), fw.ptr(shift), fw.ptr(residual), fw.ptr(y)))
+    L = _lib.lib()
+    ws, ws_bytes = None, 0
+    if use_workspace:
+        ws_bytes = L.y3_conv_wino44_workspace_bytes(ctypes.byref(d))
+        ws = _conv_scratch(x.device, ws_bytes) if ws_bytes else None
+    _lib.check(L.y3_conv2d_fwd_wino44(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44), fw.ptr(scale),
+                                      fw.ptr(shift), fw.ptr(residual), fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y
 
 
