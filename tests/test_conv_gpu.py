@@ -323,8 +323,11 @@ def test_streamk_timeout_is_loud(monkeypatch):
     wp = torch.empty(9 * cout * cin, device=dev)
     _lib.check(_lib.lib().y3_pack_conv_weights(fw.context(), fw.ptr(wt), 3, cin, cout, fw.ptr(wp)))
     wu = engine.pack_wino(wt)
+    x16 = torch.cat([x, x * 0.5])                      # 16 images: 85 x 4 = 340 F(4x4) blocks, 84 of them cut along K
+    wu44 = engine.pack_wino44(wt)
     runs = {'direct': lambda: engine.conv2d_fwd(x, wp, ones, zeros, 3, 1, cout, True),
-            'wino': lambda: engine.conv2d_fwd_wino(x, wu, ones, zeros, cout, True)}
+            'wino': lambda: engine.conv2d_fwd_wino(x, wu, ones, zeros, cout, True),
+            'wino44': lambda: engine.conv2d_fwd_wino44(x16, wu44, ones, zeros, cout, True)}
     fw.check_context()
     try:
         for name, run in runs.items():

@@ -420,8 +420,7 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
             : (net->dtype == 4 && y3_conv_wino44_preferred_impl(&d))
-            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
-                                    base + net->arena_bytes, net->scratch_bytes, &o)
+            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst), nullptr, 0, &o)
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
             ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   base + net->arena_bytes, net->scratch_bytes, &o)

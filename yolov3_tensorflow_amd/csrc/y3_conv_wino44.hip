@@ -497,15 +497,16 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = d->cout / BNC;
     const int blocks = nbt * nbn, ksteps = d->cin / KC;
-    // Persistent schedule when the last round of blocks would run partly empty and every worker gets at least two K-steps
-    // of the cut blocks; Y3_CONV_WINO44_STREAMK=0/1 overrides (experiment hook)
+    // Persistent schedule: only when the caller hands in a workspace, the last round of blocks would run partly empty and
+    // every worker gets at least two K-steps of the cut blocks.  (y3_net_forward hands in NONE: inside the bs=32 416x416
+    // forward one workgroup per block measured 11.72-11.74 ms per batch against 11.75-11.79 - the second, partly empty
+    // round of blocks runs faster than a full one, and a cut block pays a second prologue and a 128 KB hand-off; stand-alone
+    // the 26-grid 256->512 conv gains 5 %, the 52-grid one nothing.)  Y3_CONV_WINO44_STREAMK=0 turns it off everywhere.
     static const int force = getenv("Y3_CONV_WINO44_STREAMK") ? atoi(getenv("Y3_CONV_WINO44_STREAMK")) : -1;
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino44_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     const int rem = blocks % W44_WORKERS;
-    bool use_sk = has_ws && blocks > W44_WORKERS && rem != 0 && (long long)rem * ksteps >= 2LL * W44_WORKERS;
-    if (force == 0) use_sk = false;
-    if (force == 1) use_sk = has_ws && blocks >= W44_WORKERS && (long long)rem * ksteps >= W44_WORKERS;
+    const bool use_sk = force != 0 && has_ws && blocks > W44_WORKERS && rem != 0 && (long long)rem * ksteps >= 2LL * W44_WORKERS;
     if (use_sk) {
         a.partial = static_cast<float*>(workspace);
         a.workers = W44_WORKERS;

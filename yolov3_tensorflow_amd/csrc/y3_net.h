@@ -183,8 +183,6 @@ struct y3_net {
             if (dtype == 1) break;   // the bf16 kernels use no stream-K scratch
             scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
             if (dtype == 4) scratch_bytes = std::max(scratch_bytes, y3_conv_wino_workspace_bytes_impl(&d));
-            if (dtype == 4 && y3_conv_wino44_preferred_impl(&d))
-                scratch_bytes = std::max(scratch_bytes, y3_conv_wino44_workspace_bytes_impl(&d));
         }
         scratch_bytes = (scratch_bytes + 255) & ~(size_t)255;
         flags_bytes = scratch_bytes ? layers.size() * FLAG_WORDS * sizeof(unsigned) : 0;
