@@ -1,5 +1,5 @@
-// Winograd F(4x4, 3x3) form of the stride-1 3x3 conv (+ folded BN + LeakyReLU + residual) for INFERENCE, exact fp32
-// arithmetic on v_mfma_f32_16x16x4_f32.  Replaces the same reference code as y3_conv.hip / y3_conv_wino.hip
+// Winograd F(4x4, 3x3) form of the stride-1 3x3 conv (+ folded BN + LeakyReLU + residual) for INFERENCE, fp32
+// arithmetic (products and sums in fp32; the transforms round, see the numerics line below) on v_mfma_f32_16x16x4_f32.  Replaces the same reference code as y3_conv.hip / y3_conv_wino.hip
 // (utils/layer_utils.py:9-22,25-32): 36 multiplies per 4x4 output tile and channel pair instead of 144 (direct) or 64
 // (F(2x2,3x3)) - 1.78x less MFMA work than y3_conv_wino.hip.
 //
@@ -13,17 +13,22 @@
 //     16 tiles x 16 channels of every position as v_mfma_f32_16x16x4_f32 accumulators (36 x 4 = 144 registers, two waves
 //     per SIMD), so the 36 position sums of one (tile, channel) sit in ONE lane and A^T M A needs no exchange between
 //     waves at all;
-//   * K-step = 8 input channels = 72 MFMAs per wave.  The B^T d B tile of the NEXT K-step is staged through the LDS
-//     ([2][36][32 tiles][32 B], 72 KB): thread (tile, channel pair, job) loads the patch rows its job needs as 8-byte
-//     bounds-checked loads (padding = out of range = 0), transforms them on float2s and writes one or two rows of the 6x6
-//     result (jobs: row 0 | rows 1,2 | rows 3,4 | row 5 - the paired rows share their first pass).  Weight fragments never
-//     touch the LDS: a lane's 8 bytes of U[pos][cout][2 channels] come straight from global memory (512 contiguous bytes
-//     per wave load) through a rolling window of registers that runs ahead across K-step boundaries;
-//   * channel k of the 8 plays "k" in MFMA (k / 2 % ... ) as both operands agree: lane quarter q = lane / 16 reads channels
-//     2q, 2q+1 (one ds_read_b64 / one 8-byte load) and MFMA m = 0, 1 consumes channel 2q + m;
-//   * epilogue: A^T M A per accumulator register in registers (120 adds / multiplies by 2, 4, 8 per 4x4 tile), scale /
-//     shift, LeakyReLU, residual, stores.
-// One block per workgroup, no stream-K: inference layers of the network give 256-5,408 blocks.
+//   * K-step = 8 input channels = 72 MFMAs per wave, ONE barrier.  Raw 6x6 patches go global -> LDS by DMA
+//     (buffer_load ... lds: no registers, padding = out-of-range lanes = zeros), two K-steps ahead; inside a K-step thread
+//     (tile, channel pair, job) reads the patch rows its job needs from the LDS, transforms them on float2s and writes one
+//     or two rows of B^T d B for the NEXT K-step (jobs: row 0 | rows 1,2 | rows 3,4 | row 5 - paired rows share their first
+//     pass); then the MFMAs of THIS K-step: activation fragments from the LDS three positions ahead, weight fragments -
+//     a lane's 8 bytes of U[pos][cout][2 channels], 512 contiguous bytes per wave load - straight from global memory through
+//     a rolling window of nine registers pairs that runs on across K-step boundaries.  The order is pinned with scheduling
+//     barriers: left alone, hipcc moves every fragment read right in front of its MFMAs;
+//   * lane quarter q = lane / 16 reads channels 2q, 2q+1 of both operands (one ds_read_b64 / one 8-byte load) and MFMA
+//     m = 0, 1 consumes channel 2q + m - which of the 8 channels plays "k" where is free as long as both operands agree;
+//   * tail: A^T M A per accumulator register in registers (120 adds / multiplies by 2, 4, 8 per 4x4 tile), staged through
+//     the LDS ([tile][pixel][64 channels]) so that scale / shift, LeakyReLU and the residual run on 16-byte pieces and an
+//     output pixel's 64 channels leave as 256 contiguous bytes;
+//   * with a workspace: persistent schedule (whole rounds of blocks, the remaining blocks cut along K and finished inside
+//     the kernel, same hand-off as y3_conv_wino.hip).  y3_net_forward does not use it (profiles/r03_wino44.txt has the
+//     measurements, and those of every variant tried on the way).
 #include <cstdlib>
 #include "y3_internal.h"
 
