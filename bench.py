@@ -543,6 +543,19 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
             "regimes": regimes}
 
 
+def layer_input_grids(table, size):
+    """Input grid (pixels per side) of each of the 75 convs: the body halves it at every stride-2 conv (416 -> 13), the
+    head runs at 13, 26 (from layer 60 on) and 52 (from layer 68 on)."""
+    grids, g = [], size
+    for li, (k, s, cin, cout, bn) in enumerate(table):
+        if li == 60 or li == 68:
+            g *= 2
+        grids.append(g)
+        if s == 2:
+            g //= 2
+    return grids
+
+
 def winograd_issue_factors(table, precision, size):
     """Per layer: (is_winograd, MFMA work ISSUED / direct-convolution FLOPs) for the kernel the library runs in `precision`.
     F(2x2,3x3) layers issue 16/36 of the direct count; the layers y3_conv_wino44_preferred names run F(4x4,3x3) in the
@@ -550,15 +563,13 @@ def winograd_issue_factors(table, precision, size):
     256/169).  The factor follows the library's own choice, so `achieved` never counts work a kernel did not issue."""
     from yolov3_tensorflow_amd import engine
     is_w, fac = [], []
-    grid = size
-    for (k, s, cin, cout, bn) in table:
-        g_in = grid
-        if s == 2:
-            grid //= 2
+    grid_of = layer_input_grids(table, size)
+    for li, (k, s, cin, cout, bn) in enumerate(table):
+        g_in = grid_of[li]
         w = precision == 'f32_wino' and bool(engine.wino_eligible(k, s, cin, cout))
         f = 1.0
         if w:
-            if engine.wino44_preferred(k, s, cin, cout):
+            if engine.wino44_preferred(BATCH, g_in, g_in, k, s, cin, cout):
                 t = -(-g_in // 4) * 4
                 f = (36.0 / 144.0) * (t * t) / float(g_in * g_in)
             else:

@@ -153,7 +153,8 @@ int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const
  * y3_pack_conv_weights_wino44.  Results differ from the direct kernel by fp32 roundings of the transforms (measured on the
  * whole network: boxes 1.0e-5 of the box scale from the fp64 oracle, 6.3e-6 for the direct sum). */
 int y3_conv_wino44_eligible(const y3_conv_desc* d);
-int y3_conv_wino44_preferred(const y3_conv_desc* d);   /* the layers y3_net_forward (dtype 4) gives to this kernel */
+int y3_conv_wino44_candidate(const y3_conv_desc* d);   /* by shape: the convs worth an alternative packing (y3_net_set_layer_alt) */
+int y3_conv_wino44_preferred(const y3_conv_desc* d);   /* for THIS n, h, w: a candidate with enough blocks to fill the CUs */
 int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino44);
 size_t y3_conv_wino44_workspace_bytes(const y3_conv_desc* d);   /* scratch of the persistent schedule; workspace = NULL is allowed */
 int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44, const float* scale,
@@ -226,14 +227,16 @@ int y3_net_destroy(y3_net* net);
  * intermediate activations are bf16, the three feature maps stay fp32.  2 / 3 = fp32 tensors with the products on
  * the bf16 matrix pipe (y3_conv2d_fwd_split with planes = 3 / 2): layer weights from y3_pack_conv_weights_split.
  * 4 = fp32 with the Winograd kernel for the layers y3_conv_wino_eligible accepts (their weights from
- * y3_pack_conv_weights_wino) - except those y3_conv_wino44_preferred names, which y3_net_forward runs on the
- * F(4x4,3x3) kernel (their weights from y3_pack_conv_weights_wino44) - and the direct kernel for the rest.  (The train
- * step, y3_net_train_*, packs its own kernels every step and uses F(2x2,3x3) throughout.) */
+ * y3_pack_conv_weights_wino) and the direct kernel for the rest.  A layer y3_conv_wino44_candidate names may also get
+ * its F(4x4,3x3) packing (y3_net_set_layer_alt, weights from y3_pack_conv_weights_wino44): y3_net_forward then runs it on
+ * that kernel whenever y3_conv_wino44_preferred says the launch is large enough (bs=32 at 416x416: yes; bs=4: no).  (The
+ * train step, y3_net_train_*, packs its own kernels every step and uses F(2x2,3x3) throughout.) */
 int y3_net_set_dtype(y3_net* net, int dtype);
 int y3_net_num_layers(const y3_net* net);
 /* geometry of layer i for input-independent fields: k, stride, cin, cout, has_bn */
 int y3_net_layer_info(const y3_net* net, int i, int* k, int* stride, int* cin, int* cout, int* has_bn);
 int y3_net_set_layer(y3_net* net, int i, const float* w_packed, const float* scale, const float* shift);
+int y3_net_set_layer_alt(y3_net* net, int i, const float* w_wino44);   /* optional, dtype 4: see y3_net_set_dtype */
 size_t y3_net_workspace_bytes(const y3_net* net, int n, int h, int w);
 /* x [n,h,w,3] -> fm1 [n,h/32,w/32,3*(5+C)], fm2 (/16), fm3 (/8).  h,w multiples of 32. */
 int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* workspace,

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "y3_pack_conv_weights_wino": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "y3_conv_wino_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv_wino44_eligible": (c_int, [POINTER(ConvDesc)]),
+    "y3_conv_wino44_candidate": (c_int, [POINTER(ConvDesc)]),
     "y3_conv_wino44_preferred": (c_int, [POINTER(ConvDesc)]),
     "y3_pack_conv_weights_wino44": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "y3_conv_wino44_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
@@ -95,6 +96,7 @@ PROTOTYPES = {
     "y3_net_layer_info": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),
     "y3_net_set_layer": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "y3_net_set_layer_alt": (c_int, [c_void_p, c_int, c_void_p]),
     "y3_net_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "y3_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                c_void_p, c_void_p]),

@@ -189,6 +189,7 @@ extern "C" int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const floa
 }
 
 extern "C" int y3_conv_wino44_eligible(const y3_conv_desc* d) { return y3_conv_wino44_eligible_impl(d); }
+extern "C" int y3_conv_wino44_candidate(const y3_conv_desc* d) { return y3_conv_wino44_candidate_impl(d); }
 extern "C" int y3_conv_wino44_preferred(const y3_conv_desc* d) { return y3_conv_wino44_preferred_impl(d); }
 
 extern "C" int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino44) {
@@ -352,6 +353,12 @@ extern "C" int y3_net_set_layer(y3_net* net, int i, const float* w_packed, const
     return Y3_OK;
 }
 
+extern "C" int y3_net_set_layer_alt(y3_net* net, int i, const float* w_wino44) {
+    Y3_CHECK_ARG(net && i >= 0 && i < (int)net->layers.size(), "y3_net_set_layer_alt: bad layer index %d", i);
+    net->layers[i].w_alt = w_wino44;       // NULL: the layer runs on its y3_net_set_layer packing at every size
+    return Y3_OK;
+}
+
 static int check_size(const char* who, int n, int h, int w) {
     Y3_CHECK_ARG(n > 0, "%s: batch must be positive", who);
     Y3_CHECK_ARG(h > 0 && w > 0 && h % 32 == 0 && w % 32 == 0,
@@ -419,8 +426,8 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         const int rc = net->dtype == 1
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
-            : (net->dtype == 4 && y3_conv_wino44_preferred_impl(&d))
-            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst), nullptr, 0, &o)
+            : (net->dtype == 4 && l.w_alt && y3_conv_wino44_preferred_impl(&d))
+            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w_alt, l.scale, l.shift, ptr(l.resid), ptr(l.dst), nullptr, 0, &o)
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
             ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   base + net->arena_bytes, net->scratch_bytes, &o)

@@ -452,16 +452,32 @@ int y3_conv_wino44_eligible_impl(const y3_conv_desc* d) {
            d->n > 0 && d->h > 1 && d->w > 1;
 }
 
-// The layers y3_net_forward (dtype 4) runs on this kernel instead of the F(2x2,3x3) one: where it measured faster inside the
-// bs=32 416x416 forward (tools/layer_profile.py, profiles/r03_wino44.txt) - the 128->256 convs (52-grid: 0.245 -> 0.205 ms)
-// and the 512->1024 convs (13-grid: 0.241 -> 0.234 ms).  The 256->512 convs lose to block-count quantisation (392 blocks
-// on 256 CUs), the 32->64 / 64->128 ones to their 4-8 K-step blocks.  Y3_WINO44=0 turns the kernel off, =2 takes every
-// eligible layer (A/B runs).
-int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
+// The convs y3_net_forward (dtype 4) runs on this kernel instead of the F(2x2,3x3) one, given the alternative packing
+// (y3_net_set_layer_alt): where it measured faster inside the forward (tools/layer_profile.py, profiles/r03_wino44.txt).
+//   candidate (shape only: what a caller packs for): the 128->256 convs (52-grid at 416x416: 0.245 -> 0.205 ms at bs=32) and
+//     the 512->1024 convs (13-grid: 0.241 -> 0.234 ms).  The 256->512 convs lose to block-count quantisation (392 blocks on
+//     256 CUs), the 32->64 / 64->128 ones to their 4-8 K-step blocks;
+//   preferred (this launch): a candidate whose blocks - 32 tiles x 64 channels, one workgroup each, no K-split - fill at
+//     least three quarters of the 256 CUs.  Below that the F(2x2) kernel's stream-K schedule wins by keeping every CU busy:
+//     a bs=4 forward measured 3.74 ms with it against 4.77 ms with this kernel on 32-88 blocks per layer.
+// Y3_WINO44=0 turns the kernel off, =2 takes every eligible conv whatever its size (A/B runs).
+static int wino44_mode() {
     static const int mode = getenv("Y3_WINO44") ? atoi(getenv("Y3_WINO44")) : 1;
-    if (mode == 0 || !y3_conv_wino44_eligible_impl(d)) return 0;
-    if (mode == 2) return 1;
+    return mode;
+}
+
+int y3_conv_wino44_candidate_impl(const y3_conv_desc* d) {
+    if (wino44_mode() == 0 || !y3_conv_wino44_eligible_impl(d)) return 0;
+    if (wino44_mode() == 2) return 1;
     return (d->cin == 128 && d->cout == 256) || (d->cin == 512 && d->cout == 1024);
+}
+
+int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
+    if (!y3_conv_wino44_candidate_impl(d)) return 0;
+    if (wino44_mode() == 2) return 1;
+    const long long tiles = (long long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4);
+    const long long blocks = ((tiles + BT - 1) / BT) * (d->cout / BNC);
+    return blocks >= 192;
 }
 
 int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {

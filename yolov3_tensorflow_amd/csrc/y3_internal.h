@@ -93,7 +93,8 @@ int y3_launch_conv_split(hipStream_t stream, const y3_conv_desc* d, int planes, 
 int y3_conv_wino_eligible_impl(const y3_conv_desc* d);
 // F(4x4,3x3) inference kernel (y3_conv_wino44.hip)
 int y3_conv_wino44_eligible_impl(const y3_conv_desc* d);
-int y3_conv_wino44_preferred_impl(const y3_conv_desc* d);
+int y3_conv_wino44_candidate_impl(const y3_conv_desc* d);   // by shape (what to pack an alternative kernel for)
+int y3_conv_wino44_preferred_impl(const y3_conv_desc* d);   // for this launch (candidate + enough blocks to fill the CUs)
 int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out);
 size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d);
 int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,

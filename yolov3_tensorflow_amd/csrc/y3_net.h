@@ -17,6 +17,7 @@ struct Layer {
     int src, up, resid, dst;  // tensor ids (-1 = none)
     int c_up;
     const float *w, *scale, *shift;
+    const float* w_alt = nullptr;   // dtype 4: the F(4x4,3x3) packing of a y3_conv_wino44_candidate layer (y3_net_set_layer_alt)
 };
 
 struct y3_train_state;                       // y3_net_train.hip: what a training forward leaves for loss / backward

@@ -62,14 +62,28 @@ def prepare_conv_params_wino(w_var, bn_vars=None, bias_var=None, stride=1):
     k, _, cin, cout = w_var.shape
     if not wino_eligible(k, stride, cin, cout):
         return w32, scale, shift
-    f44 = wino44_preferred(k, stride, cin, cout)       # the layers y3_net_forward runs on the F(4x4,3x3) kernel
-    key = w_var.op_name + ('#wino44' if f44 else '#wino')
+    key = w_var.op_name + '#wino'
     hit = _param_cache.get(key)
     if hit is not None and hit[0] == w_var.version:
         return hit[1], scale, shift
-    wu = pack_wino44(w_var.tensor) if f44 else pack_wino(w_var.tensor)
+    wu = pack_wino(w_var.tensor)
     _param_cache[key] = (w_var.version, wu)
     return wu, scale, shift
+
+
+def prepare_conv_alt_wino44(w_var, stride=1):
+    """The F(4x4,3x3) packing of a layer y3_conv_wino44_candidate names (None for the others): y3_net_forward runs such a
+    layer on that kernel when the launch is large enough (y3_net_set_layer_alt)."""
+    k, _, cin, cout = w_var.shape
+    if not wino44_candidate(k, stride, cin, cout):
+        return None
+    key = w_var.op_name + '#wino44'
+    hit = _param_cache.get(key)
+    if hit is not None and hit[0] == w_var.version:
+        return hit[1]
+    wu = pack_wino44(w_var.tensor)
+    _param_cache[key] = (w_var.version, wu)
+    return wu
 
 
 def prepare_conv_params(w_var, bn_vars=None, bias_var=None):
@@ -193,9 +207,15 @@ def wino44_eligible(k, stride, cin, cout, c_up=0):
     return _lib.lib().y3_conv_wino44_eligible(ctypes.byref(d)) == 1
 
 
-def wino44_preferred(k, stride, cin, cout, c_up=0):
-    """True for the convs y3_net_forward gives to the F(4x4,3x3) kernel in 'f32_wino' mode (y3_conv_wino44_preferred)."""
+def wino44_candidate(k, stride, cin, cout, c_up=0):
+    """True for the conv shapes worth an F(4x4,3x3) packing beside the F(2x2,3x3) one (y3_conv_wino44_candidate)."""
     d = _lib.ConvDesc(1, 8, 8, cin, c_up, cout, k, stride, 0)
+    return _lib.lib().y3_conv_wino44_candidate(ctypes.byref(d)) == 1
+
+
+def wino44_preferred(n, h, w, k, stride, cin, cout, c_up=0):
+    """True when y3_net_forward ('f32_wino' mode) runs this conv - input [n, h, w, cin] - on the F(4x4,3x3) kernel."""
+    d = _lib.ConvDesc(n, h, w, cin, c_up, cout, k, stride, 0)
     return _lib.lib().y3_conv_wino44_preferred(ctypes.byref(d)) == 1
 
 

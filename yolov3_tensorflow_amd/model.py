@@ -106,7 +106,11 @@ class yolov3(object):
                     prep = engine.prepare_conv_params_bf16 if bf16 else engine.prepare_conv_params
                     wp, sc, sh = prep(w, bn_vars=bnv, bias_var=bias)
                 _lib.check(L.y3_net_set_layer(ent['handle'], i, fw.ptr(wp), fw.ptr(sc), fw.ptr(sh)))
-                keep.append((wp, sc, sh))
+                alt = None
+                if self.compute_dtype == 'f32_wino':       # the F(4x4,3x3) packing beside it, where the library wants one
+                    alt = engine.prepare_conv_alt_wino44(w, stride=ent['table'][i][1])
+                    _lib.check(L.y3_net_set_layer_alt(ent['handle'], i, fw.ptr(alt)))
+                keep.append((wp, sc, sh, alt))
             ent['keep'] = keep   # the library holds raw pointers: keep the tensors alive
             ent['version'] = fw.global_version()
         return ent
