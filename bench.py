@@ -19,19 +19,23 @@ Workloads
   c5 (configs[4]): the c2 forward with bf16 storage at 608x608, bs=16 per GPU.
 Prints ONE JSON line on rank 0.
 
-roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the
-Winograd F(2x2,3x3) kernel conv_wino8_f32_kernel (the stride-1 3x3 convs: 32 launches, ~65 % of the step).
-`achieved` = the MFMA work those launches ISSUE (16/36 of the direct-convolution FLOPs) / the sum of their durations,
+roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the two
+Winograd kernels of the stride-1 3x3 convs (32 launches, ~60 % of the step): conv_wino44_f32_kernel (F(4x4,3x3): the
+128->256 and 512->1024 convs when the launch fills the chip) and conv_wino8_f32_kernel (F(2x2,3x3): the others).
+`achieved` = the MFMA work those launches ISSUE - per layer 16/36 (F(2x2)) or 36/144 x tile padding (F(4x4)) of the
+direct-convolution FLOPs, by the kernel the library picks (winograd_issue_factors) - / the sum of their durations,
 measured with hipEvents recorded on the launch stream inside the timed region; `peak` = 157.3 TFLOP/s (fp32 MFMA);
 `frac` = achieved / peak.  `achieved_algorithmic` counts the direct-convolution FLOPs (it may exceed `peak`: Winograd
-needs 2.25x fewer multiplies).  `whole_forward_frac` = sum over the 75 layers of max(bytes / 8 TB/s, issued FLOPs /
-157.3 TF/s), divided by the measured ms_per_step.
+needs 2.25x / 4x fewer multiplies).  `whole_forward_frac` = sum over the 75 layers of max(bytes / 8 TB/s, issued FLOPs /
+157.3 TF/s), divided by the measured ms_per_step.  `traffic`: fabric-side bytes per launch from a committed rocprofv3
+--pmc pass, reported only when that pass was taken on the kernel sources of this build.
 fast_path / direct_path: after the timed region the same steps are repeated with other compute_dtypes and reported next
 to `value` with the max deviation between the feature maps.  Never `value`.
 cpu_baseline: the CPU oracle's torch-fp32 restatement of the same graph ("port"; the literal TF-CPU reference cannot run
-here: no TensorFlow), same weights, a bounded sample, rank 0 and N=1 only.
-box_delta_vs_oracle: outside the timed region, the decoded boxes/confs/probs of one image of the bench batch against the
-CPU oracle on that image (BASELINE metric: "box delta vs ref").
+here: no TensorFlow), same weights, ONE bounded sample, rank 0 and N=1 only.
+box_delta_vs_oracle: outside the timed region, the decoded boxes/confs/probs of all 32 images of the bench batch against
+the CPU oracle in fp32 and fp64 (BASELINE metric: "box delta vs ref"), with the fp32 oracle's own drift beside them.
+detect / c5 / c4: the other BASELINE configurations as secondary objects of the c2 line (measured after everything above).
 """
 import argparse
 import json
