@@ -149,7 +149,8 @@ int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const
  * round of the 256 resident workgroups run a persistent schedule: whole rounds of blocks first, the remaining blocks cut
  * along K and finished inside the kernel (same hand-off protocol and failure reporting as y3_conv2d_fwd_wino).  y3_conv_wino44_eligible accepts
  * (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cout %% 64 == 0).  w_wino44 = G g G^T with the 6x3 G of the
- * interpolation points 0, +-1, +-2, inf, packed [36][cin/8][cout][8] fp32 (36*cin*cout floats) by
+ * interpolation points 0, +-1, +-2, inf, packed [18 position pairs][cin/8][cout][4 channel pairs][2 positions][2 channels]
+ * fp32 (36*cin*cout floats: an opaque layout, what the kernel's 16-byte fragment loads want) by
  * y3_pack_conv_weights_wino44.  Results differ from the direct kernel by fp32 roundings of the transforms (measured on the
  * whole network: boxes 1.0e-5 of the box scale from the fp64 oracle, 6.3e-6 for the direct sum). */
 int y3_conv_wino44_eligible(const y3_conv_desc* d);

@@ -8,7 +8,8 @@
 //   restatement of the whole forward against the fp64 oracle): boxes 1.0e-5 of the box scale against 7.5e-6 for F(2x2,3x3)
 //   and 6.3e-6 for the direct sum - a hundred times inside the 1e-3 of the north star.
 //
-//   * weights U = G g G^T transformed once at load time and packed [36][Cin/8][Cout][8] (y3_pack_conv_weights_wino44);
+//   * weights U = G g G^T transformed once at load time and packed [18 position pairs][Cin/8][Cout][4 channel pairs][2 positions]
+//     [2 channels] (y3_pack_conv_weights_wino44): a lane's fragments of two neighbouring positions are 16 contiguous bytes;
 //   * a workgroup = eight waves owns 32 tiles x 64 output channels for ALL 36 transform positions; wave (wm, wn) holds
 //     16 tiles x 16 channels of every position as v_mfma_f32_16x16x4_f32 accumulators (36 x 4 = 144 registers, two waves
 //     per SIMD), so the 36 position sums of one (tile, channel) sit in ONE lane and A^T M A needs no exchange between
@@ -17,9 +18,9 @@
 //     (buffer_load ... lds: no registers, padding = out-of-range lanes = zeros), two K-steps ahead; inside a K-step thread
 //     (tile, channel pair, job) reads the patch rows its job needs from the LDS, transforms them on float2s and writes one
 //     or two rows of B^T d B for the NEXT K-step (jobs: row 0 | rows 1,2 | rows 3,4 | row 5 - paired rows share their first
-//     pass); then the MFMAs of THIS K-step: activation fragments from the LDS three positions ahead, weight fragments -
-//     a lane's 8 bytes of U[pos][cout][2 channels], 512 contiguous bytes per wave load - straight from global memory through
-//     a rolling window of nine registers pairs that runs on across K-step boundaries.  The order is pinned with scheduling
+//     pass); then the MFMAs of THIS K-step: activation fragments from the LDS four positions ahead, weight fragments -
+//     a lane's 16 bytes for two positions, 1 KB contiguous per wave load - straight from global memory through a rolling
+//     window of six loads (twelve positions) that runs on across K-step boundaries.  The order is pinned with scheduling
 //     barriers: left alone, hipcc moves every fragment read right in front of its MFMAs;
 //   * lane quarter q = lane / 16 reads channels 2q, 2q+1 of both operands (one ds_read_b64 / one 8-byte load) and MFMA
 //     m = 0, 1 consumes channel 2q + m - which of the 8 channels plays "k" where is free as long as both operands agree;
@@ -39,7 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct W44Args {
     const float* x;      // [N,H,W,Cin]
-    const float* u;      // packed [36][Cin/8][Cout][8]
+    const float* u;      // packed [18 position pairs][Cin/8][Cout][4 channel pairs][2 positions][2 channels]
     const float* scale;  // [Cout]
     const float* shift;  // [Cout]
     const float* resid;  // [N,H,W,Cout] or nullptr
@@ -61,7 +62,8 @@ constexpr int ROWB = KC * 4;                   // LDS bytes per (position, tile)
 constexpr int PLANE = BT * ROWB;               // one position's tiles
 constexpr int STAGE = 36 * PLANE;              // 36,864 B
 constexpr unsigned OOB = 0x80000000u;
-constexpr int BDEPTH = 9;                      // weight fragments in flight per wave (divides 36: the window runs on across K-steps)
+constexpr int BDEPTH = 6;                      // weight fragment loads in flight per wave: one load = one lane's 16 bytes for a PAIR of
+                                               // positions (divides 18: the window runs on across K-steps)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) unsigned gu32;   // flags are only ever touched by agent-scope global atomics
@@ -170,8 +172,8 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
     const int st_off = (unit >> 2) * ROWB + (unit & 3) * 8;          // staging job: (tile, channel pair) inside a plane
     const int row16 = lane & 15, quart = lane >> 4;
     const int a_off = (wm * 16 + row16) * ROWB + quart * 8;          // activation fragment inside a position plane
-    const unsigned b_pos_stride = (unsigned)((size_t)ksteps * p.Cout * KC * 4);             // bytes between positions
-    const unsigned b_ks_stride = (unsigned)(p.Cout * KC * 4);
+    const unsigned b_pos_stride = (unsigned)((size_t)ksteps * p.Cout * 2 * KC * 4);         // bytes between position pairs
+    const unsigned b_ks_stride = (unsigned)(p.Cout * 2 * KC * 4);
     constexpr int RS = BNC + 4;                                      // staged output row stride in floats
     float* cs = reinterpret_cast<float*>(smem) + wm * (16 * 16 * RS);
     int* tinfo = reinterpret_cast<int*>(smem + 2 * 16 * 16 * RS * 4);     // [BT][2]: pixel index of the tile's corner, valid rows | cols << 8
@@ -239,19 +241,21 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
         f32x4 acc[36];
 #pragma unroll
         for (int pos = 0; pos < 36; ++pos) acc[pos] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // weights are packed [pos / 2][Cin / 8][Cout][lane quarter][pos % 2][2 channels]: a lane's fragments of two
+        // neighbouring positions are 16 contiguous bytes, a wave load 1 KB
         const unsigned b_voff = (n0 + wn * 16 + row16 < p.Cout)
-            ? (unsigned)(((n0 + wn * 16 + row16) * KC + quart * 2) * 4) : OOB;
-        f32x2 bq[BDEPTH];
-        auto issue_b = [&](int slot, int pos, int ks) {
-            bq[slot] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                rs_u, b_voff, (unsigned)pos * b_pos_stride + (unsigned)ks * b_ks_stride, 0));
+            ? (unsigned)(((n0 + wn * 16 + row16) * 2 * KC + quart * 4) * 4) : OOB;
+        f32x4 bq[BDEPTH];
+        auto issue_b = [&](int slot, int pair, int ks) {
+            bq[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_u, b_voff, (unsigned)pair * b_pos_stride + (unsigned)ks * b_ks_stride, 0));
         };
 
         // ---- prologue: raw(ks0), raw(ks0+1) by DMA; V(ks0) = transform(raw(ks0)); the first weight fragments ---------------
         dma_raw(ks0, 0);
         if (ks0 + 1 < ks1) dma_raw(ks0 + 1, 1);
 #pragma unroll
-        for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, ks0);
+        for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, ks0);      // pairs 0 .. BDEPTH-1
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // the DMAs are older than the fragment loads
         __builtin_amdgcn_s_barrier();
         transform(0, 0);
@@ -266,24 +270,29 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
             // transforms stale data into a buffer nobody reads: keeps the K-step's shape)
             transform(cur ^ 1, cur ^ 1);
             const unsigned char* vs = smem + cur * STAGE + a_off;
-            constexpr int AD = 3;                                  // activation fragments read ahead
+            constexpr int AD = 4;                                  // activation fragments read ahead (two pairs)
             f32x2 aq[AD];
 #pragma unroll
             for (int s = 0; s < AD; ++s) aq[s] = *reinterpret_cast<const f32x2*>(vs + s * PLANE);
 #pragma unroll
-            for (int pos = 0; pos < 36; ++pos) {
-                const f32x2 a = aq[pos % AD];
-                const f32x2 b = bq[pos % BDEPTH];
-                if (pos + AD < 36) aq[pos % AD] = *reinterpret_cast<const f32x2*>(vs + (pos + AD) * PLANE);
-                // refill the slot with the fragment BDEPTH positions ahead (it runs on into the next K-step; past the last
-                // K-step it re-reads a valid address and is never used)
-                {
-                    const int np = pos + BDEPTH;
-                    if (np < 36) issue_b(pos % BDEPTH, np, ks);
-                    else issue_b(pos % BDEPTH, np - 36, more ? ks + 1 : ks);
+            for (int pr = 0; pr < 18; ++pr) {
+                const f32x2 a0 = aq[(2 * pr) % AD], a1 = aq[(2 * pr + 1) % AD];
+                const f32x4 b = bq[pr % BDEPTH];
+                if (2 * pr + AD < 36) {
+                    aq[(2 * pr) % AD] = *reinterpret_cast<const f32x2*>(vs + (2 * pr + AD) * PLANE);
+                    aq[(2 * pr + 1) % AD] = *reinterpret_cast<const f32x2*>(vs + (2 * pr + 1 + AD) * PLANE);
                 }
-                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[pos], 0, 0, 0);
-                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[pos], 0, 0, 0);
+                // refill the slot with the pair BDEPTH pairs ahead (it runs on into the next K-step; past the last K-step it
+                // re-reads a valid address and is never used)
+                {
+                    const int np = pr + BDEPTH;
+                    if (np < 18) issue_b(pr % BDEPTH, np, ks);
+                    else issue_b(pr % BDEPTH, np - 18, more ? ks + 1 : ks);
+                }
+                acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b[0], acc[2 * pr], 0, 0, 0);
+                acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b[2], acc[2 * pr + 1], 0, 0, 0);
+                acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b[1], acc[2 * pr], 0, 0, 0);
+                acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b[3], acc[2 * pr + 1], 0, 0, 0);
                 // keep the software pipeline as written: left alone, hipcc's scheduler moves every fragment read right in
                 // front of its MFMAs (lgkmcnt(0) / vmcnt(1..3) ahead of each pair: the LDS and L2 latencies in full, 72 times)
                 __builtin_amdgcn_sched_barrier(0);
@@ -405,7 +414,7 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
     }
 }
 
-// U = G g G^T for every (ci, co), G the 6x3 matrix of F(4x4,3x3); out[pos][ci/8][co][ci%8]
+// U = G g G^T for every (ci, co), G the 6x3 matrix of F(4x4,3x3); out[pos/2][ci/8][co][(ci%8)/2][pos%2][ci%2]
 __global__ void __launch_bounds__(256) pack_weights_wino44_kernel(const float* __restrict__ w_hwio, float* __restrict__ out,
                                                                   int cin, int cout) {
     const long long total = (long long)cin * cout;
@@ -440,7 +449,11 @@ __global__ void __launch_bounds__(256) pack_weights_wino44_kernel(const float* _
                                 t0 * (1.f / 24.f) - t1 * (1.f / 12.f) + t2 * (1.f / 6.f), t2};
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                out[(((size_t)(a * 6 + b) * (cin / KC) + kb) * cout + co) * KC + cil] = u[b];
+            {
+                const int pos = a * 6 + b;
+                // [pos / 2][cin / 8][cout][channel pair = lane quarter][pos % 2][channel % 2]
+                out[((((size_t)(pos >> 1) * (cin / KC) + kb) * cout + co) * 2 * KC) + (cil >> 1) * 4 + (pos & 1) * 2 + (cil & 1)] = u[b];
+            }
         }
     }
 }

@@ -220,7 +220,7 @@ def wino44_preferred(n, h, w, k, stride, cin, cout, c_up=0):
 
 
 def pack_wino44(w_hwio):
-    """HWIO [3,3,cin,cout] fp32 device tensor -> the F(4x4,3x3) packing [36][cin/8][cout][8] (y3_pack_conv_weights_wino44)."""
+    """HWIO [3,3,cin,cout] fp32 device tensor -> the F(4x4,3x3) packing (36*cin*cout floats, y3_pack_conv_weights_wino44)."""
     _, _, cin, cout = w_hwio.shape
     out = torch.empty(36 * cin * cout, dtype=torch.float32, device=w_hwio.device)
     _lib.check(_lib.lib().y3_pack_conv_weights_wino44(fw.context(w_hwio.device), fw.ptr(w_hwio), cin, cout, fw.ptr(out)))
