@@ -18,34 +18,35 @@ import sys
 import numpy as np
 
 
+def _flag(text):
+    return str(text).lower() == 'true'
+
+
+# (option, type, default, help).  The first twelve are the reference's options (eval.py:22-60) with its defaults, except
+# restore_path, which names a darknet .weights file or a native .npz instead of a TF checkpoint.
+OPTIONS = (
+    ('eval_file', str, './data/my_data/val.txt', 'annotation txt file of the validation / test set'),
+    ('restore_path', str, './data/darknet_weights/yolov3.weights', 'darknet .weights file or native .npz checkpoint'),
+    ('anchor_path', str, './data/yolo_anchors.txt', 'anchor txt file'),
+    ('class_name_path', str, './data/coco.names', 'class names file'),
+    ('img_size', int, [416, 416], 'network input size as: width height'),
+    ('letterbox_resize', _flag, False, 'true: keep the aspect ratio and pad; false: plain stretch'),
+    ('num_threads', int, 10, 'accepted for compatibility, unused'),
+    ('prefetech_buffer', int, 5, 'accepted for compatibility, unused'),
+    ('nms_threshold', float, 0.45, 'IoU above which NMS suppresses a box'),
+    ('score_threshold', float, 0.01, 'class score below which a box is not a candidate'),
+    ('nms_topk', int, 400, 'most detections kept per class'),
+    ('use_voc_07_metric', _flag, False, 'true: the 11-point VOC 2007 AP'),
+    ('batch_size', int, 32, 'images per device batch (the reference evaluates one at a time)'),
+    ('compute_dtype', str, 'f32_wino', 'f32_wino (exact fp32, Winograd 3x3 kernels) | f32 | f32_bf16x6 (DESIGN.md 4.3-4.4)'),
+)
+
+
 def build_parser():
     parser = argparse.ArgumentParser(description="YOLO-V3 eval procedure.")
-    # some paths
-    parser.add_argument("--eval_file", type=str, default="./data/my_data/val.txt",
-                        help="The path of the validation or test txt file.")
-    parser.add_argument("--restore_path", type=str, default="./data/darknet_weights/yolov3.weights",
-                        help="The path of the darknet .weights file (or native .npz checkpoint) to restore.")
-    parser.add_argument("--anchor_path", type=str, default="./data/yolo_anchors.txt",
-                        help="The path of the anchor txt file.")
-    parser.add_argument("--class_name_path", type=str, default="./data/coco.names",
-                        help="The path of the class names.")
-    # some numbers
-    parser.add_argument("--img_size", nargs='*', type=int, default=[416, 416],
-                        help="Resize the input image to `img_size`, size format: [width, height]")
-    parser.add_argument("--letterbox_resize", type=lambda x: (str(x).lower() == 'true'), default=False,
-                        help="Whether to use the letterbox resize, i.e., keep the original image aspect ratio.")
-    parser.add_argument("--num_threads", type=int, default=10, help="(accepted for compatibility; unused)")
-    parser.add_argument("--prefetech_buffer", type=int, default=5, help="(accepted for compatibility; unused)")
-    parser.add_argument("--nms_threshold", type=float, default=0.45, help="IOU threshold in nms operation.")
-    parser.add_argument("--score_threshold", type=float, default=0.01,
-                        help="Threshold of the probability of the classes in nms operation.")
-    parser.add_argument("--nms_topk", type=int, default=400, help="Keep at most nms_topk outputs after nms.")
-    parser.add_argument("--use_voc_07_metric", type=lambda x: (str(x).lower() == 'true'), default=False,
-                        help="Whether to use the voc 2007 mAP metrics.")
-    # additions
-    parser.add_argument("--batch_size", type=int, default=32, help="Images per device batch (the reference uses 1).")
-    parser.add_argument("--compute_dtype", type=str, default="f32_wino",
-                        help="f32_wino (default: exact fp32, Winograd 3x3 kernels) | f32 | f32_bf16x6 (DESIGN.md 4.3-4.4)")
+    for name, kind, default, text in OPTIONS:
+        extra = {'nargs': '*'} if isinstance(default, list) else {}
+        parser.add_argument('--' + name, type=kind, default=default, help=text, **extra)
     return parser
 
 

@@ -1,23 +1,34 @@
 # coding: utf-8
-"""utils.plot_utils of the reference (ref: utils/plot_utils.py:9-34) for images in OpenCV's B,G,R order: the same colour
-table, boxes and captions drawn through the cv2 shim."""
+"""`utils.plot_utils` as the reference's scripts import it (ref: utils/plot_utils.py:9-34), for images held in OpenCV's
+B,G,R order: the package's colour table, and a labelled box drawn through the cv2 shim's primitives."""
 import random
 
 import cv2
 
 from yolov3_tensorflow_amd.utils.plot_utils import get_color_table          # noqa: F401
 
+_BLACK = [0, 0, 0]
+_FONT = 0           # cv2.FONT_HERSHEY_SIMPLEX
+
+
+def _caption(img, anchor, text, colour, stroke):
+    """`text` in black on a `colour` strip whose bottom-left corner is `anchor` (the box's top-left corner)."""
+    pen = max(stroke - 1, 1)
+    size = float(stroke) / 3
+    (wide, tall), _baseline = cv2.getTextSize(text, _FONT, fontScale=size, thickness=pen)
+    x, y = anchor
+    cv2.rectangle(img, anchor, (x + wide, y - tall - 3), colour, -1)
+    cv2.putText(img, text, (x, y - 2), _FONT, size, _BLACK, thickness=pen, lineType=cv2.LINE_AA)
+
 
 def plot_one_box(img, coord, label=None, color=None, line_thickness=None):
-    """Box `coord` = [x_min, y_min, x_max, y_max] on `img` in place, with `label` on a filled strip above it."""
-    thick = line_thickness or max(int(round(0.002 * max(img.shape[0:2]))), 1)
-    color = color or [random.randint(0, 255) for _ in range(3)]
-    top_left = (int(coord[0]), int(coord[1]))
-    cv2.rectangle(img, top_left, (int(coord[2]), int(coord[3])), color, thickness=thick)
+    """Draw the box coord = [x_min, y_min, x_max, y_max] on `img` in place; `label`, when given, goes on a filled strip
+    above it.  No colour -> a random one; no thickness -> 0.2 % of the longer image side, at least one pixel."""
+    if not line_thickness:
+        line_thickness = max(int(round(0.002 * max(img.shape[:2]))), 1)
+    if not color:
+        color = [random.randint(0, 255), random.randint(0, 255), random.randint(0, 255)]
+    x0, y0, x1, y1 = [int(v) for v in coord[:4]]
+    cv2.rectangle(img, (x0, y0), (x1, y1), color, thickness=line_thickness)
     if label:
-        font_thick = max(thick - 1, 1)
-        scale = float(thick) / 3
-        (tw, th), _ = cv2.getTextSize(label, 0, fontScale=scale, thickness=font_thick)
-        cv2.rectangle(img, top_left, (top_left[0] + tw, top_left[1] - th - 3), color, -1)
-        cv2.putText(img, label, (top_left[0], top_left[1] - 2), 0, scale, [0, 0, 0], thickness=font_thick,
-                    lineType=cv2.LINE_AA)
+        _caption(img, (x0, y0), label, color, line_thickness)

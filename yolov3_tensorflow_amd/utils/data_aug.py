@@ -1,14 +1,17 @@
 # coding: utf-8
-"""The training augmentations of the reference's utils/data_aug.py (mix_up, random_color_distort, random_expand,
-random_crop_with_constraints, resize_with_bbox, random_flip), OpenCV-free: numpy + PIL on RGB uint8 images.
+"""Training augmentations with the reference's `utils.data_aug` interface (mix_up, random_color_distort, random_expand,
+random_crop_with_constraints, resize_with_bbox, random_flip, letterbox_resize, bbox_crop, bbox_iou), OpenCV-free: numpy +
+PIL on RGB uint8 images.
 
-These feed the train step (the feeder); they are host-side plumbing, not the hot path, and they are
-random by construction, so they are held to DISTRIBUTIONAL fidelity, not bit parity:
-  * the box arithmetic (crop constraints, IoU, clipping, flips, expansion offsets, mix-up weights) follows the reference
-    line by line (utils/data_aug.py:12-380);
-  * every function draws its random numbers from explicit generators (`rng`: numpy RandomState, `prng`: random.Random)
-    instead of the process-global ones, so a feeder worker thread is reproducible from (seed, epoch, sample index) -
-    the reference's tf.data threads share the global generators and are not (utils/data_utils.py:190 says so);
+These feed the train step (the feeder); they are host-side plumbing, not the hot path.  What is held
+fixed against the reference (utils/data_aug.py:12-380), and how:
+  * the box arithmetic - crop windows, IoU, clipping, flips, canvas offsets, mix-up weights - gives the reference's numbers
+    draw for draw: tests/test_feeder_cpu.py replays vectors recorded from the reference module under the same seeds
+    (tests/golden/make_aug_golden.py).  That pins the ORDER and the arguments of every random draw below, which is why
+    each function says which draws it makes;
+  * every function takes explicit generators (`rng`: a numpy RandomState, `prng`: a random.Random) and falls back to the
+    process-global ones only when given none, so a feeder worker is reproducible from (seed, epoch, sample index) - the
+    reference's tf.data threads share the global generators and are not (utils/data_utils.py:190 says so);
   * the colour jitter works in HSV with OpenCV's units (H in [0,180), S and V in [0,255]); the conversion itself goes
     through PIL's C code (hue rescaled), the exact 8-bit OpenCV definition is kept as rgb_to_hsv_u8 / hsv_to_rgb_u8;
   * cv2.resize with the random interpolation 0..4: INTER_NEAREST and INTER_LINEAR are the exact restatements of
@@ -16,84 +19,85 @@ random by construction, so they are held to DISTRIBUTIONAL fidelity, not bit par
 """
 from __future__ import division, print_function
 
+import math
 import random as _random
 
 import numpy as np
 
+_INF = float('inf')
+
 
 def _gens(rng, prng):
-    return (rng if rng is not None else np.random), (prng if prng is not None else _random)
+    """(numpy-style generator, random.Random-style generator), each defaulting to the process-global module."""
+    return (np.random if rng is None else rng), (_random if prng is None else prng)
+
+
+def _with_column(boxes, value):
+    """boxes [N, C] with one more column holding `value` (float64, as np.full makes it)."""
+    return np.hstack([boxes, np.full((len(boxes), 1), value)])
 
 
 def mix_up(img1, img2, bbox1, bbox2, rng=None):
-    '''
-    reference utils/data_aug.py:12-39.
-    return:
-        mix_img: HWC format mix up image
-        mix_bbox: [N, 5] shape mix up bbox, i.e. `x_min, y_min, x_max, y_mix, mixup_weight`.
-    '''
+    """Blend two images on a common top-left-anchored canvas with a Beta(1.5, 1.5) weight (reference
+    utils/data_aug.py:12-39).  One draw: rng.beta.
+    Returns (uint8 HWC image, boxes [N1+N2, 5] = x_min, y_min, x_max, y_max, weight of the image the box came from)."""
     rng, _ = _gens(rng, None)
-    height = max(img1.shape[0], img2.shape[0])
-    width = max(img1.shape[1], img2.shape[1])
-    mix_img = np.zeros(shape=(height, width, 3), dtype='float32')
-    rand_num = rng.beta(1.5, 1.5)
-    rand_num = max(0, min(1, rand_num))
-    mix_img[:img1.shape[0], :img1.shape[1], :] = img1.astype('float32') * rand_num
-    mix_img[:img2.shape[0], :img2.shape[1], :] += img2.astype('float32') * (1. - rand_num)
-    mix_img = mix_img.astype('uint8')
-    # the last element of the 2nd dimention is the mix up weight
-    bbox1 = np.concatenate((bbox1, np.full(shape=(bbox1.shape[0], 1), fill_value=rand_num)), axis=-1)
-    bbox2 = np.concatenate((bbox2, np.full(shape=(bbox2.shape[0], 1), fill_value=1. - rand_num)), axis=-1)
-    mix_bbox = np.concatenate((bbox1, bbox2), axis=0)
-    return mix_img, mix_bbox
+    lam = min(1, max(0, rng.beta(1.5, 1.5)))
+    (h1, w1), (h2, w2) = img1.shape[:2], img2.shape[:2]
+    canvas = np.zeros((max(h1, h2), max(w1, w2), 3), np.float32)
+    canvas[:h1, :w1] = img1.astype(np.float32) * lam
+    canvas[:h2, :w2] += img2.astype(np.float32) * (1. - lam)
+    return canvas.astype(np.uint8), np.vstack([_with_column(bbox1, lam), _with_column(bbox2, 1. - lam)])
 
 
 def bbox_crop(bbox, crop_box=None, allow_outside_center=True):
-    """Crop bounding boxes to a slice area (x_min, y_min, width, height); reference utils/data_aug.py:42-93."""
-    bbox = bbox.copy()
+    """Boxes [N, 4+] re-expressed inside the window crop_box = (x_min, y_min, width, height): clipped to it, shifted to
+    its origin, and dropped when nothing is left (or, with allow_outside_center=False, when the centre lies outside).
+    A None / 0 entry of crop_box means "unbounded on that side" (reference utils/data_aug.py:42-93)."""
+    out = bbox.copy()
     if crop_box is None:
-        return bbox
-    if not len(crop_box) == 4:
+        return out
+    if len(crop_box) != 4:
         raise ValueError("Invalid crop_box parameter, requires length 4, given {}".format(str(crop_box)))
-    if sum([int(c is None) for c in crop_box]) == 4:
-        return bbox
-    l, t, w, h = crop_box
-    left = l if l else 0
-    top = t if t else 0
-    right = left + (w if w else np.inf)
-    bottom = top + (h if h else np.inf)
-    crop_bbox = np.array((left, top, right, bottom))
+    if all(c is None for c in crop_box):
+        return out
+    x0, y0 = crop_box[0] or 0, crop_box[1] or 0
+    origin = np.array((x0, y0))
+    far = np.array((x0 + (crop_box[2] or _INF), y0 + (crop_box[3] or _INF)))
     if allow_outside_center:
-        mask = np.ones(bbox.shape[0], dtype=bool)
+        keep = np.ones(len(out), dtype=bool)
     else:
-        centers = (bbox[:, :2] + bbox[:, 2:4]) / 2
-        mask = np.logical_and(crop_bbox[:2] <= centers, centers < crop_bbox[2:]).all(axis=1)
-    # transform borders
-    bbox[:, :2] = np.maximum(bbox[:, :2], crop_bbox[:2])
-    bbox[:, 2:4] = np.minimum(bbox[:, 2:4], crop_bbox[2:4])
-    bbox[:, :2] -= crop_bbox[:2]
-    bbox[:, 2:4] -= crop_bbox[:2]
-    mask = np.logical_and(mask, (bbox[:, :2] < bbox[:, 2:4]).all(axis=1))
-    return bbox[mask]
+        mid = (out[:, :2] + out[:, 2:4]) / 2
+        keep = ((origin <= mid) & (mid < far)).all(axis=1)
+    out[:, :2] = np.maximum(out[:, :2], origin)
+    out[:, 2:4] = np.minimum(out[:, 2:4], far)
+    out[:, :2] -= origin
+    out[:, 2:4] -= origin
+    keep &= (out[:, :2] < out[:, 2:4]).all(axis=1)
+    return out[keep]
 
 
 def bbox_iou(bbox_a, bbox_b, offset=0):
-    """IoU of every pair of boxes of two sets ([N,4+], [M,4+]) -> [N,M]; reference utils/data_aug.py:95-125."""
-    if bbox_a.shape[1] < 4 or bbox_b.shape[1] < 4:
+    """Pairwise IoU of two box sets ([N, 4+], [M, 4+]) -> [N, M]; `offset` 1 counts pixels inclusively (reference
+    utils/data_aug.py:95-125)."""
+    if min(bbox_a.shape[1], bbox_b.shape[1]) < 4:
         raise IndexError("Bounding boxes axis 1 must have at least length 4")
-    tl = np.maximum(bbox_a[:, None, :2], bbox_b[:, :2])
-    br = np.minimum(bbox_a[:, None, 2:4], bbox_b[:, 2:4])
-    area_i = np.prod(br - tl + offset, axis=2) * (tl < br).all(axis=2)
-    area_a = np.prod(bbox_a[:, 2:4] - bbox_a[:, :2] + offset, axis=1)
-    area_b = np.prod(bbox_b[:, 2:4] - bbox_b[:, :2] + offset, axis=1)
-    return area_i / (area_a[:, None] + area_b - area_i)
+
+    def area(lo, hi):
+        side = hi - lo + offset
+        return side[..., 0] * side[..., 1]
+
+    lo = np.maximum(bbox_a[:, None, :2], bbox_b[:, :2])
+    hi = np.minimum(bbox_a[:, None, 2:4], bbox_b[:, 2:4])
+    overlap = area(lo, hi) * (lo < hi).all(axis=2)
+    return overlap / (area(bbox_a[:, :2], bbox_a[:, 2:4])[:, None] + area(bbox_b[:, :2], bbox_b[:, 2:4]) - overlap)
 
 
 def _iou_min_max(rows, crop):
     """min and max over the boxes of bbox_iou(box, crop) for ONE crop box, in plain Python floats: the same float64
     arithmetic as bbox_iou on a [N,4] float32 array against an int crop, without ~10 numpy calls per trial (the crop loop
     runs up to 300 trials per image)."""
-    lo, hi = float('inf'), -float('inf')
+    lo, hi = _INF, -_INF
     cl, ct, cr, cb = crop
     area_b = float((cr - cl) * (cb - ct))
     for x0, y0, x1, y1 in rows:
@@ -105,41 +109,53 @@ def _iou_min_max(rows, crop):
     return lo, hi
 
 
+_DEFAULT_IOU_BANDS = ((0.1, None), (0.3, None), (0.5, None), (0.7, None), (0.9, None), (None, 1))
+
+
+def _draw_window(prng, w, h, min_scale, max_scale, max_aspect_ratio):
+    """One trial window (x, y, width, height) inside a w x h image, or None for a degenerate one.  Draws, in this order:
+    scale ~ U(min_scale, max_scale); aspect ~ U(max(1/R, s^2), min(R, 1/s^2)); then y and x offsets by randrange (the
+    offsets are not drawn for a degenerate trial - random.randrange(0) raises in the reference there)."""
+    s = prng.uniform(min_scale, max_scale)
+    root = math.sqrt(prng.uniform(max(1 / max_aspect_ratio, s * s), min(max_aspect_ratio, 1 / (s * s))))
+    win_h, win_w = int(h * s / root), int(w * s * root)
+    if h - win_h < 1 or w - win_w < 1:
+        return None
+    y = prng.randrange(h - win_h)
+    x = prng.randrange(w - win_w)
+    return x, y, win_w, win_h
+
+
 def random_crop_with_constraints(bbox, size, min_scale=0.3, max_scale=1, max_aspect_ratio=2, constraints=None,
                                  max_trial=50, rng=None, prng=None):
-    """SSD-style random crop under IoU constraints (reference utils/data_aug.py:128-225).
-    Returns (cropped boxes [M,4+], (x_offset, y_offset, new_width, new_height))."""
+    """SSD-style random crop (reference utils/data_aug.py:128-225).  For each (min_iou, max_iou) band of `constraints`,
+    up to max_trial windows are drawn (prng, see _draw_window) until one whose IoU with EVERY box lies in the band; the
+    whole image is always a candidate too.  Candidates are then taken in random order (rng.randint) until one keeps at
+    least one box centre.  size = (width, height).
+    Returns (boxes [M, 4+] in the window's frame, (x_offset, y_offset, width, height))."""
     rng, prng = _gens(rng, prng)
-    if constraints is None:
-        constraints = ((0.1, None), (0.3, None), (0.5, None), (0.7, None), (0.9, None), (None, 1))
     w, h = size
-    candidates = [(0, 0, w, h)]
+    pool = [(0, 0, w, h)]
     rows = [tuple(float(v) for v in b[:4]) for b in bbox]
-    for min_iou, max_iou in constraints:
-        min_iou = -np.inf if min_iou is None else min_iou
-        max_iou = np.inf if max_iou is None else max_iou
+    for band in (_DEFAULT_IOU_BANDS if constraints is None else constraints):
+        floor = -_INF if band[0] is None else band[0]
+        ceil = _INF if band[1] is None else band[1]
         for _ in range(max_trial):
-            scale = prng.uniform(min_scale, max_scale)
-            aspect_ratio = prng.uniform(max(1 / max_aspect_ratio, scale * scale), min(max_aspect_ratio, 1 / (scale * scale)))
-            crop_h = int(h * scale / np.sqrt(aspect_ratio))
-            crop_w = int(w * scale * np.sqrt(aspect_ratio))
-            if h - crop_h < 1 or w - crop_w < 1:     # (random.randrange(0) raises in the reference; a degenerate
-                continue                             # trial is skipped here)
-            crop_t = prng.randrange(h - crop_h)
-            crop_l = prng.randrange(w - crop_w)
-            if len(bbox) == 0:
-                return bbox, (crop_l, crop_t, crop_w, crop_h)
-            iou_min, iou_max = _iou_min_max(rows, (crop_l, crop_t, crop_l + crop_w, crop_t + crop_h))
-            if min_iou <= iou_min and iou_max <= max_iou:
-                candidates.append((crop_l, crop_t, crop_w, crop_h))
+            win = _draw_window(prng, w, h, min_scale, max_scale, max_aspect_ratio)
+            if win is None:
+                continue
+            if not rows:                  # nothing to constrain: the first proper window is the crop
+                return bbox, win
+            x, y, ww, wh = win
+            least, most = _iou_min_max(rows, (x, y, x + ww, y + wh))
+            if floor <= least and most <= ceil:
+                pool.append(win)
                 break
-    # random select one
-    while candidates:
-        crop = candidates.pop(rng.randint(0, len(candidates)))
-        new_bbox = bbox_crop(bbox, crop, allow_outside_center=False)
-        if new_bbox.size < 1:
-            continue
-        return new_bbox, (crop[0], crop[1], crop[2], crop[3])
+    while pool:
+        win = pool.pop(rng.randint(0, len(pool)))
+        kept = bbox_crop(bbox, win, allow_outside_center=False)
+        if kept.size:
+            return kept, tuple(win)
     return bbox, (0, 0, w, h)
 
 
@@ -173,44 +189,36 @@ def hsv_to_rgb_u8(hsv):
 
 
 def random_color_distort(img, brightness_delta=32, hue_vari=18, sat_vari=0.5, val_vari=0.5, rng=None):
-    '''
-    randomly distort image color: brightness, then hue / saturation / value in one of two orders
-    (reference utils/data_aug.py:228-271).  img: RGB uint8, HWC (the reference holds BGR: only the conversion differs).
-    '''
+    """Photometric jitter of an RGB uint8 HWC image (reference utils/data_aug.py:228-271, which holds BGR: only the
+    conversion differs).  Draws, all from rng, in this order: a coin and, on heads, an integer-truncated brightness shift
+    U(-brightness_delta, brightness_delta); one randint(0, 2) choosing the channel order (1: value, saturation, hue;
+    0: saturation, hue, value); then per channel a coin and, on heads, its amount - hue: an integer rotation
+    randint(-hue_vari, hue_vari) on the 180-degree circle; saturation / value: a gain 1 + U(-vari, vari)."""
     rng, _ = _gens(rng, None)
+    from PIL import Image
 
-    def random_hue(img_hsv, p=0.5):
-        if rng.uniform(0, 1) > p:
-            hue_delta = rng.randint(-hue_vari, hue_vari)
-            img_hsv[:, :, 0] = (img_hsv[:, :, 0] + hue_delta) % 180
-        return img_hsv
-
-    def random_saturation(img_hsv, p=0.5):
-        if rng.uniform(0, 1) > p:
-            img_hsv[:, :, 1] *= 1 + rng.uniform(-sat_vari, sat_vari)
-        return img_hsv
-
-    def random_value(img_hsv, p=0.5):
-        if rng.uniform(0, 1) > p:
-            img_hsv[:, :, 2] *= 1 + rng.uniform(-val_vari, val_vari)
-        return img_hsv
-
-    if rng.uniform(0, 1) > 0.5:        # brightness
+    if rng.uniform(0, 1) > 0.5:
         img = img.astype(np.float32) + int(rng.uniform(-brightness_delta, brightness_delta))
     img = np.clip(img, 0, 255).astype(np.uint8)
     # RGB <-> HSV through PIL's C conversion (hue on a 0..255 circle there: rescaled to OpenCV's 0..180 so that the jitter
     # amounts mean what they mean in the reference); rgb_to_hsv_u8 / hsv_to_rgb_u8 above are the exact 8-bit OpenCV
     # definition in numpy, 10x slower - half of a feeder worker's time per image when they were used here
-    from PIL import Image
-    img_hsv = np.asarray(Image.fromarray(img).convert('HSV')).astype(np.float32)
-    img_hsv[:, :, 0] *= 180.0 / 255.0
-    if rng.randint(0, 2):
-        img_hsv = random_hue(random_saturation(random_value(img_hsv)))
-    else:
-        img_hsv = random_value(random_hue(random_saturation(img_hsv)))
-    img_hsv = np.clip(img_hsv, 0, 255)
-    img_hsv[:, :, 0] = np.minimum(img_hsv[:, :, 0] * (255.0 / 180.0), 255.0)
-    return np.asarray(Image.fromarray(img_hsv.astype(np.uint8), 'HSV').convert('RGB'))
+    hsv = np.asarray(Image.fromarray(img).convert('HSV')).astype(np.float32)
+    hsv[..., 0] *= 180.0 / 255.0
+
+    def jitter(channel):
+        if not rng.uniform(0, 1) > 0.5:
+            return
+        if channel == 0:
+            hsv[..., 0] = (hsv[..., 0] + rng.randint(-hue_vari, hue_vari)) % 180
+        else:
+            hsv[..., channel] *= 1 + rng.uniform(-(sat_vari, val_vari)[channel - 1], (sat_vari, val_vari)[channel - 1])
+
+    for channel in ((2, 1, 0) if rng.randint(0, 2) else (1, 0, 2)):
+        jitter(channel)
+    hsv = np.clip(hsv, 0, 255)
+    hsv[..., 0] = np.minimum(hsv[..., 0] * (255.0 / 180.0), 255.0)
+    return np.asarray(Image.fromarray(hsv.astype(np.uint8), 'HSV').convert('RGB'))
 
 
 def _resize_any(img, new_width, new_height, interp):
@@ -225,77 +233,68 @@ def _resize_any(img, new_width, new_height, interp):
 
 
 def letterbox_resize(img, new_width, new_height, interp=0):
-    '''
-    Letterbox resize. keep the original aspect ratio in the resized image (reference utils/data_aug.py:274-293).
-    '''
-    ori_height, ori_width = img.shape[:2]
-    resize_ratio = min(new_width / ori_width, new_height / ori_height)
-    resize_w = int(resize_ratio * ori_width)
-    resize_h = int(resize_ratio * ori_height)
-    img = _resize_any(img, resize_w, resize_h, interp)
-    image_padded = np.full((new_height, new_width, 3), 128, np.uint8)
-    dw = int((new_width - resize_w) / 2)
-    dh = int((new_height - resize_h) / 2)
-    image_padded[dh: resize_h + dh, dw: resize_w + dw, :] = img
-    return image_padded, resize_ratio, dw, dh
+    """Aspect-preserving resize onto a grey (128) new_height x new_width canvas, centred (reference
+    utils/data_aug.py:274-293).  Returns (canvas, scale, x padding, y padding) - what maps a box into the canvas."""
+    src_h, src_w = img.shape[:2]
+    scale = min(new_width / src_w, new_height / src_h)
+    fit_w, fit_h = int(scale * src_w), int(scale * src_h)
+    pad_x, pad_y = int((new_width - fit_w) / 2), int((new_height - fit_h) / 2)
+    canvas = np.full((new_height, new_width, 3), 128, np.uint8)
+    canvas[pad_y:pad_y + fit_h, pad_x:pad_x + fit_w] = _resize_any(img, fit_w, fit_h, interp)
+    return canvas, scale, pad_x, pad_y
 
 
 def resize_with_bbox(img, bbox, new_width, new_height, interp=0, letterbox=False):
-    '''
-    Resize the image and correct the bbox accordingly (reference utils/data_aug.py:296-320; any of the five cv2
-    interpolation codes).  bbox: [N, >=4]; extra columns (the mix-up weight) are kept.
-    '''
-    bbox = np.array(bbox, np.float32)
-    if bbox.ndim == 1:
-        bbox = bbox.reshape(-1, 4)
+    """Resize an image (plain stretch, or letterbox) and carry its boxes along (reference utils/data_aug.py:296-320; any
+    of the five cv2 interpolation codes).  bbox: [N, >=4]; columns past the fourth (the mix-up weight) pass through."""
+    boxes = np.array(bbox, np.float32)
+    if boxes.ndim == 1:
+        boxes = boxes.reshape(-1, 4)
+    xs, ys = boxes[:, 0:3:2], boxes[:, 1:4:2]          # views: x_min/x_max and y_min/y_max
     if letterbox:
-        image_padded, resize_ratio, dw, dh = letterbox_resize(img, new_width, new_height, interp)
-        bbox[:, [0, 2]] = bbox[:, [0, 2]] * resize_ratio + dw
-        bbox[:, [1, 3]] = bbox[:, [1, 3]] * resize_ratio + dh
-        return image_padded, bbox
-    ori_height, ori_width = img.shape[:2]
-    img = _resize_any(img, new_width, new_height, interp)
-    bbox[:, [0, 2]] = bbox[:, [0, 2]] / ori_width * new_width
-    bbox[:, [1, 3]] = bbox[:, [1, 3]] / ori_height * new_height
-    return img, bbox
+        out, scale, pad_x, pad_y = letterbox_resize(img, new_width, new_height, interp)
+        xs *= scale
+        xs += pad_x
+        ys *= scale
+        ys += pad_y
+    else:
+        src_h, src_w = img.shape[:2]
+        out = _resize_any(img, new_width, new_height, interp)
+        xs /= src_w
+        xs *= new_width
+        ys /= src_h
+        ys *= new_height
+    return out, boxes
 
 
 def random_flip(img, bbox, px=0, py=0, rng=None):
-    '''
-    Randomly flip the image and correct the bbox (reference utils/data_aug.py:323-346).
-    px / py: the probability of a horizontal / vertical flip
-    '''
+    """Mirror the image left-right with probability px and top-bottom with probability py, boxes (modified in place)
+    mirrored with it (reference utils/data_aug.py:323-346).  Two draws, always both: rng.uniform(0, 1) for x, then y."""
     rng, _ = _gens(rng, None)
-    height, width = img.shape[:2]
+    extent_y, extent_x = img.shape[:2]
     if rng.uniform(0, 1) < px:
         img = img[:, ::-1]
-        xmax = width - bbox[:, 0]
-        xmin = width - bbox[:, 2]
-        bbox[:, 0] = xmin
-        bbox[:, 2] = xmax
+        bbox[:, [0, 2]] = extent_x - bbox[:, [2, 0]]
     if rng.uniform(0, 1) < py:
         img = img[::-1]
-        ymax = height - bbox[:, 1]
-        ymin = height - bbox[:, 3]
-        bbox[:, 1] = ymin
-        bbox[:, 3] = ymax
+        bbox[:, [1, 3]] = extent_y - bbox[:, [3, 1]]
     return np.ascontiguousarray(img), bbox
 
 
 def random_expand(img, bbox, max_ratio=4, fill=0, keep_ratio=True, prng=None):
-    '''
-    Random expand original image with borders: place it on a larger canvas (reference utils/data_aug.py:349-380).
-    '''
+    """Place the image at a random position on a `fill`-coloured canvas up to max_ratio times larger, boxes (modified in
+    place) shifted with it (reference utils/data_aug.py:349-380).  Draws from prng: the x ratio U(1, max_ratio), the y
+    ratio (only when keep_ratio is false), then the y and the x offset by randint (inclusive)."""
     _, prng = _gens(None, prng)
-    h, w, c = img.shape
-    ratio_x = prng.uniform(1, max_ratio)
-    ratio_y = ratio_x if keep_ratio else prng.uniform(1, max_ratio)
-    oh, ow = int(h * ratio_y), int(w * ratio_x)
-    off_y = prng.randint(0, oh - h)
-    off_x = prng.randint(0, ow - w)
-    dst = np.full(shape=(oh, ow, c), fill_value=fill, dtype=img.dtype)
-    dst[off_y:off_y + h, off_x:off_x + w, :] = img
-    # correct bbox
-    bbox[:, :2] += (off_x, off_y)
-    bbox[:, 2:4] += (off_x, off_y)
-    return dst, bbox
+    src_h, src_w, channels = img.shape
+    grow_x = prng.uniform(1, max_ratio)
+    grow_y = grow_x if keep_ratio else prng.uniform(1, max_ratio)
+    big_h, big_w = int(src_h * grow_y), int(src_w * grow_x)
+    at_y = prng.randint(0, big_h - src_h)
+    at_x = prng.randint(0, big_w - src_w)
+    canvas = np.full((big_h, big_w, channels), fill, dtype=img.dtype)
+    canvas[at_y:at_y + src_h, at_x:at_x + src_w] = img
+    shift = (at_x, at_y)
+    bbox[:, :2] += shift
+    bbox[:, 2:4] += shift
+    return canvas, bbox
