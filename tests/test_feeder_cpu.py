@@ -145,8 +145,18 @@ def test_worker_pool_is_shared_started_from_a_forkserver_and_reproducible(tmp_pa
         assert g[0] == want[0] and g[1].dtype == np.uint8
         for a, b in zip(g[1:], want[1:]):
             np.testing.assert_array_equal(a, b)
-    f1 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), num_threads=3)
-    f2 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), mode='val', num_threads=3)
+    f1 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), num_threads=3, backend='process')
+    f2 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), mode='val', num_threads=3,
+                       backend='process')
     assert f1._executor() is pool and f2._executor() is pool
     f1.close()
     assert feeder._shared_process_pool(3) is pool          # closing a feeder leaves the shared workers alone
+    # the default: threads (the pixel work is native code that releases the GIL), each writing its float32 slot in place
+    f3 = feeder.Feeder(lines, 2, 80, [96, 64], np.arange(18, dtype=np.float32), num_threads=3)
+    assert f3.backend == 'thread' and f3._executor() is not pool
+    slot = np.empty((64, 96, 3), np.float32)
+    got = f3._executor().submit(feeder._worker_sample, jobs[0], slot).result(timeout=120)
+    want = feeder._worker_sample(jobs[0])
+    assert got[1] is slot
+    np.testing.assert_array_equal(slot, want[1].astype(np.float32) / np.float32(255.))
+    f3.close()

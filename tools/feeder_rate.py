@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Standalone throughput of the feeder: images/s decoded, augmented, resized and copied to the device with nothing
+consuming them but this loop - how far the host side is from what the train step asks for (704 images/s per GPU at
+416x416, bs=64: profiles/r03_bench_c4_n1.json).  Synthetic 640x480 JPEGs (COCO's usual size), 'train' mode with mix-up,
+multi-scale off, batch 64.
+
+    python tools/feeder_rate.py [--workers 8,16,32] [--backends thread,process] [--native 1,0] [--batches 12]
+"""
+import argparse
+import os
+import pathlib
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ANCHORS = np.array([10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326], np.float32)
+
+
+def write_set(folder, n, seed=0):
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    lines = []
+    for i in range(n):
+        w, h = 640, 480
+        small = rng.randint(0, 256, (h // 10, w // 10, 3)).astype(np.uint8)
+        path = str(folder / ('img_%d.jpg' % i))
+        Image.fromarray(small).resize((w, h), Image.BICUBIC).save(path, quality=90)
+        parts = ['%d' % i, path, '%d' % w, '%d' % h]
+        for _ in range(int(rng.randint(1, 8))):
+            x0, y0 = rng.uniform(0, w * 0.5), rng.uniform(0, h * 0.5)
+            parts += ['%d' % rng.randint(0, 80), '%.1f' % x0, '%.1f' % y0, '%.1f' % (x0 + rng.uniform(20, w * 0.45)),
+                      '%.1f' % (y0 + rng.uniform(20, h * 0.45))]
+        lines.append(' '.join(parts))
+    return lines
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workers', default='8,16,32')
+    ap.add_argument('--backends', default='thread,process')
+    ap.add_argument('--native', default='1,0')
+    ap.add_argument('--batches', type=int, default=12)
+    ap.add_argument('--batch_size', type=int, default=64)
+    args = ap.parse_args()
+    import torch
+    from yolov3_tensorflow_amd.feeder import Feeder
+    lines = write_set(pathlib.Path(tempfile.mkdtemp()), 256)
+    lines = (lines * ((args.batches + 3) * args.batch_size // len(lines) + 1))[:(args.batches + 3) * args.batch_size]
+    print('host threads available: %d' % len(os.sched_getaffinity(0)), flush=True)
+    for native in args.native.split(','):
+        os.environ['Y3_FEED_NATIVE'] = native
+        for backend in args.backends.split(','):
+            for workers in [int(v) for v in args.workers.split(',')]:
+                f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True,
+                           num_threads=workers, prefetch=5, seed=1, backend=backend)
+                it = f.epoch(0)
+                for _ in range(3):              # pool start-up, pinned buffers
+                    next(it)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.batches):
+                    next(it)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                it.close()
+                f.close()
+                print('native=%s backend=%-7s workers=%3d: %7.0f images/s' % (native, backend, workers,
+                                                                                args.batches * args.batch_size / dt), flush=True)
+
+
+if __name__ == '__main__':
+    main()

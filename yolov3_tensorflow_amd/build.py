@@ -1,8 +1,8 @@
-"""Build libyolo355.so (the C-ABI HIP library) in-tree for gfx950.
+"""Build libyolo355.so (the C-ABI HIP library, gfx950) and liby3feed.so (the feeder's host-side image library) in-tree.
 
     python -m yolov3_tensorflow_amd.build [--force]
 
-hipcc cross-compiles without a GPU; the resulting .so travels with the repo snapshot to the GPU box.
+hipcc cross-compiles without a GPU; the resulting .so files travel with the repo snapshot to the GPU box.
 """
 import os
 import subprocess
@@ -31,6 +31,29 @@ SOURCES = [
     ("y3_wgrad_wino.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+# liby3feed.so: host code (include/yolo355_feed.h).  No FMA contraction and no fast-math: it reproduces numpy's float32
+# loops and Pillow's C arithmetic bit for bit.  Baseline x86-64 only (the file is built here and runs on the GPU box).
+FEED_SRC = os.path.join(CSRC, "y3_feed.cpp")
+FEED_LIB = os.path.join(CSRC, "liby3feed.so")
+FEED_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-Wall",
+              "-Wno-format-truncation"]
+
+
+def build_feed(force=False, verbose=True):
+    deps = [FEED_SRC, os.path.join(HERE, "..", "include", "yolo355_feed.h")]
+    if not force and os.path.exists(FEED_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(FEED_LIB) for d in deps):
+        return FEED_LIB
+    tmp = FEED_LIB + ".%d.tmp" % os.getpid()         # (several feeder workers may get here at once: rename is atomic)
+    cmd = [os.environ.get("CXX", "g++")] + FEED_FLAGS + [FEED_SRC, "-o", tmp]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if out.returncode != 0:
+        raise RuntimeError("building liby3feed.so failed:\n%s\n%s" % (" ".join(cmd), out.stdout.decode(errors="replace")))
+    os.replace(tmp, FEED_LIB)
+    return FEED_LIB
 
 
 def _hipcc():
@@ -67,6 +90,7 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    build_feed(force=force, verbose=verbose)
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()

@@ -6,17 +6,21 @@
 rebuilt for one process per GPU with the device-resident target assignment of this package:
 
   * `num_threads` workers (reference: args.num_threads = 10) decode, augment and resize ONE image each
-    (utils.data_utils.parse_sample).  They are worker PROCESSES by default: the numpy restatements of the OpenCV
-    resizes and of the colour jitter hold the GIL for much of their time, and 16 threads measured 274 images/s where the
-    train step wants 530 (tests/test_feeder_gpu.py); the children never touch the device.  The workers come from a
-    `forkserver` (one pool per process and worker count, shared by the training and the validation feeder): forking the
-    training process itself copies every PINNED host page eagerly - measured 93 s for four workers once 8 GB were
-    pinned, against 0.4 s in a fresh process (tools/feeder_diag.py) - and the feeder is what pins them.  (As with any
-    multiprocessing start method but fork, a SCRIPT that builds a Feeder needs the usual `if __name__ == '__main__':`
-    guard: the workers import the main module.)  A coordinator thread assembles
-    whole batches in PINNED host buffers and copies them to the device on a SIDE stream; a bounded queue of `prefetch` batches
-    (reference: prefetech_buffer = 5) decouples it from the train step, so decode / resize / H2D of batch i+1.. overlap the
-    step on batch i;
+    (utils.data_utils.parse_sample).  The pixel work - blend, colour jitter, crop, resize, pad, flip, /255 - and the crop
+    search run in liby3feed.so (include/yolo355_feed.h: native code where the reference's is OpenCV), which releases the
+    GIL, as PIL's JPEG decoder does; a worker holds the GIL for well under a millisecond per image.  So the workers are
+    THREADS by default (backend='thread') and each writes its float32 image straight into its slot of the batch's pinned
+    host buffer: no pickling, no second pass.  backend='process' keeps the round-2 arrangement for the numpy / Pillow
+    pixel path (Y3_FEED_NATIVE=0, which holds the GIL most of the time): worker processes from a `forkserver` (one pool per
+    process and worker count, shared by the training and the validation feeder) hand back 8-bit images that the
+    coordinator divides into the pinned buffer.  Why a forkserver: forking the training process itself copies every
+    PINNED host page eagerly - measured 93 s for four workers once 8 GB were pinned, against 0.4 s in a fresh process
+    (tools/feeder_diag.py) - and the feeder is what pins them.  (As with any multiprocessing start method but fork, a
+    SCRIPT that builds a process-backed Feeder needs the usual `if __name__ == '__main__':` guard.)
+  * a coordinator thread keeps `prefetch` batches of jobs in flight, and copies each finished batch to the device on a
+    SIDE stream; a bounded queue of `prefetch` batches (reference: prefetech_buffer = 5) decouples it from the train step,
+    so decode / resize / H2D of batch i+1.. overlap the step on batch i.  The pinned buffers are recycled once their copy
+    has completed (pinning 130 MB per batch afresh costs more than filling it);
   * the consumer makes its compute stream wait for the copy's event (no host synchronisation) and runs `y3_process_box`
     for the whole batch on the device (utils.data_utils.process_box_batch: bit-exact against the reference's
     process_box), so the three y_true tensors (3.6 MB per 416x416 image - more than the image itself) never cross PCIe;
@@ -35,12 +39,36 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
-def _worker_sample(job):
-    """One sample in a worker (process or thread): job = (line or mix-up pair, [w, h], mode, letterbox, rng key)."""
+def _worker_sample(job, out=None):
+    """One sample in a worker: job = (line or mix-up pair, [w, h], mode, letterbox, rng key).  A thread is handed `out`, its
+    float32 slot of the batch buffer; a process returns the 8-bit image (a quarter of the bytes to pickle)."""
     from .utils.data_utils import parse_sample
     line, size, mode, letterbox, key = job
     return parse_sample(line, size, mode, letterbox, rng=np.random.RandomState(key % (2 ** 31)), prng=random.Random(key),
-                        as_uint8=True)
+                        as_uint8=out is None, out=out)
+
+
+class _PinnedBuffers(object):
+    """Pinned host batch buffers by shape, handed out again once the H2D copy that read them has completed."""
+
+    def __init__(self):
+        self.busy = []          # (event, tensor)
+
+    def take(self, shape):
+        import torch
+        shape = tuple(int(v) for v in shape)
+        free = [i for i, (ev, _) in enumerate(self.busy) if ev.query()]
+        for i in free:
+            if tuple(self.busy[i][1].shape) == shape:
+                return self.busy.pop(i)[1]
+        # none of this shape is free.  Multi-scale training moves from size to size: keep a handful of free buffers of
+        # other shapes (the size may come back), unpin the rest
+        for i in reversed(free[:-4]):
+            del self.busy[i]
+        return torch.empty(shape, dtype=torch.float32).pin_memory()
+
+    def give(self, event, tensor):
+        self.busy.append((event, tensor))
 
 
 _POOLS = {}
@@ -77,7 +105,7 @@ class Batch(object):
 class Feeder(object):
     def __init__(self, lines, batch_size, class_num, img_size, anchors, mode='train', multi_scale=False, use_mix_up=False,
                  letterbox_resize=True, num_threads=10, prefetch=5, shuffle=None, seed=0, rank=0, world=1, interval=10,
-                 device=None, drop_remainder=False, backend='process'):
+                 device=None, drop_remainder=False, backend=None):
         self.lines = [l for l in lines if (l.strip() if isinstance(l, str) else l)]
         self.batch_size, self.class_num = int(batch_size), int(class_num)
         self.img_size, self.anchors = list(img_size), np.asarray(anchors, np.float32).reshape(9, 2)
@@ -91,6 +119,9 @@ class Feeder(object):
         self.device = device
         self.drop_remainder = drop_remainder
         self.batches_served = 0          # the reference's iter_cnt: counts batches over epochs (multi-scale schedule)
+        if backend is None:      # threads when the pixel work is native code that releases the GIL (module docstring)
+            from . import feed_native
+            backend = 'thread' if feed_native.enabled() else 'process'
         if backend not in ('process', 'thread'):
             raise ValueError("backend must be 'process' or 'thread'")
         self.backend = backend
@@ -159,6 +190,9 @@ class Feeder(object):
 
         pool = self._executor()
 
+        buffers = _PinnedBuffers()
+        in_place = self.backend == 'thread'
+
         def produce():
             try:
                 # keep up to `prefetch` batches of decode jobs in flight
@@ -172,15 +206,18 @@ class Feeder(object):
                         except StopIteration:
                             exhausted = True
                             break
-                        futs = [pool.submit(_worker_sample, self._job(epoch, b, j, line, size))
-                                for j, line in enumerate(lines)]
-                        pending.append((b, size, futs))
+                        pinned = buffers.take((len(lines), size[1], size[0], 3))
+                        slots = pinned.numpy()
+                        jobs = [self._job(epoch, b, j, line, size) for j, line in enumerate(lines)]
+                        if in_place:
+                            futs = [pool.submit(_worker_sample, job, slots[j]) for j, job in enumerate(jobs)]
+                        else:
+                            futs = [pool.submit(_worker_sample, job) for job in jobs]
+                        pending.append((b, size, futs, pinned))
                     if not pending:
                         break
-                    b, size, futs = pending.pop(0)
+                    b, size, futs, pinned = pending.pop(0)
                     samples = [f.result() for f in futs]
-                    n = len(samples)
-                    pinned = torch.empty((n, size[1], size[0], 3), dtype=torch.float32).pin_memory()
                     ids, _, boxes, labels, counts = collate(samples, out_images=pinned.numpy())
                     with torch.cuda.stream(copy_stream):
                         images = pinned.to(dev, non_blocking=True)
@@ -189,7 +226,8 @@ class Feeder(object):
                         ct = torch.from_numpy(counts.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(copy_stream)
-                    item = (ids, size, images, bx, lb, ct, ev, pinned)
+                    buffers.give(ev, pinned)
+                    item = (ids, size, images, bx, lb, ct, ev)
                     while not stop.is_set():
                         try:
                             q.put(item, timeout=0.1)
@@ -209,7 +247,7 @@ class Feeder(object):
                     break
                 if isinstance(item, BaseException):
                     raise item
-                ids, size, images, bx, lb, ct, ev, pinned = item
+                ids, size, images, bx, lb, ct, ev = item
                 torch.cuda.current_stream(dev).wait_event(ev)         # device-side ordering only
                 for t in (images, bx, lb, ct):
                     t.record_stream(torch.cuda.current_stream(dev))

@@ -37,17 +37,29 @@ def _with_column(boxes, value):
     return np.hstack([boxes, np.full((len(boxes), 1), value)])
 
 
-def mix_up(img1, img2, bbox1, bbox2, rng=None):
-    """Blend two images on a common top-left-anchored canvas with a Beta(1.5, 1.5) weight (reference
-    utils/data_aug.py:12-39).  One draw: rng.beta.
-    Returns (uint8 HWC image, boxes [N1+N2, 5] = x_min, y_min, x_max, y_max, weight of the image the box came from)."""
+def mix_up_boxes(bbox1, bbox2, rng=None):
+    """The image-free half of mix_up: draws the weight (one draw: rng.beta(1.5, 1.5)) and labels the boxes with it.
+    Returns (weight of the first image, boxes [N1+N2, 5])."""
     rng, _ = _gens(rng, None)
     lam = min(1, max(0, rng.beta(1.5, 1.5)))
+    return lam, np.vstack([_with_column(bbox1, lam), _with_column(bbox2, 1. - lam)])
+
+
+def blend(img1, img2, lam):
+    """The pixel half of mix_up: lam * img1 + (1 - lam) * img2 in float32 on a black canvas that holds both, as uint8."""
     (h1, w1), (h2, w2) = img1.shape[:2], img2.shape[:2]
     canvas = np.zeros((max(h1, h2), max(w1, w2), 3), np.float32)
     canvas[:h1, :w1] = img1.astype(np.float32) * lam
     canvas[:h2, :w2] += img2.astype(np.float32) * (1. - lam)
-    return canvas.astype(np.uint8), np.vstack([_with_column(bbox1, lam), _with_column(bbox2, 1. - lam)])
+    return canvas.astype(np.uint8)
+
+
+def mix_up(img1, img2, bbox1, bbox2, rng=None):
+    """Blend two images on a common top-left-anchored canvas with a Beta(1.5, 1.5) weight (reference
+    utils/data_aug.py:12-39).  One draw: rng.beta.
+    Returns (uint8 HWC image, boxes [N1+N2, 5] = x_min, y_min, x_max, y_max, weight of the image the box came from)."""
+    lam, boxes = mix_up_boxes(bbox1, bbox2, rng)
+    return blend(img1, img2, lam), boxes
 
 
 def bbox_crop(bbox, crop_box=None, allow_outside_center=True):
@@ -126,6 +138,46 @@ def _draw_window(prng, w, h, min_scale, max_scale, max_aspect_ratio):
     return x, y, win_w, win_h
 
 
+def _candidate_windows(prng, rows, w, h, min_scale, max_scale, max_aspect_ratio, bands, max_trial):
+    """The trial loop of random_crop_with_constraints: per (floor, ceil) band, up to max_trial windows from _draw_window
+    until one whose IoU with EVERY box row lies in the band.  Returns (windows found, None), or (None, window) when there
+    are no rows: nothing to constrain, the first proper window is the crop."""
+    found = []
+    for floor, ceil in bands:
+        for _ in range(max_trial):
+            win = _draw_window(prng, w, h, min_scale, max_scale, max_aspect_ratio)
+            if win is None:
+                continue
+            if not rows:
+                return None, win
+            x, y, ww, wh = win
+            least, most = _iou_min_max(rows, (x, y, x + ww, y + wh))
+            if floor <= least and most <= ceil:
+                found.append(win)
+                break
+    return found, None
+
+
+def _candidate_windows_native(prng, rows, w, h, min_scale, max_scale, max_aspect_ratio, bands, max_trial):
+    """_candidate_windows in liby3feed.so (y3f_crop_candidates), drawing from prng's own Mersenne Twister state: the same
+    windows, and prng left exactly where the Python loop would leave it (tests/test_feed_native.py)."""
+    import ctypes
+    from .. import feed_native
+    version, words, gauss = prng.getstate()
+    state = np.array(words, dtype=np.uint32)
+    boxes = np.array(rows, dtype=np.float64).reshape(-1, 4)
+    limits = np.array(bands, dtype=np.float64).reshape(-1, 2)
+    windows = np.zeros((max(1, len(limits)), 4), np.int32)
+    count = ctypes.c_int32(0)
+    feed_native.check(feed_native.lib().y3f_crop_candidates(
+        state.ctypes.data, boxes.ctypes.data, len(boxes), int(w), int(h), float(min_scale), float(max_scale),
+        float(max_aspect_ratio), limits.ctypes.data, len(limits), int(max_trial), windows.ctypes.data, ctypes.byref(count)))
+    prng.setstate((version, tuple(state.tolist()), gauss))
+    if count.value < 0:
+        return None, tuple(int(v) for v in windows[0])
+    return [tuple(int(v) for v in win) for win in windows[:count.value]], None
+
+
 def random_crop_with_constraints(bbox, size, min_scale=0.3, max_scale=1, max_aspect_ratio=2, constraints=None,
                                  max_trial=50, rng=None, prng=None):
     """SSD-style random crop (reference utils/data_aug.py:128-225).  For each (min_iou, max_iou) band of `constraints`,
@@ -135,22 +187,17 @@ def random_crop_with_constraints(bbox, size, min_scale=0.3, max_scale=1, max_asp
     Returns (boxes [M, 4+] in the window's frame, (x_offset, y_offset, width, height))."""
     rng, prng = _gens(rng, prng)
     w, h = size
-    pool = [(0, 0, w, h)]
     rows = [tuple(float(v) for v in b[:4]) for b in bbox]
-    for band in (_DEFAULT_IOU_BANDS if constraints is None else constraints):
-        floor = -_INF if band[0] is None else band[0]
-        ceil = _INF if band[1] is None else band[1]
-        for _ in range(max_trial):
-            win = _draw_window(prng, w, h, min_scale, max_scale, max_aspect_ratio)
-            if win is None:
-                continue
-            if not rows:                  # nothing to constrain: the first proper window is the crop
-                return bbox, win
-            x, y, ww, wh = win
-            least, most = _iou_min_max(rows, (x, y, x + ww, y + wh))
-            if floor <= least and most <= ceil:
-                pool.append(win)
-                break
+    bands = [(-_INF if lo is None else lo, _INF if hi is None else hi)
+             for lo, hi in (_DEFAULT_IOU_BANDS if constraints is None else constraints)]
+    from .. import feed_native
+    search = _candidate_windows
+    if feed_native.enabled() and hasattr(prng, 'getstate') and max(w, h) < 2 ** 31:      # (any random.Random, or `random`)
+        search = _candidate_windows_native
+    found, only = search(prng, rows, w, h, min_scale, max_scale, max_aspect_ratio, bands, max_trial)
+    if found is None:
+        return bbox, only
+    pool = [(0, 0, w, h)] + found
     while pool:
         win = pool.pop(rng.randint(0, len(pool)))
         kept = bbox_crop(bbox, win, allow_outside_center=False)
@@ -188,40 +235,61 @@ def hsv_to_rgb_u8(hsv):
     return np.clip(np.rint(np.stack([r, g, b], axis=-1)), 0, 255).astype(np.uint8)
 
 
-def random_color_distort(img, brightness_delta=32, hue_vari=18, sat_vari=0.5, val_vari=0.5, rng=None):
-    """Photometric jitter of an RGB uint8 HWC image (reference utils/data_aug.py:228-271, which holds BGR: only the
-    conversion differs).  Draws, all from rng, in this order: a coin and, on heads, an integer-truncated brightness shift
-    U(-brightness_delta, brightness_delta); one randint(0, 2) choosing the channel order (1: value, saturation, hue;
-    0: saturation, hue, value); then per channel a coin and, on heads, its amount - hue: an integer rotation
-    randint(-hue_vari, hue_vari) on the 180-degree circle; saturation / value: a gain 1 + U(-vari, vari)."""
+def color_distort_draws(brightness_delta=32, hue_vari=18, sat_vari=0.5, val_vari=0.5, rng=None):
+    """The draws of random_color_distort, all from rng, in this order: a coin and, on heads, an integer-truncated
+    brightness shift U(-brightness_delta, brightness_delta); one randint(0, 2) choosing the channel order (1: value,
+    saturation, hue; 0: saturation, hue, value); then per channel a coin and, on heads, its amount - hue: an integer
+    rotation randint(-hue_vari, hue_vari) on the 180-degree circle; saturation / value: a gain 1 + U(-vari, vari).
+    Returns (brightness shift, hue rotation or None, saturation gain or None, value gain or None)."""
     rng, _ = _gens(rng, None)
-    from PIL import Image
+    shift = int(rng.uniform(-brightness_delta, brightness_delta)) if rng.uniform(0, 1) > 0.5 else 0
+    amount = [None, None, None]           # hue, saturation, value
+    for channel in ((2, 1, 0) if rng.randint(0, 2) else (1, 0, 2)):
+        if not rng.uniform(0, 1) > 0.5:
+            continue
+        if channel == 0:
+            amount[0] = int(rng.randint(-hue_vari, hue_vari))
+        else:
+            vari = (sat_vari, val_vari)[channel - 1]
+            amount[channel] = float(1 + rng.uniform(-vari, vari))
+    return shift, amount[0], amount[1], amount[2]
 
-    if rng.uniform(0, 1) > 0.5:
-        img = img.astype(np.float32) + int(rng.uniform(-brightness_delta, brightness_delta))
+
+def apply_color_distort(img, draws):
+    """The pixel half of random_color_distort for draws = (brightness shift, hue rotation, saturation gain, value gain)."""
+    from PIL import Image
+    shift, hue, sat, val = draws
+    if shift:
+        img = img.astype(np.float32) + shift
     img = np.clip(img, 0, 255).astype(np.uint8)
     # RGB <-> HSV through PIL's C conversion (hue on a 0..255 circle there: rescaled to OpenCV's 0..180 so that the jitter
     # amounts mean what they mean in the reference); rgb_to_hsv_u8 / hsv_to_rgb_u8 above are the exact 8-bit OpenCV
     # definition in numpy, 10x slower - half of a feeder worker's time per image when they were used here
     hsv = np.asarray(Image.fromarray(img).convert('HSV')).astype(np.float32)
     hsv[..., 0] *= 180.0 / 255.0
-
-    def jitter(channel):
-        if not rng.uniform(0, 1) > 0.5:
-            return
-        if channel == 0:
-            hsv[..., 0] = (hsv[..., 0] + rng.randint(-hue_vari, hue_vari)) % 180
-        else:
-            hsv[..., channel] *= 1 + rng.uniform(-(sat_vari, val_vari)[channel - 1], (sat_vari, val_vari)[channel - 1])
-
-    for channel in ((2, 1, 0) if rng.randint(0, 2) else (1, 0, 2)):
-        jitter(channel)
+    if hue is not None:
+        hsv[..., 0] = (hsv[..., 0] + hue) % 180
+    if sat is not None:
+        hsv[..., 1] *= sat
+    if val is not None:
+        hsv[..., 2] *= val
     hsv = np.clip(hsv, 0, 255)
     hsv[..., 0] = np.minimum(hsv[..., 0] * (255.0 / 180.0), 255.0)
     return np.asarray(Image.fromarray(hsv.astype(np.uint8), 'HSV').convert('RGB'))
 
 
+def random_color_distort(img, brightness_delta=32, hue_vari=18, sat_vari=0.5, val_vari=0.5, rng=None):
+    """Photometric jitter of an RGB uint8 HWC image: brightness, then hue / saturation / value (reference
+    utils/data_aug.py:228-271, which holds BGR: only the conversion differs).  The draws: color_distort_draws."""
+    return apply_color_distort(img, color_distort_draws(brightness_delta, hue_vari, sat_vari, val_vari, rng))
+
+
 def _resize_any(img, new_width, new_height, interp):
+    """cv2.resize with interpolation code 0..4 (see the module docstring); the same bytes from liby3feed.so when the native
+    path is on, from the numpy restatements / Pillow otherwise."""
+    from .. import feed_native
+    if feed_native.enabled():
+        return feed_native.resize(img, new_width, new_height, interp)
     from .data_utils import resize_nearest_cv2, resize_bilinear_cv2
     if interp == 0:
         return resize_nearest_cv2(img, new_width, new_height)
@@ -232,69 +300,99 @@ def _resize_any(img, new_width, new_height, interp):
     return np.asarray(Image.fromarray(np.asarray(img, np.uint8)).resize((int(new_width), int(new_height)), mode))
 
 
+def letterbox_geometry(src_w, src_h, new_width, new_height):
+    """(scale, fitted width, fitted height, x padding, y padding) of letterbox_resize for a src_w x src_h image."""
+    scale = min(new_width / src_w, new_height / src_h)
+    fit_w, fit_h = int(scale * src_w), int(scale * src_h)
+    return scale, fit_w, fit_h, int((new_width - fit_w) / 2), int((new_height - fit_h) / 2)
+
+
 def letterbox_resize(img, new_width, new_height, interp=0):
     """Aspect-preserving resize onto a grey (128) new_height x new_width canvas, centred (reference
     utils/data_aug.py:274-293).  Returns (canvas, scale, x padding, y padding) - what maps a box into the canvas."""
     src_h, src_w = img.shape[:2]
-    scale = min(new_width / src_w, new_height / src_h)
-    fit_w, fit_h = int(scale * src_w), int(scale * src_h)
-    pad_x, pad_y = int((new_width - fit_w) / 2), int((new_height - fit_h) / 2)
+    scale, fit_w, fit_h, pad_x, pad_y = letterbox_geometry(src_w, src_h, new_width, new_height)
     canvas = np.full((new_height, new_width, 3), 128, np.uint8)
     canvas[pad_y:pad_y + fit_h, pad_x:pad_x + fit_w] = _resize_any(img, fit_w, fit_h, interp)
     return canvas, scale, pad_x, pad_y
 
 
-def resize_with_bbox(img, bbox, new_width, new_height, interp=0, letterbox=False):
-    """Resize an image (plain stretch, or letterbox) and carry its boxes along (reference utils/data_aug.py:296-320; any
-    of the five cv2 interpolation codes).  bbox: [N, >=4]; columns past the fourth (the mix-up weight) pass through."""
+def resize_boxes(bbox, src_w, src_h, new_width, new_height, letterbox=False):
+    """The box half of resize_with_bbox: a float32 copy of bbox ([N, >=4], or a flat list of 4k numbers) mapped from a
+    src_w x src_h image into the resized (or letterboxed) one."""
     boxes = np.array(bbox, np.float32)
     if boxes.ndim == 1:
         boxes = boxes.reshape(-1, 4)
     xs, ys = boxes[:, 0:3:2], boxes[:, 1:4:2]          # views: x_min/x_max and y_min/y_max
     if letterbox:
-        out, scale, pad_x, pad_y = letterbox_resize(img, new_width, new_height, interp)
+        scale, _, _, pad_x, pad_y = letterbox_geometry(src_w, src_h, new_width, new_height)
         xs *= scale
         xs += pad_x
         ys *= scale
         ys += pad_y
     else:
-        src_h, src_w = img.shape[:2]
-        out = _resize_any(img, new_width, new_height, interp)
         xs /= src_w
         xs *= new_width
         ys /= src_h
         ys *= new_height
-    return out, boxes
+    return boxes
+
+
+def resize_with_bbox(img, bbox, new_width, new_height, interp=0, letterbox=False):
+    """Resize an image (plain stretch, or letterbox) and carry its boxes along (reference utils/data_aug.py:296-320; any
+    of the five cv2 interpolation codes).  bbox: [N, >=4]; columns past the fourth (the mix-up weight) pass through."""
+    src_h, src_w = img.shape[:2]
+    boxes = resize_boxes(bbox, src_w, src_h, new_width, new_height, letterbox)
+    if letterbox:
+        return letterbox_resize(img, new_width, new_height, interp)[0], boxes
+    return _resize_any(img, new_width, new_height, interp), boxes
+
+
+def flip_boxes(bbox, width, height, px=0, py=0, rng=None):
+    """The box half of random_flip: two draws, always both (rng.uniform(0, 1) for x, then y); the boxes (modified in
+    place) of a width x height image are mirrored with it.  Returns (flipped in x?, flipped in y?)."""
+    rng, _ = _gens(rng, None)
+    in_x = rng.uniform(0, 1) < px
+    if in_x:
+        bbox[:, [0, 2]] = width - bbox[:, [2, 0]]
+    in_y = rng.uniform(0, 1) < py
+    if in_y:
+        bbox[:, [1, 3]] = height - bbox[:, [3, 1]]
+    return in_x, in_y
 
 
 def random_flip(img, bbox, px=0, py=0, rng=None):
     """Mirror the image left-right with probability px and top-bottom with probability py, boxes (modified in place)
-    mirrored with it (reference utils/data_aug.py:323-346).  Two draws, always both: rng.uniform(0, 1) for x, then y."""
-    rng, _ = _gens(rng, None)
-    extent_y, extent_x = img.shape[:2]
-    if rng.uniform(0, 1) < px:
+    mirrored with it (reference utils/data_aug.py:323-346).  The draws: flip_boxes."""
+    in_x, in_y = flip_boxes(bbox, img.shape[1], img.shape[0], px, py, rng)
+    if in_x:
         img = img[:, ::-1]
-        bbox[:, [0, 2]] = extent_x - bbox[:, [2, 0]]
-    if rng.uniform(0, 1) < py:
+    if in_y:
         img = img[::-1]
-        bbox[:, [1, 3]] = extent_y - bbox[:, [3, 1]]
     return np.ascontiguousarray(img), bbox
 
 
-def random_expand(img, bbox, max_ratio=4, fill=0, keep_ratio=True, prng=None):
-    """Place the image at a random position on a `fill`-coloured canvas up to max_ratio times larger, boxes (modified in
-    place) shifted with it (reference utils/data_aug.py:349-380).  Draws from prng: the x ratio U(1, max_ratio), the y
-    ratio (only when keep_ratio is false), then the y and the x offset by randint (inclusive)."""
+def expand_boxes(bbox, src_w, src_h, max_ratio=4, keep_ratio=True, prng=None):
+    """The box half of random_expand.  Draws from prng: the x ratio U(1, max_ratio), the y ratio (only when keep_ratio is
+    false), then the y and the x offset by randint (inclusive); the boxes (modified in place) move by the offset.
+    Returns (canvas width, canvas height, x offset, y offset)."""
     _, prng = _gens(None, prng)
-    src_h, src_w, channels = img.shape
     grow_x = prng.uniform(1, max_ratio)
     grow_y = grow_x if keep_ratio else prng.uniform(1, max_ratio)
     big_h, big_w = int(src_h * grow_y), int(src_w * grow_x)
     at_y = prng.randint(0, big_h - src_h)
     at_x = prng.randint(0, big_w - src_w)
-    canvas = np.full((big_h, big_w, channels), fill, dtype=img.dtype)
-    canvas[at_y:at_y + src_h, at_x:at_x + src_w] = img
     shift = (at_x, at_y)
     bbox[:, :2] += shift
     bbox[:, 2:4] += shift
+    return big_w, big_h, at_x, at_y
+
+
+def random_expand(img, bbox, max_ratio=4, fill=0, keep_ratio=True, prng=None):
+    """Place the image at a random position on a `fill`-coloured canvas up to max_ratio times larger, boxes (modified in
+    place) shifted with it (reference utils/data_aug.py:349-380).  The draws: expand_boxes."""
+    src_h, src_w, channels = img.shape
+    big_w, big_h, at_x, at_y = expand_boxes(bbox, src_w, src_h, max_ratio, keep_ratio, prng)
+    canvas = np.full((big_h, big_w, channels), fill, dtype=img.dtype)
+    canvas[at_y:at_y + src_h, at_x:at_x + src_w] = img
     return canvas, bbox

@@ -145,12 +145,14 @@ def resize_bilinear_cv2(img, new_width, new_height):
 
 
 def _resize(img, new_width, new_height, interp):
-    if interp == 0:
-        return resize_nearest_cv2(img, new_width, new_height)
-    if interp == 1:
-        return resize_bilinear_cv2(img, new_width, new_height)
-    raise ValueError("interp must be 0 (cv2.INTER_NEAREST) or 1 (cv2.INTER_LINEAR); the other OpenCV interpolations "
-                     "are only used by the training augmentation, which is out of scope")
+    if interp not in (0, 1):
+        raise ValueError("interp must be 0 (cv2.INTER_NEAREST) or 1 (cv2.INTER_LINEAR); the other OpenCV interpolations "
+                         "are only used by the training augmentation (utils.data_aug)")
+    from .. import feed_native
+    img = np.asarray(img)
+    if feed_native.enabled() and img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3:
+        return feed_native.resize(img, new_width, new_height, interp)      # the same bytes, natively (liby3feed.so)
+    return resize_nearest_cv2(img, new_width, new_height) if interp == 0 else resize_bilinear_cv2(img, new_width, new_height)
 
 
 def letterbox_resize(img, new_width, new_height, interp=0):
@@ -207,14 +209,23 @@ def _read_rgb(pic_path):
     return np.asarray(Image.open(pic_path).convert('RGB'))
 
 
-def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False):
+def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False, out=None):
     """The image half of the reference's parse_data (utils/data_utils.py:118-172): read (PIL, RGB), mix-up when `line` is
     a pair, the 'train' augmentation chain (colour distortion, expansion, constrained crop, resize with a random
     interpolation, horizontal flip) or the plain 'val' resize.  Returns (img_idx, float32 RGB image in [0,1] of shape
     [img_size[1], img_size[0], 3], boxes [K,5] with the mix-up weight in column 4, labels [>=K]: the crop may drop boxes
-    and, like the reference, does not drop their labels - see collate()).  Target assignment (process_box) is NOT done here: the feeder runs it on the device for the whole batch (process_box_batch)."""
+    and, like the reference, does not drop their labels - see collate()).  Target assignment (process_box) is NOT done here: the feeder runs it on the device for the whole batch (process_box_batch).
+
+    Two executions of the same recipe, bit-identical (tests/test_feed_native.py): every draw and all box arithmetic come
+    from utils.data_aug either way; the pixels go through liby3feed.so in one pass (feed_native.enabled(), the default), or
+    through data_aug's numpy / Pillow functions one augmentation at a time (Y3_FEED_NATIVE=0).  `out`: a [h, w, 3] array
+    (uint8 with as_uint8, else float32) to write the image into - the native path fills it directly."""
     from . import data_aug
+    from .. import feed_native
     rng = rng if rng is not None else np.random
+    train = str(mode) == 'train'
+    width, height = int(img_size[0]), int(img_size[1])
+    partner, lam = None, 1.0
     if not isinstance(line, (list, tuple)):
         img_idx, pic_path, boxes, labels, _, _ = parse_line(line)
         img = _read_rgb(pic_path)
@@ -224,9 +235,49 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
         # the mix up case
         _, pic_path1, boxes1, labels1, _, _ = parse_line(line[0])
         img_idx, pic_path2, boxes2, labels2, _, _ = parse_line(line[1])
-        img, boxes = data_aug.mix_up(_read_rgb(pic_path1), _read_rgb(pic_path2), boxes1, boxes2, rng=rng)
+        img, partner = _read_rgb(pic_path1), _read_rgb(pic_path2)
+        lam, boxes = data_aug.mix_up_boxes(boxes1, boxes2, rng=rng)
         labels = np.concatenate((labels1, labels2))
-    if str(mode) == 'train':
+    if not feed_native.enabled():
+        if partner is not None:
+            img = data_aug.blend(img, partner, lam)
+        image, boxes = _augment_numpy(img, boxes, width, height, train, letterbox_resize, rng, prng)
+        # the input of yolo_v3 should be in range 0~1 (as_uint8: the caller divides - the feeder's workers hand the 8-bit
+        # image to the parent, a quarter of the bytes to pickle, and the parent divides straight into its pinned buffer)
+        image = np.ascontiguousarray(image, np.uint8) if as_uint8 else np.asarray(image, np.float32) / 255.
+        if out is not None:
+            out[...] = image
+            image = out
+        return img_idx, image, np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+
+    # the same recipe, pixels last: the draws and the boxes first (in parse_data's order), then one native pass
+    src_h = max(img.shape[0], partner.shape[0]) if partner is not None else img.shape[0]
+    src_w = max(img.shape[1], partner.shape[1]) if partner is not None else img.shape[1]
+    colour, offset, window, interp, flip = None, (0, 0), (0, 0, src_w, src_h), 1, False
+    if train:
+        colour = data_aug.color_distort_draws(rng=rng)
+        canvas_w, canvas_h = src_w, src_h
+        if rng.uniform(0, 1) > 0.5:                     # random expansion with prob 0.5
+            canvas_w, canvas_h, at_x, at_y = data_aug.expand_boxes(boxes, src_w, src_h, 4, prng=prng)
+            offset = (at_x, at_y)
+        boxes, window = data_aug.random_crop_with_constraints(boxes, (canvas_w, canvas_h), rng=rng, prng=prng)
+        interp = rng.randint(0, 5)                      # resize with random interpolation
+    boxes = data_aug.resize_boxes(boxes, window[2], window[3], width, height, letterbox_resize)
+    if train:
+        flip, _ = data_aug.flip_boxes(boxes, width, height, px=0.5, rng=rng)
+    resized, pad = (width, height), (0, 0)
+    if letterbox_resize:
+        _, fit_w, fit_h, pad_x, pad_y = data_aug.letterbox_geometry(window[2], window[3], width, height)
+        resized, pad = (fit_w, fit_h), (pad_x, pad_y)
+    image = feed_native.sample(img, partner, lam, colour, offset, window, interp, resized, (width, height), pad, 128, flip,
+                               out=out, as_float=not as_uint8)
+    return img_idx, image, np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+
+
+def _augment_numpy(img, boxes, width, height, train, letterbox_resize, rng, prng):
+    """parse_data's chain on the numpy / Pillow functions of utils.data_aug, one augmentation at a time."""
+    from . import data_aug
+    if train:
         img = data_aug.random_color_distort(img, rng=rng)
         if rng.uniform(0, 1) > 0.5:                     # random expansion with prob 0.5
             img, boxes = data_aug.random_expand(img, boxes, 4, prng=prng)
@@ -235,15 +286,9 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
         x0, y0, w, h = crop
         img = img[y0: y0 + h, x0: x0 + w]
         interp = rng.randint(0, 5)                      # resize with random interpolation
-        img, boxes = data_aug.resize_with_bbox(img, boxes, img_size[0], img_size[1], interp=interp,
-                                               letterbox=letterbox_resize)
-        img, boxes = data_aug.random_flip(img, boxes, px=0.5, rng=rng)
-    else:
-        img, boxes = resize_with_bbox(img, boxes, img_size[0], img_size[1], interp=1, letterbox=letterbox_resize)
-    # the input of yolo_v3 should be in range 0~1 (as_uint8: the caller divides - the feeder's workers hand the 8-bit
-    # image to the parent, a quarter of the bytes to pickle, and the parent divides straight into its pinned buffer)
-    img = np.ascontiguousarray(img, np.uint8) if as_uint8 else np.asarray(img, np.float32) / 255.
-    return img_idx, img, np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+        img, boxes = data_aug.resize_with_bbox(img, boxes, width, height, interp=interp, letterbox=letterbox_resize)
+        return data_aug.random_flip(img, boxes, px=0.5, rng=rng)
+    return resize_with_bbox(img, boxes, width, height, interp=1, letterbox=letterbox_resize)
 
 
 def parse_data(line, class_num, img_size, anchors, mode, letterbox_resize):
@@ -327,7 +372,7 @@ def collate(samples, out_images=None):
     for i, (idx, img, b, l) in enumerate(samples):
         if img.dtype == np.uint8:        # img.astype(float32) / 255. of parse_data, written in place (no temporaries)
             np.true_divide(img, np.float32(255.), out=images[i], dtype=np.float32)
-        else:
+        elif img.ctypes.data != images[i].ctypes.data:      # (a feeder thread has written its slot of out_images already)
             images[i] = img
         # REFERENCE QUIRK kept (SURVEY B.10 "do not fix silently"): the constrained crop of the 'train' chain drops boxes
         # (bbox_crop filters them) but parse_data never filters `labels`, and process_box labels box i with labels[i] -
