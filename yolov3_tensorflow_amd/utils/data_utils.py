@@ -206,7 +206,8 @@ iter_cnt = 0        # the reference's module-global batch counter (multi-scale: 
 
 def _read_rgb(pic_path):
     from PIL import Image
-    return np.asarray(Image.open(pic_path).convert('RGB'))
+    img = Image.open(pic_path)
+    return np.asarray(img if img.mode == 'RGB' else img.convert('RGB'))      # (convert() copies even RGB -> RGB)
 
 
 def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False, out=None):
