@@ -7,15 +7,13 @@ images goes forward -> decode -> per-class NMS on the device in one launch set (
 the loss of the batch is computed on the device from `process_box_batch` targets, and only the surviving detections
 cross to the host.  Weights: a darknet `.weights` file (`--restore_path`; the reference restores a TF checkpoint
 converted from the same file) or a native `.npz` checkpoint written by train.py / convert_weight.py.  Images are read
-with PIL and resized like the reference's validation path (cv2.INTER_LINEAR, plain or letterboxed) by the OpenCV-free
-restatement in utils.data_utils.
+with PIL and resized like the reference's validation path (cv2.INTER_LINEAR arithmetic, plain or letterboxed) by the
+feeder's worker threads (yolov3_tensorflow_amd.feeder, 'val' mode), ahead of the device.
 """
 from __future__ import division, print_function
 
 import argparse
 import sys
-
-import numpy as np
 
 
 def _flag(text):
@@ -31,8 +29,8 @@ OPTIONS = (
     ('class_name_path', str, './data/coco.names', 'class names file'),
     ('img_size', int, [416, 416], 'network input size as: width height'),
     ('letterbox_resize', _flag, False, 'true: keep the aspect ratio and pad; false: plain stretch'),
-    ('num_threads', int, 10, 'accepted for compatibility, unused'),
-    ('prefetech_buffer', int, 5, 'accepted for compatibility, unused'),
+    ('num_threads', int, 10, 'decode / resize worker threads of the feeder'),
+    ('prefetech_buffer', int, 5, 'batches the feeder keeps ahead of the device'),
     ('nms_threshold', float, 0.45, 'IoU above which NMS suppresses a box'),
     ('score_threshold', float, 0.01, 'class score below which a box is not a candidate'),
     ('nms_topk', int, 400, 'most detections kept per class'),
@@ -50,22 +48,11 @@ def build_parser():
     return parser
 
 
-def load_image(path, line_boxes, img_size, letterbox):
-    """PIL read + the reference's non-train preprocessing (utils/data_utils.py:163-173): resize_with_bbox(interp=1 =
-    cv2.INTER_LINEAR, restated in utils.data_utils.resize_bilinear_cv2), plain or letterboxed, to img_size [w, h];
-    returns (float32 RGB image in [0,1], boxes mapped to the new frame)."""
-    from PIL import Image
-    from yolov3_tensorflow_amd.utils.data_utils import resize_with_bbox
-    img = np.asarray(Image.open(path).convert('RGB'))
-    img, boxes = resize_with_bbox(img, line_boxes, img_size[0], img_size[1], interp=1, letterbox=letterbox)
-    return np.asarray(img, np.float32) / 255., boxes
-
-
 def main(argv=None):
     args = build_parser().parse_args(argv)
     import torch
     import yolov3_tensorflow_amd as y3
-    from yolov3_tensorflow_amd.utils.data_utils import parse_line, process_box_batch
+    from yolov3_tensorflow_amd.feeder import Feeder
     from yolov3_tensorflow_amd.utils.eval_utils import get_preds_batch, voc_eval, parse_gt_rec
     from yolov3_tensorflow_amd.utils import eval_utils
     from yolov3_tensorflow_amd.utils.misc_utils import (parse_anchors, read_class_names, AverageMeter, load_weights,
@@ -90,27 +77,21 @@ def main(argv=None):
     print('\n----------- start to eval -----------\n')
     meters = [AverageMeter() for _ in range(5)]      # total, xy, wh, conf, class
     val_preds = []
-    for start in range(0, args.img_cnt, args.batch_size):
-        chunk = [parse_line(l) for l in lines[start:start + args.batch_size]]
-        n = len(chunk)
-        kmax = max(len(c[3]) for c in chunk)
-        images = np.zeros((n, args.img_size[1], args.img_size[0], 3), np.float32)
-        boxes = np.zeros((n, kmax, 5), np.float32)
-        labels = np.zeros((n, kmax), np.int64)
-        counts = np.zeros((n,), np.int64)
-        for i, (_, pic_path, b, l, _, _) in enumerate(chunk):
-            images[i], nb = load_image(pic_path, b, args.img_size, args.letterbox_resize)
-            k = len(l)
-            boxes[i, :k, :4], boxes[i, :k, 4], labels[i, :k], counts[i] = nb, 1.0, l, k     # mix-up weight 1
-        y_true = process_box_batch(boxes, labels, counts, args.img_size, args.class_num, args.anchors)
+    # the reference's tf.data pipeline (eval.py:54-62: batch, py_func(get_batch_data) on num_threads workers, prefetch) is
+    # the feeder in 'val' mode: decode + resize (cv2.INTER_LINEAR arithmetic, plain or letterboxed) on worker threads into
+    # pinned buffers, side-stream upload and target assignment on the device, overlapped with the forward of the batch before
+    feeder = Feeder(lines, args.batch_size, args.class_num, args.img_size, args.anchors, mode='val',
+                    letterbox_resize=args.letterbox_resize, num_threads=args.num_threads, prefetch=args.prefetech_buffer)
+    for batch in feeder.epoch(0):
         with y3.variable_scope('yolov3'):
-            fms = yolo_model.forward(images, False)
-        loss = yolo_model.compute_loss(fms, y_true)
+            fms = yolo_model.forward(batch.images, False)
+        loss = yolo_model.compute_loss(fms, batch.y_true)
         pb, _, _, ps = yolo_model.predict(fms, with_scores=True)
         dets = gpu_nms_batched(pb, ps, args.class_num, args.nms_topk, args.score_threshold, args.nms_threshold)
-        val_preds.extend(get_preds_batch([c[0] for c in chunk], dets))
+        val_preds.extend(get_preds_batch(batch.image_ids, dets))
         for m, v in zip(meters, loss):
-            m.update(float(v), n)
+            m.update(float(v), len(batch.image_ids))
+    feeder.close()
 
     rec_total, prec_total, ap_total = AverageMeter(), AverageMeter(), AverageMeter()
     eval_utils.gt_dict = {}

@@ -10,7 +10,7 @@ or stale one is rebuilt on first use; when that is impossible the error is raise
 import ctypes
 import os
 import threading
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
 
 import numpy as np
 
@@ -33,7 +33,6 @@ class Job(ctypes.Structure):            # y3f_job
                 ("pad_y", c_int32), ("pad_value", c_int32), ("flip_x", c_int32)]
 
 
-_U8 = POINTER(c_uint8)
 # name -> (restype, argtypes); tests/test_feed_native.py checks this table against the header
 PROTOTYPES = {
     "y3f_last_error": (c_char_p, []),
