@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — the YOLOv3 hot path on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|c5|feeder]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -17,6 +17,8 @@ Workloads
   c4 (configs[3]): one TRAIN step — forward(is_training) -> compute_loss -> backward -> bucketed RCCL all-reduce of the
      gradients (overlapped with backward) -> clip -> SGD update of the whole model — at 416x416, bs=64 per GPU.
   c5 (configs[4]): the c2 forward with bf16 storage at 608x608, bs=16 per GPU.
+  feeder: the host side of c4 alone - one feeder per rank (10 worker threads, prefetch 5: the reference's defaults) decoding
+     synthetic JPEGs, augmenting, resizing to 416x416 and uploading bs=64 batches that nothing consumes (run_feeder).
 Prints ONE JSON line on rank 0.
 
 roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the two
@@ -35,7 +37,8 @@ cpu_baseline: the CPU oracle's torch-fp32 restatement of the same graph ("port";
 here: no TensorFlow), same weights, ONE bounded sample, rank 0 and N=1 only.
 box_delta_vs_oracle: outside the timed region, the decoded boxes/confs/probs of all 32 images of the bench batch against
 the CPU oracle in fp32 and fp64 (BASELINE metric: "box delta vs ref"), with the fp32 oracle's own drift beside them.
-detect / c5 / c4: the other BASELINE configurations as secondary objects of the c2 line (measured after everything above).
+detect / c5 / c4 / feeder: the other BASELINE configurations, and the host side of c4, as secondary objects of the c2 line
+(measured after everything above).
 """
 import argparse
 import json
@@ -337,11 +340,12 @@ def parse_args(argv):
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
-                    help="c2 only: skip the secondary objects (fast_path / direct_path, detect, c5, c4) measured after the "
+                    help="c2 only: skip the secondary objects (fast_path / direct_path, detect, c5, c4, feeder) measured after the "
                          "timed region of `value`")
-    ap.add_argument('--workload', choices=['c2', 'c4', 'c5'], default='c2',
+    ap.add_argument('--workload', choices=['c2', 'c4', 'c5', 'feeder'], default='c2',
                     help="c2 (default, the BASELINE metric): fp32 forward 416x416 bs=32; c4: train step 416x416 bs=64 "
-                         "per GPU, SGD, RCCL gradient all-reduce; c5: bf16-storage forward 608x608 bs=16")
+                         "per GPU, SGD, RCCL gradient all-reduce; c5: bf16-storage forward 608x608 bs=16; feeder: the "
+                         "host side of c4 alone (decode + augment + resize + upload of bs=64 batches, nothing consuming)")
     ap.add_argument('--precision', choices=['f32_wino', 'f32', 'f32_bf16x6', 'f32_bf16x3'], default='f32_wino',
                     help="c2/c4. f32_wino (default): fp32 MFMA arithmetic, Winograd kernels for the stride-1 3x3 convs "
                          "(forward: F(4x4,3x3) where the library prefers it, F(2x2,3x3) elsewhere; train step: F(2x2,3x3)), "
@@ -375,7 +379,7 @@ def main(argv=None):
 
     def set_workload(name, batch=None):
         global BATCH, SIZE
-        BATCH, SIZE = {'c2': (32, 416), 'c4': (64, 416), 'c5': (16, 608)}[name]
+        BATCH, SIZE = {'c2': (32, 416), 'c4': (64, 416), 'c5': (16, 608), 'feeder': (64, 416)}[name]
         if batch:
             BATCH = batch
 
@@ -407,6 +411,8 @@ def main(argv=None):
 
     if args.workload == 'c4':
         out = run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks)
+    elif args.workload == 'feeder':
+        out = run_feeder(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks)
     else:
         out = run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks)
     if args.workload == 'c2' and not args.no_secondary and args.batch is None:
@@ -421,18 +427,18 @@ def main(argv=None):
         # SECONDARY_BUDGET_S rank 0 prints what it has and every rank leaves with status 0.
         def give_up():
             if rank == 0 and out is not None:
-                for name in ('detect', 'c5', 'c4'):
+                for name in ('detect', 'c5', 'c4', 'feeder'):
                     out.setdefault(name, {"error": "not finished within %d s (watchdog)" % SECONDARY_BUDGET_S})
                 print(json.dumps(out), flush=True)
             os._exit(0)
         watchdog = threading.Timer(SECONDARY_BUDGET_S, give_up)
         watchdog.daemon = True
         watchdog.start()
-        for name, fn in (('detect', run_detect), ('c5', run_forward), ('c4', run_train)):
+        for name, fn in (('detect', run_detect), ('c5', run_forward), ('c4', run_train), ('feeder', run_feeder)):
             sub = copy.copy(args)
             sub.workload = name if name != 'detect' else 'c2'
             sub.no_secondary, sub.no_cpu_baseline, sub.secondary = True, True, True
-            sub.steps, sub.warmup = (8, 3) if name == 'c4' else (10, 3)
+            sub.steps, sub.warmup = (8, 3) if name in ('c4', 'feeder') else (10, 3)
             set_workload(sub.workload)
             try:
                 torch.cuda.empty_cache()
@@ -450,12 +456,57 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
+def run_feeder(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks):
+    """SURVEY.md 8f row 1, the host side of the train step on its own: every rank's feeder (reference train.py:34-43:
+    num_parallel_calls = 10, prefetch 5) decodes synthetic 640x480 JPEGs, runs the reference's 'train' augmentation chain
+    with mix-up, resizes to 416x416, fills pinned buffers and uploads bs=64 batches - with nothing consuming them but this
+    loop, so the figure is what the host side can deliver, to be read against what the c4 step consumes."""
+    import importlib.util
+    import pathlib
+    import tempfile
+    spec = importlib.util.spec_from_file_location('feeder_rate', os.path.join(ROOT, 'tools', 'feeder_rate.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    from yolov3_tensorflow_amd.feeder import Feeder
+    workers, prefetch = 10, 5
+    total = (args.steps + args.warmup + 1) * BATCH
+    with tempfile.TemporaryDirectory() as folder:
+        lines = tool.write_set(pathlib.Path(folder), 256, seed=rank)
+        lines = (lines * (total // len(lines) + 1))[:total]
+        feeder = Feeder(lines, BATCH, CLASS_NUM, [SIZE, SIZE], tool.ANCHORS, mode='train', use_mix_up=True,
+                        num_threads=workers, prefetch=prefetch, seed=1 + rank)
+        it = feeder.epoch(0)
+        for _ in range(args.warmup):
+            next(it)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            next(it)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        it.close()
+        feeder.close()
+    if rank != 0:
+        return None
+    return {
+        "metric": "images/sec delivered by the feeder (decode + 'train' augmentation with mix-up + resize to 416x416 + "
+                  "upload), nothing consuming",
+        "value": round(world * BATCH * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic 640x480 JPEGs, 1-7 boxes each",
+        "config": {"workload": "the host side of configs[3]: per GPU one feeder, %d worker threads, prefetch %d, bs=%d, "
+                               "pixel work in liby3feed.so" % (workers, prefetch, BATCH),
+                   "batch_per_gpu": BATCH, "image_size": SIZE, "backend": feeder.backend, "workers": workers},
+    }
+
+
 def slim(res):
     """A secondary object of the c2 line: the measurement, its workload and its roofline (no nested secondaries)."""
     if res is None or 'error' in res:
         return res
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'dtype', 'precision', 'scaling',
-            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes')
+            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data')
     return {k: res[k] for k in keep if k in res}
 
 
