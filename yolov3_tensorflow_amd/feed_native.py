@@ -4,8 +4,8 @@
 The numpy / Pillow functions of utils/data_aug.py and utils/data_utils.py DEFINE what this library computes (and pin the
 draws and the box arithmetic against the reference); the library produces the same bytes several times faster and in a
 single pass (tests/test_feed_native.py holds it to bit equality).  `enabled()` is what the feeder's per-sample code asks:
-true unless Y3_FEED_NATIVE=0.  The library is built by yolov3_tensorflow_amd.build (g++, a second and a half) and a missing
-or stale one is rebuilt on first use; when that is impossible the error is raised, not swallowed.
+true unless Y3_FEED_NATIVE=0.  The library is built by yolov3_tensorflow_amd.build (g++, a second and a half); a missing one
+is built on first use, and when that is impossible the error is raised, not swallowed.
 """
 import ctypes
 import os
@@ -56,19 +56,22 @@ def enabled():
 
 
 def lib():
-    """The loaded library (built first if it is missing or older than its source)."""
+    """The loaded library.  A missing one is built first (g++, a second and a half; `python -m yolov3_tensorflow_amd.build`
+    is what rebuilds a stale one); a failure to build or load is raised."""
     global _lib
     if _lib is not None:
         return _lib
     with _lock:
         if _lib is None:
-            if "Y3_FEED_LIB_PATH" not in os.environ:
+            if not os.path.exists(LIB_PATH) and "Y3_FEED_LIB_PATH" not in os.environ:
                 from . import build
                 build.build_feed(verbose=False)
             handle = ctypes.CDLL(LIB_PATH)
             for name, (restype, argtypes) in PROTOTYPES.items():
-                fn = getattr(handle, name)
+                fn = getattr(handle, name)          # AttributeError if the symbol is missing
                 fn.restype, fn.argtypes = restype, argtypes
+            if handle.y3f_abi_version() != 1:
+                raise RuntimeError("liby3feed.so ABI version mismatch: rebuild with `python -m yolov3_tensorflow_amd.build`")
             _lib = handle
     return _lib
 
