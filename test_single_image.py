@@ -36,7 +36,7 @@ def parse_args(argv):
 
 def to_network_frame(image, size, letterbox):
     """uint8 RGB image -> ([1,h,w,3] float32 in [0,1], function mapping network-frame boxes back to the image)."""
-    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize, resize_bilinear_cv2
+    from yolov3_tensorflow_amd.utils.data_utils import letterbox_resize, _resize
     h0, w0 = image.shape[:2]
     if letterbox:
         resized, ratio, dw, dh = letterbox_resize(image, size[0], size[1])
@@ -47,7 +47,7 @@ def to_network_frame(image, size, letterbox):
             return boxes
     else:
         # cv2.resize(img_ori, tuple(new_size)): OpenCV's default interpolation, INTER_LINEAR (test_single_image.py:43)
-        resized = resize_bilinear_cv2(image, size[0], size[1])
+        resized = _resize(image, size[0], size[1], 1)
 
         def back(boxes):
             boxes[:, [0, 2]] *= w0 / float(size[0])

@@ -44,6 +44,39 @@ def test_reference_demo_script_runs_unchanged_in_dry_run(tmp_path):
         assert im.size == (1296, 729)
 
 
+def _tiny_video(path, frames=5, size=(320, 240), fps=12.0, seed=3):
+    """A short Motion-JPEG AVI of smooth random frames, written by this package's own writer; returns the frames."""
+    from PIL import Image
+    from yolov3_tensorflow_amd.utils.video_utils import MjpegAviWriter
+    rng = np.random.RandomState(seed)
+    made = []
+    with MjpegAviWriter(str(path), fps, size, quality=92) as w:
+        for _ in range(frames):
+            small = rng.randint(0, 256, (size[1] // 16, size[0] // 16, 3)).astype(np.uint8)
+            made.append(np.asarray(Image.fromarray(small).resize(size, Image.BICUBIC)))
+            w.write(made[-1])
+    return made
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='the reference checkout is not on this machine')
+def test_reference_video_script_runs_unchanged_in_dry_run(tmp_path):
+    """video_test.py of the reference, byte-unchanged: cv2.VideoCapture / VideoWriter of the shim over a Motion-JPEG AVI,
+    per-frame letterbox, Session.run, box drawing, putText, imshow / waitKey, and the saved result video."""
+    os.makedirs(tmp_path / 'data')
+    for f in ('yolo_anchors.txt', 'coco.names'):
+        with open(os.path.join(ROOT, 'data', f)) as src, open(tmp_path / 'data' / f, 'w') as dst:
+            dst.write(src.read())
+    _tiny_video(tmp_path / 'in.avi', frames=4)
+    rc, out = _run(os.path.join(REF, 'video_test.py'), [str(tmp_path / 'in.avi'), '--save_video', 'true'], str(tmp_path),
+                   {'Y3_COMPAT_DRY_RUN': '1'})
+    assert rc == 0, out[-3000:]
+    assert 'writing Motion-JPEG to video_result.avi' in out           # asked for mp4v into video_result.mp4
+    from yolov3_tensorflow_amd.utils.video_utils import open_video
+    result = open_video(str(tmp_path / 'video_result.avi'))
+    assert (result.frame_count, result.width, result.height, int(result.fps)) == (4, 320, 240, 12)
+    assert result.read().shape == (240, 320, 3)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason='the reference checkout is not on this machine')
 def test_reference_convert_script_runs_unchanged_in_dry_run(tmp_path):
     os.makedirs(tmp_path / 'data' / 'darknet_weights')

@@ -1,4 +1,4 @@
-"""The reference's OWN driver scripts (convert_weight.py, test_single_image.py, eval.py, train.py + args.py), byte-unchanged,
+"""The reference's OWN driver scripts (convert_weight.py, test_single_image.py, video_test.py, eval.py, train.py + args.py), byte-unchanged,
 run for real on the device through `python -m yolov3_tensorflow_amd.compat.run`.
 
 The scripts are not part of this repository and /root/reference does not exist on the GPU box: tools/gpu_reference_scripts.sh
@@ -16,7 +16,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SCRIPTS = os.environ.get('Y3_REFERENCE_SCRIPTS') or os.path.join(ROOT, 'oracle', '_ref', 'scripts')
-NEEDED = ('convert_weight.py', 'test_single_image.py', 'eval.py', 'train.py', 'args.py')
+NEEDED = ('convert_weight.py', 'test_single_image.py', 'video_test.py', 'eval.py', 'train.py', 'args.py')
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not all(os.path.exists(os.path.join(SCRIPTS, f)) for f in NEEDED),
@@ -79,6 +79,41 @@ def test_reference_demo_script_reproduces_the_golden_detections(workdir):
     from PIL import Image
     with Image.open(os.path.join(workdir, 'detection_result.jpg')) as im:
         assert im.size == (1296, 729)
+
+
+def test_reference_video_script_detects_on_every_frame(workdir):
+    """video_test.py on a three-frame Motion-JPEG AVI of the demo image (the third frame mirrored): the last frame's
+    detections are left in the script's globals, the annotated result video has the three frames at the source size."""
+    from PIL import Image
+    from yolov3_tensorflow_amd.utils.video_utils import MjpegAviWriter, open_video
+    picture = np.asarray(Image.open(os.path.join(HERE, 'golden', 'messi.jpg')).convert('RGB').resize((648, 364), Image.BICUBIC))
+    clip = os.path.join(workdir, 'clip.avi')
+    with MjpegAviWriter(clip, 10, (648, 364), quality=95) as w:
+        for frame in (picture, picture, picture[:, ::-1]):
+            w.write(frame)
+    res = os.path.join(workdir, 'video_det.npz')
+    rc, out = _run('video_test.py', [clip, '--save_video', 'true'], workdir, keep=(res, ['boxes_', 'scores_', 'labels_', 'i']))
+    assert rc == 0, out[-3000:]
+    d = np.load(res)
+    print('video_test.py (reference, compat): %d detections on the last of 3 frames, scores %.3f..%.3f'
+          % (len(d['labels_']), d['scores_'].min(), d['scores_'].max()))
+    assert len(d['labels_']) > 20 and d['scores_'].min() >= 0.3
+    assert (d['boxes_'][:, 2] > d['boxes_'][:, 0]).all() and np.isfinite(d['boxes_']).all()
+    # this package's own video_test.py on the same clip and weights finds the same number of objects on that frame
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'video_test.py'), clip, '--restore_path',
+                        os.path.join(workdir, 'data', 'darknet_weights', 'yolov3.weights'), '--anchor_path',
+                        os.path.join(ROOT, 'data', 'yolo_anchors.txt'), '--class_name_path',
+                        os.path.join(ROOT, 'data', 'coco.names'), '--batch_size', '1'],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    native = r.stdout.decode(errors='replace')
+    assert r.returncode == 0, native[-3000:]
+    counts = [int(v) for v in re.findall(r'frame \d+: (\d+) detections', native)]
+    print('video_test.py (native twin): detections per frame %s' % counts)
+    assert len(counts) == 3 and abs(counts[2] - len(d['labels_'])) <= 2
+    result = open_video(os.path.join(workdir, 'video_result.avi'))
+    assert (result.frame_count, result.width, result.height) == (3, 648, 364)
+    first = result.read()
+    assert np.abs(first.astype(int) - picture.astype(int)).mean() > 0.5           # boxes and the time were drawn on it
 
 
 def test_reference_eval_script_matches_the_native_eval(workdir):
