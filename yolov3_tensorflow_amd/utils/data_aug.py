@@ -160,7 +160,9 @@ def _candidate_windows(prng, rows, w, h, min_scale, max_scale, max_aspect_ratio,
 
 def _candidate_windows_native(prng, rows, w, h, min_scale, max_scale, max_aspect_ratio, bands, max_trial):
     """_candidate_windows in liby3feed.so (y3f_crop_candidates), drawing from prng's own Mersenne Twister state: the same
-    windows, and prng left exactly where the Python loop would leave it (tests/test_feed_native.py)."""
+    windows, and prng left exactly where the Python loop would leave it (tests/test_feed_native.py).  getstate -> search ->
+    setstate is not atomic: like any use of one generator from several threads, it needs a generator per thread (the feeder
+    gives every sample its own)."""
     import ctypes
     from .. import feed_native
     version, words, gauss = prng.getstate()

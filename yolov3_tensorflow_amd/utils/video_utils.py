@@ -46,6 +46,14 @@ class AviReader(object):
     def __init__(self, path):
         self.path = path
         self._f = open(path, 'rb')
+        try:
+            self._open()
+        except Exception:
+            self._f.close()
+            raise
+
+    def _open(self):
+        path = self.path
         head = self._f.read(12)
         if len(head) < 12 or head[:4] != b'RIFF' or head[8:12] != b'AVI ':
             raise VideoError("%s is not an AVI (RIFF) file" % path)
