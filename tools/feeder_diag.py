@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Why the feeder's workers come from a forkserver: time to start four workers and get one batch of samples back, in a
-fresh process and after the process has pinned 8 GB of host memory (what a training process does: the feeder's own
-batches are pinned), with workers FORKED from this process against workers from the forkserver pool.
+"""Why the feeder's worker PROCESSES (backend='process'; the default backend is threads over liby3feed.so) come from a
+forkserver: time to start four workers and get one batch of samples back, in a fresh process and after the process has
+pinned 8 GB of host memory (what a training process does: the feeder's own batches are pinned), with workers FORKED from
+this process against workers from the forkserver pool.
 
     python tools/feeder_diag.py          (needs a GPU for the pinned allocations)
 
