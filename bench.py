@@ -15,7 +15,9 @@ Workloads
      independent replica on its own stream; torch.distributed (RCCL) carries only the two barriers and the max-over-ranks
      of the elapsed time.
   c4 (configs[3]): one TRAIN step — forward(is_training) -> compute_loss -> backward -> bucketed RCCL all-reduce of the
-     gradients (overlapped with backward) -> clip -> SGD update of the whole model — at 416x416, bs=64 per GPU.
+     gradients (overlapped with backward) -> clip -> SGD update of the whole model — at 416x416, bs=64 per GPU.  `value` is
+     measured on resident synthetic tensors; `fed` repeats the steps with the batches coming from the feeder (JPEG decode,
+     the reference's augmentation chain, resize, upload, target assignment under the steps).
   c5 (configs[4]): the c2 forward with bf16 storage at 608x608, bs=16 per GPU.
   feeder: the host side of c4 alone - one feeder per rank (10 worker threads, prefetch 5: the reference's defaults) decoding
      synthetic JPEGs, augmenting, resizing to 416x416 and uploading bs=64 batches that nothing consumes (run_feeder).
@@ -353,6 +355,7 @@ def parse_args(argv):
                          "f32_bf16x3: fp32 tensors, every product rebuilt from 6 / 3 bf16 plane products with fp32 "
                          "accumulation")
     ap.add_argument('--batch', type=int, default=None, help="per-GPU batch (default: the workload's BASELINE value)")
+    ap.add_argument('--no-fed', action='store_true', help="c4: skip the repetition of the steps on batches from the feeder")
     ap.add_argument('--head-only', action='store_true', help="c4: update only yolov3/yolov3_head (the reference's "
                                                              "default update_part) instead of the whole model")
     args = ap.parse_args(argv)
@@ -506,7 +509,7 @@ def slim(res):
     if res is None or 'error' in res:
         return res
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'dtype', 'precision', 'scaling',
-            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data')
+            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data', 'fed')
     return {k: res[k] for k in keep if k in res}
 
 
@@ -666,8 +669,11 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         fw.check_context()
-    loss0 = float(loss[0])
-    assert np.isfinite(loss0), "non-finite loss"
+        loss0 = float(loss[0])
+        assert np.isfinite(loss0), "non-finite loss"
+        # the same steps with the batches coming from the feeder (decode + augmentation + resize + upload + target assignment
+        # under the steps): never `value`, reported beside it
+        fed = None if args.no_fed else fed_train_steps(args, trainer, torch, rank, barrier, max_over_ranks)
     if rank != 0:
         return None
     table = [(l['k'], l['stride'], l['cin'], l['cout'], l['bn']) for l in model._train['topo'].layers]
@@ -712,7 +718,44 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
                                "count) over the step time, BN / loss / update kernels included in the time; "
                                "achieved_algorithmic counts direct-convolution FLOPs"},
         "loss": round(loss0, 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+        "fed": None if fed is None else dict(fed, images_per_s=round(world * BATCH / (fed["ms_per_step"] * 1e-3), 2)),
     }
+
+
+def fed_train_steps(args, trainer, torch, rank, barrier, max_over_ranks):
+    """The c4 step with its batches decoded, augmented ('train' chain with mix-up), resized, uploaded and target-assigned by
+    the feeder while the device runs the previous step (reference train.py:34-58: num_parallel_calls = 10, prefetch 5)."""
+    import importlib.util
+    import pathlib
+    import tempfile
+    spec = importlib.util.spec_from_file_location('feeder_rate', os.path.join(ROOT, 'tools', 'feeder_rate.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    from yolov3_tensorflow_amd.feeder import Feeder
+    warm, workers, prefetch = 2, 10, 5
+    total = (args.steps + warm + 1) * BATCH
+    with tempfile.TemporaryDirectory() as folder:
+        lines = tool.write_set(pathlib.Path(folder), 256, seed=rank)
+        lines = (lines * (total // len(lines) + 1))[:total]
+        feeder = Feeder(lines, BATCH, CLASS_NUM, [SIZE, SIZE], tool.ANCHORS, mode='train', use_mix_up=True,
+                        num_threads=workers, prefetch=prefetch, seed=1 + rank)
+        it = feeder.epoch(0)
+        for _ in range(warm):
+            batch = next(it)
+            loss = trainer.step(batch.images, batch.y_true)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            batch = next(it)
+            loss = trainer.step(batch.images, batch.y_true)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        it.close()
+        feeder.close()
+    assert np.isfinite(float(loss[0])), "non-finite loss on fed batches"
+    return {"ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps, "workers": workers,
+            "prefetch": prefetch, "backend": feeder.backend,
+            "data": "synthetic 640x480 JPEGs through the reference's 'train' augmentation chain with mix-up"}
 
 
 # ------------------------------------------------------------------------------------------------------------
