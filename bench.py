@@ -673,7 +673,12 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
         assert np.isfinite(loss0), "non-finite loss"
         # the same steps with the batches coming from the feeder (decode + augmentation + resize + upload + target assignment
         # under the steps): never `value`, reported beside it
-        fed = None if args.no_fed else fed_train_steps(args, trainer, torch, rank, barrier, max_over_ranks)
+        fed = None
+        if not args.no_fed:
+            try:
+                fed = fed_train_steps(args, trainer, torch, rank, barrier, max_over_ranks)
+            except Exception as e:      # the fed repetition must never cost the resident measurement
+                fed = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank != 0:
         return None
     table = [(l['k'], l['stride'], l['cin'], l['cout'], l['bn']) for l in model._train['topo'].layers]
@@ -718,7 +723,8 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
                                "count) over the step time, BN / loss / update kernels included in the time; "
                                "achieved_algorithmic counts direct-convolution FLOPs"},
         "loss": round(loss0, 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
-        "fed": None if fed is None else dict(fed, images_per_s=round(world * BATCH / (fed["ms_per_step"] * 1e-3), 2)),
+        "fed": fed if fed is None or "error" in fed
+        else dict(fed, images_per_s=round(world * BATCH / (fed["ms_per_step"] * 1e-3), 2)),
     }
 
 
