@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Where the forward's time above its own bound sits, by kernel family (DESIGN.md section 8's table).
+
+    python tools/gap_table.py [profiles/r03_layers_bs32_416_wino.csv] [--batch 32] [--size 416]
+
+Input: the per-layer csv of tools/layer_profile.py (layer, k, stride, cin, cout, ms).  Per layer the bound is
+max(algorithmic bytes / 8 TB/s, ISSUED FLOPs / 157.3 TF/s) - bench.py's `whole_forward_frac` accounting: a Winograd
+F(2x2,3x3) layer issues 16/36 of the direct-convolution FLOPs, an F(4x4,3x3) layer (the 128->256 and 512->1024 convs at
+this batch) 36/144 times the padding of its 4x4 tiles.  No GPU needed.
+"""
+import argparse
+import collections
+import csv
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('csv', nargs='?', default=os.path.join(ROOT, 'profiles', 'r03_layers_bs32_416_wino.csv'))
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=416)
+    args = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = list(csv.DictReader(open(args.csv)))
+    table = [(int(r['k']), int(r['stride']), int(r['cin']), int(r['cout']), 1) for r in rows]
+    ms = np.array([float(r['ms']) for r in rows])
+    flops = bench.conv_flops(table, args.batch, args.size, args.size)
+    nbytes = bench.conv_bytes(table, args.batch, args.size, args.size)
+    grids = bench.layer_input_grids(table, args.size)
+    names, factor = [], []
+    for (k, s, cin, cout, _), g in zip(table, grids):
+        if k == 3 and s == 1 and cin >= 32:
+            if (cin, cout) in ((128, 256), (512, 1024)):          # y3_conv_wino44_candidate; preferred at this batch
+                t = -(-g // 4) * 4
+                names.append('F(4x4,3x3) %d->%d @%d' % (cin, cout, g))
+                factor.append(0.25 * t * t / float(g * g))
+            else:
+                names.append('F(2x2,3x3) %d->%d @%d' % (cin, cout, g))
+                factor.append(16.0 / 36.0)
+        else:
+            names.append('3x3 stride 2' if (k, s) == (3, 2) else ('1x1' if k == 1 else 'stem'))
+            factor.append(1.0)
+    issued = flops * np.array(factor)
+    bound = np.maximum(nbytes / (bench.PEAK_HBM_TBPS * 1e12), issued / (bench.PEAK_FP32_MFMA_TFLOPS * 1e12)) * 1e3
+    groups = collections.OrderedDict()
+    for i, name in enumerate(names):
+        g = groups.setdefault(name, [0, 0.0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += ms[i]
+        g[2] += bound[i]
+        g[3] += issued[i]
+    print('%-26s %3s %9s %9s %6s %8s %10s' % ('layers', 'n', 'ms', 'bound ms', 'frac', 'gap ms', 'TF/s issued'))
+    for name, (n, m, b, iss) in sorted(groups.items(), key=lambda kv: kv[1][2] - kv[1][1]):
+        print('%-26s %3d %9.3f %9.3f %6.2f %8.3f %10.1f' % (name, n, m, b, b / m, m - b, iss / m / 1e9))
+    print('%-26s %3d %9.3f %9.3f %6.2f %8.3f' % ('whole forward', len(ms), ms.sum(), bound.sum(), bound.sum() / ms.sum(),
+                                                 ms.sum() - bound.sum()))
+
+
+if __name__ == '__main__':
+    main()
