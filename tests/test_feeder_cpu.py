@@ -160,3 +160,41 @@ def test_worker_pool_is_shared_started_from_a_forkserver_and_reproducible(tmp_pa
     assert got[1] is slot
     np.testing.assert_array_equal(slot, want[1].astype(np.float32) / np.float32(255.))
     f3.close()
+
+
+def test_batch_workers_of_get_batch_data(tmp_path, monkeypatch):
+    """utils.data_utils.BATCH_WORKERS (the reference's num_parallel_calls, handed over by the compat tf.data shim): 'val'
+    batches do not depend on it; 'train' batches on worker threads are reproducible from the global numpy seed."""
+    import threading
+    from yolov3_tensorflow_amd.utils import data_utils
+    lines = _write_set(tmp_path)
+    one = data_utils._map_samples(lines, [96, 64], 'val', True)
+    monkeypatch.setattr(data_utils, 'BATCH_WORKERS', 4)
+    seen = set()
+    real = data_utils.parse_sample
+
+    def spy(*a, **k):
+        seen.add(threading.current_thread().name)
+        return real(*a, **k)
+    monkeypatch.setattr(data_utils, 'parse_sample', spy)
+    four = data_utils._map_samples(lines, [96, 64], 'val', True)
+    assert all(n.startswith('y3-batch') for n in seen) and len(one) == len(four) == len(lines)
+    for a, b in zip(one, four):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+    np.random.seed(11)
+    t1 = data_utils._map_samples(lines, [96, 64], 'train', False)
+    np.random.seed(11)
+    t2 = data_utils._map_samples(lines, [96, 64], 'train', False)
+    for a, b in zip(t1, t2):
+        for x, y in zip(a[1:], b[1:]):
+            np.testing.assert_array_equal(x, y)
+    assert any(not np.array_equal(a[1], b[1]) for a, b in zip(t1, one))         # augmented: not the plain resize
+    # the shim's map() is what raises the setting
+    from yolov3_tensorflow_amd import compat
+    compat.install()
+    import tensorflow as tf
+    monkeypatch.setattr(data_utils, 'BATCH_WORKERS', 1)
+    tf.data.TextLineDataset(str(tmp_path / 'none.txt')).batch(2).map(lambda x: x, num_parallel_calls=6).prefetch(3)
+    assert data_utils.BATCH_WORKERS == 6

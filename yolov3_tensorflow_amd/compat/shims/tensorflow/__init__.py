@@ -200,10 +200,18 @@ class _Dataset(object):
         return _Dataset(shuffled)
 
     def map(self, map_func, num_parallel_calls=None):
+        """The map function becomes part of the element's graph and runs when a Session.run asks for the element.
+        num_parallel_calls: the reference maps py_func(get_batch_data) over BATCHES of lines (train.py:37-43); the
+        parallelism is handed to get_batch_data, which runs that many of a batch's samples at once
+        (utils.data_utils.BATCH_WORKERS) - same throughput lever, no speculative evaluation of graph nodes."""
+        if num_parallel_calls and int(num_parallel_calls) > 1:
+            from yolov3_tensorflow_amd.utils import data_utils as _du
+            _du.BATCH_WORKERS = max(int(_du.BATCH_WORKERS), int(num_parallel_calls))
         prev = self._graph
         return _Dataset(self._source, (lambda x: map_func(prev(x))) if prev else map_func)
 
     def prefetch(self, buffer_size):
+        """Accepted; elements are produced when a run asks for them (nothing is computed ahead of the session)."""
         return self
 
     def repeat(self, count=None):

@@ -353,10 +353,38 @@ def get_batch_data(batch_line, class_num, img_size, anchors, mode, multi_scale=F
     batch_line = [l for l in (batch_line.tolist() if hasattr(batch_line, 'tolist') else list(batch_line))]
     if mix_up and mode == 'train':
         batch_line = mix_up_lines(batch_line)
-    samples = [parse_sample(line, img_size, mode, letterbox_resize) for line in batch_line]
+    samples = _map_samples(batch_line, img_size, mode, letterbox_resize)
     ids, images, boxes, labels, counts = collate(samples)
     ys = process_box_batch(boxes, labels, counts, img_size, int(class_num), anchors)
     return (np.asarray(ids, np.int64), images) + tuple(y.cpu().numpy() for y in ys)
+
+
+# How many parse_sample calls of ONE get_batch_data batch run at once: the `num_parallel_calls` of the reference's
+# `dataset.map(py_func(get_batch_data), num_parallel_calls=args.num_threads)` (train.py:37-43), which the compat tf.data shim
+# hands over.  1 (the default): in the calling thread, on the process-global generators, exactly like one py_func call of
+# the reference.  More: worker threads (the pixel work releases the GIL); a 'train' batch then gives every line its own
+# generators, seeded in line order from the global numpy generator - the samples no longer depend on which thread ran
+# first, but they are not the ones the single-threaded call would draw.
+BATCH_WORKERS = 1
+_BATCH_POOLS = {}
+
+
+def _map_samples(lines, img_size, mode, letterbox_resize):
+    import random as _random
+    workers = min(int(BATCH_WORKERS), len(lines))
+    if workers <= 1:
+        return [parse_sample(line, img_size, mode, letterbox_resize) for line in lines]
+    from concurrent.futures import ThreadPoolExecutor
+    pool = _BATCH_POOLS.get(workers)
+    if pool is None:
+        pool = _BATCH_POOLS[workers] = ThreadPoolExecutor(workers, thread_name_prefix='y3-batch')
+    if str(mode) == 'train':
+        seeds = [int(v) for v in np.random.randint(0, 2 ** 31 - 1, size=len(lines))]
+        jobs = [pool.submit(parse_sample, line, img_size, mode, letterbox_resize, np.random.RandomState(seed),
+                            _random.Random(seed)) for line, seed in zip(lines, seeds)]
+    else:
+        jobs = [pool.submit(parse_sample, line, img_size, mode, letterbox_resize) for line in lines]
+    return [j.result() for j in jobs]
 
 
 def collate(samples, out_images=None):
