@@ -4,7 +4,7 @@
 its constants turned into options: objects marked difficult are skipped, images without a remaining object or without a
 file on disk are skipped, indices count the lines written.
 
-    python misc/parse_voc_xml.py --names ./data/voc.names \\
+    python misc/parse_voc_xml.py --names ./voc_names.txt \\
         --train /data/VOCdevkit/VOC2007:trainval /data/VOCdevkit/VOC2012:trainval --val /data/VOCdevkit/VOC2007:test \\
         --train_out train.txt --val_out val.txt
 """
