@@ -8,7 +8,8 @@ rebuilt for one process per GPU with the device-resident target assignment of th
   * `num_threads` workers (reference: args.num_threads = 10) decode, augment and resize ONE image each
     (utils.data_utils.parse_sample).  The pixel work - blend, colour jitter, crop, resize, pad, flip, /255 - and the crop
     search run in liby3feed.so (include/yolo355_feed.h: native code where the reference's is OpenCV), which releases the
-    GIL, as PIL's JPEG decoder does; a worker holds the GIL for well under a millisecond per image.  So the workers are
+    GIL, as PIL's JPEG decoder does; a worker holds the GIL for a little under a millisecond per image (which levels one
+    process off at 1,000-1,200 images/s: profiles/r03_feeder_rate.txt).  So the workers are
     THREADS by default (backend='thread') and each writes its float32 image straight into its slot of the batch's pinned
     host buffer: no pickling, no second pass.  backend='process' keeps the round-2 arrangement for the numpy / Pillow
     pixel path (Y3_FEED_NATIVE=0, which holds the GIL most of the time): worker processes from a `forkserver` (one pool per
