@@ -79,18 +79,16 @@ SIZES = [(480, 640, 416, 416), (375, 500, 320, 320), (200, 300, 608, 608), (50, 
 
 
 @pytest.mark.parametrize('interp', range(5))
-def test_resize_equals_the_numpy_and_pillow_definitions(fn, interp):
+def test_resize_equals_the_numpy_and_pillow_definitions(fn, interp, monkeypatch):
     """Codes 0 / 1: OpenCV's INTER_NEAREST / INTER_LINEAR as utils.data_utils restates them; 2 / 3 / 4: Pillow's BICUBIC /
     BOX / LANCZOS (what data_aug._resize_any calls).  Up- and down-scaling, one-axis-only, degenerate and 2x sizes."""
     from yolov3_tensorflow_amd.utils import data_aug
     rng = np.random.RandomState(interp)
     for h, w, nh, nw in SIZES:
         for img in (rng.randint(0, 256, (h, w, 3)).astype(np.uint8), _smooth(rng, h, w)):
-            os.environ['Y3_FEED_NATIVE'] = '0'
-            try:
-                want = data_aug._resize_any(img, nw, nh, interp)
-            finally:
-                os.environ.pop('Y3_FEED_NATIVE')
+            monkeypatch.setenv('Y3_FEED_NATIVE', '0')              # the definition: numpy restatements / Pillow
+            want = data_aug._resize_any(img, nw, nh, interp)
+            monkeypatch.delenv('Y3_FEED_NATIVE')
             np.testing.assert_array_equal(fn.resize(img, nw, nh, interp), want, err_msg=str((h, w, nh, nw)))
 
 
