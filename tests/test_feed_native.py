@@ -180,3 +180,42 @@ def test_sample_batch_runs_jobs_on_its_own_threads(fn):
     jobs[7].win_w = 0                    # one bad job: its error comes back, the others still ran
     assert fn.lib().y3f_sample_batch(jobs, len(imgs), None, ptrs, 3) == -1
     assert b'job 7' in fn.lib().y3f_last_error()
+
+
+def test_sample_geometry_against_a_numpy_construction(fn):
+    """y3f_sample's contract on its own (include/yolo355_feed.h): image (or mix-up blend) at an offset on an unbounded
+    black canvas, any window of that canvas - inside, overlapping or entirely off the image -, one resize, placement on a
+    padded field, mirror, /255."""
+    from yolov3_tensorflow_amd.utils import data_aug
+    rng = np.random.RandomState(8)
+    for case in range(60):
+        h1, w1 = int(rng.randint(5, 60)), int(rng.randint(5, 60))
+        img1 = rng.randint(0, 256, (h1, w1, 3)).astype(np.uint8)
+        img2, lam = None, 1.0
+        if case % 3 == 0:
+            img2 = rng.randint(0, 256, (int(rng.randint(5, 60)), int(rng.randint(5, 60)), 3)).astype(np.uint8)
+            lam = float(rng.beta(1.5, 1.5))
+        src = img1 if img2 is None else data_aug.blend(img1, img2, lam)
+        colour = None if case % 4 else data_aug.color_distort_draws(rng=np.random.RandomState(case))
+        if colour is not None:
+            src = data_aug.apply_color_distort(src, colour)
+        off = (int(rng.randint(-20, 40)), int(rng.randint(-20, 40)))
+        win = (int(rng.randint(-30, 60)), int(rng.randint(-30, 60)), int(rng.randint(1, 90)), int(rng.randint(1, 90)))
+        # the numpy construction: a canvas large enough for everything, shifted so that no index is negative
+        shift = 64
+        canvas = np.zeros((256, 256, 3), np.uint8)
+        canvas[off[1] + shift:off[1] + shift + src.shape[0], off[0] + shift:off[0] + shift + src.shape[1]] = src
+        window = canvas[win[1] + shift:win[1] + shift + win[3], win[0] + shift:win[0] + shift + win[2]]
+        interp = case % 5
+        res = (int(rng.randint(1, 50)), int(rng.randint(1, 50)))
+        out = (res[0] + int(rng.randint(0, 9)), res[1] + int(rng.randint(0, 9)))
+        pad = (int(rng.randint(0, out[0] - res[0] + 1)), int(rng.randint(0, out[1] - res[1] + 1)))
+        flip = bool(case % 2)
+        want = np.full((out[1], out[0], 3), 77, np.uint8)
+        want[pad[1]:pad[1] + res[1], pad[0]:pad[0] + res[0]] = fn.resize(window, res[0], res[1], interp)
+        if flip:
+            want = want[:, ::-1]
+        got = fn.sample(img1, img2, lam, colour, off, win, interp, res, out, pad, 77, flip)
+        np.testing.assert_array_equal(got, want, err_msg='case %d' % case)
+        as_float = fn.sample(img1, img2, lam, colour, off, win, interp, res, out, pad, 77, flip, as_float=True)
+        np.testing.assert_array_equal(as_float, want.astype(np.float32) / np.float32(255.))
