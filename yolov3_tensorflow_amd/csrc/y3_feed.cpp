@@ -22,6 +22,10 @@
 #include <thread>
 #include <vector>
 
+// The integer resize loops are compiled three times (AVX2, SSE4.1, baseline x86-64) and picked at load time by the CPU: the
+// library is built in one container and runs on another host.  Integer arithmetic only - every version gives the same bytes.
+#define Y3F_CLONES __attribute__((target_clones("avx2", "sse4.1", "default")))
+
 static_assert(sizeof(y3f_colour) == 24 && sizeof(y3f_job) == 128, "the ctypes mirrors in feed_native.py assume this layout");
 
 namespace {
@@ -79,7 +83,7 @@ struct LinearTaps {
     }
 };
 
-void resize_linear(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
+Y3F_CLONES void resize_linear(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
     if (sh == dh && sw == dw) {
         memcpy(dst, src, (size_t)sh * sw * 3);
         return;
@@ -186,7 +190,14 @@ struct Kernel1D {
     }
 };
 
-void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, double (*filter)(double), double support) {
+// `live`: the caller may know that everything outside a rectangle of the source is zero (the black canvas around an
+// expanded image): zero pixels add nothing to the integer sums, so their rows and taps are skipped - same bytes, less work.
+struct Rect {
+    int x0, y0, x1, y1;
+};
+
+Y3F_CLONES void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, double (*filter)(double), double support,
+                         Rect live) {
     const bool horizontal = dw != sw, vertical = dh != sh;
     if (!horizontal && !vertical) {
         memcpy(dst, src, (size_t)sh * sw * 3);
@@ -207,11 +218,16 @@ void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, 
         for (int y = 0; y < rows; ++y) {
             const uint8_t* in = src + (size_t)(y + row_first) * sw * 3;
             uint8_t* out = out_base + (size_t)y * dw * 3;
+            if (y + row_first < live.y0 || y + row_first >= live.y1) {
+                memset(out, 0, (size_t)dw * 3);
+                continue;
+            }
             for (int x = 0; x < dw; ++x) {
-                const int32_t* k = &kx.coef[(size_t)x * kx.ksize];
-                const uint8_t* p = in + 3 * kx.first[x];
+                const int lo = std::max(kx.first[x], live.x0), hi = std::min(kx.first[x] + kx.count[x], live.x1);
+                const int32_t* k = &kx.coef[(size_t)x * kx.ksize] + (lo - kx.first[x]);
+                const uint8_t* p = in + 3 * lo;
                 int32_t s0 = 1 << (kCoefBits - 1), s1 = s0, s2 = s0;
-                for (int t = 0, n = kx.count[x]; t < n; ++t, p += 3) {
+                for (int t = 0, n = hi - lo; t < n; ++t, p += 3) {
                     s0 += p[0] * k[t];
                     s1 += p[1] * k[t];
                     s2 += p[2] * k[t];
@@ -230,9 +246,10 @@ void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, 
     for (int y = 0; y < dh; ++y) {
         const int32_t* k = &ky.coef[(size_t)y * ky.ksize];
         std::fill(acc.begin(), acc.end(), 1 << (kCoefBits - 1));
-        for (int t = 0, n = ky.count[y]; t < n; ++t) {
-            const uint8_t* in = mid + (size_t)(ky.first[y] - row_base + t) * stride;
-            const int32_t kt = k[t];
+        const int lo = std::max(ky.first[y], live.y0), hi = std::min(ky.first[y] + ky.count[y], live.y1);
+        for (int r = lo; r < hi; ++r) {
+            const uint8_t* in = mid + (size_t)(r - row_base) * stride;
+            const int32_t kt = k[r - ky.first[y]];
             for (size_t i = 0; i < stride; ++i) acc[i] += in[i] * kt;
         }
         uint8_t* out = dst + (size_t)y * stride;
@@ -240,16 +257,17 @@ void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, 
     }
 }
 
-int resize_any(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, int interp) {
+int resize_any(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, int interp, const Rect* known = nullptr) {
     if (!src || !dst || sh < 1 || sw < 1 || dh < 1 || dw < 1)
         return fail(Y3F_EINVAL, "resize: empty image or null pointer (%dx%d -> %dx%d)", sw, sh, dw, dh);
+    const Rect live = known ? *known : Rect{0, 0, sw, sh};
     try {
         switch (interp) {
             case Y3F_INTER_NEAREST: resize_nearest(src, sh, sw, dst, dh, dw); return Y3F_OK;
             case Y3F_INTER_LINEAR: resize_linear(src, sh, sw, dst, dh, dw); return Y3F_OK;
-            case Y3F_INTER_CUBIC: resample(src, sh, sw, dst, dh, dw, filter_bicubic, 2.0); return Y3F_OK;
-            case Y3F_INTER_AREA: resample(src, sh, sw, dst, dh, dw, filter_box, 0.5); return Y3F_OK;
-            case Y3F_INTER_LANCZOS4: resample(src, sh, sw, dst, dh, dw, filter_lanczos, 3.0); return Y3F_OK;
+            case Y3F_INTER_CUBIC: resample(src, sh, sw, dst, dh, dw, filter_bicubic, 2.0, live); return Y3F_OK;
+            case Y3F_INTER_AREA: resample(src, sh, sw, dst, dh, dw, filter_box, 0.5, live); return Y3F_OK;
+            case Y3F_INTER_LANCZOS4: resample(src, sh, sw, dst, dh, dw, filter_lanczos, 3.0, live); return Y3F_OK;
             default: return fail(Y3F_EINVAL, "resize: interpolation code %d is not one of 0..4", interp);
         }
     } catch (const std::bad_alloc&) {
@@ -476,7 +494,10 @@ int run_job(const y3f_job& j, uint8_t* out_u8, float* out_f32) {
             res_store.resize((size_t)j.res_h * j.res_w * 3);
             res = res_store.data();
         }
-        const int rc = resize_any(win.data(), j.win_h, j.win_w, res, j.res_h, j.res_w, j.interp);
+        // everything of the window outside the (mixed) image is the black canvas: the resampling filters skip it
+        const Rect live = {std::max(0, x_lo - j.win_x), std::max(0, std::max(j.win_y, j.off_y) - j.win_y),
+                           std::max(0, x_hi - j.win_x), std::max(0, std::min(j.win_y + j.win_h, j.off_y + mh) - j.win_y)};
+        const int rc = resize_any(win.data(), j.win_h, j.win_w, res, j.res_h, j.res_w, j.interp, &live);
         if (rc != Y3F_OK) return rc;
         const float* unit = unit_table();
         if (plain) {
