@@ -198,3 +198,33 @@ def test_batch_workers_of_get_batch_data(tmp_path, monkeypatch):
     monkeypatch.setattr(data_utils, 'BATCH_WORKERS', 1)
     tf.data.TextLineDataset(str(tmp_path / 'none.txt')).batch(2).map(lambda x: x, num_parallel_calls=6).prefetch(3)
     assert data_utils.BATCH_WORKERS == 6
+
+
+def test_worker_processes_fill_shared_batch_buffers(tmp_path):
+    """backend='process' with the native pixel path: a worker process writes its float32 image straight into its slot of a
+    batch buffer the parent keeps in /dev/shm (page-locked for the device when there is one); only boxes and labels travel
+    through the pipe.  The slot then holds exactly what the in-process call produces."""
+    import os
+    from yolov3_tensorflow_amd import feeder
+    if not os.path.isdir('/dev/shm'):
+        import pytest
+        pytest.skip('no /dev/shm on this machine')
+    lines = _write_set(tmp_path)
+    shared = feeder._SharedBuffers()
+    entry = shared.take((3, 64, 96, 3))
+    assert entry is not None and os.path.exists(entry['path']) and entry['array'].shape == (3, 64, 96, 3)
+    pool = feeder._shared_process_pool(3)
+    jobs = [(lines[0], [96, 64], 'train', True, 501), ([lines[1], lines[2]], [96, 64], 'train', False, 502),
+            (lines[3], [96, 64], 'val', True, 503)]
+    got = [f.result(timeout=120) for f in [pool.submit(feeder._worker_sample_shared, job, entry['path'], (3, 64, 96, 3), j)
+                                           for j, job in enumerate(jobs)]]
+    for j, (job, g) in enumerate(zip(jobs, got)):
+        want = feeder._worker_sample(job, out=np.empty((64, 96, 3), np.float32))
+        assert g[0] == want[0] and g[1] is None
+        np.testing.assert_array_equal(entry['array'][j], want[1])
+        np.testing.assert_array_equal(g[2], want[2])
+        np.testing.assert_array_equal(g[3], want[3])
+    path = entry['path']
+    shared.close()
+    assert not os.path.exists(path) and shared.take((1, 2, 2, 3)) is not None       # (usable again after close)
+    shared.close()

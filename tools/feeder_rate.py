@@ -46,12 +46,27 @@ def main():
     ap.add_argument('--native', default='1,0')
     ap.add_argument('--batches', type=int, default=12)
     ap.add_argument('--batch_size', type=int, default=64)
+    ap.add_argument('--check', action='store_true', help="first compare the first batch of a process-backed feeder with a "
+                                                         "thread-backed one (same seed): they must be equal")
     args = ap.parse_args()
     import torch
     from yolov3_tensorflow_amd.feeder import Feeder
     lines = write_set(pathlib.Path(tempfile.mkdtemp()), 256)
     lines = (lines * ((args.batches + 3) * args.batch_size // len(lines) + 1))[:(args.batches + 3) * args.batch_size]
     print('host threads available: %d' % len(os.sched_getaffinity(0)), flush=True)
+    if args.check:
+        first = {}
+        for backend in ('thread', 'process'):
+            f = Feeder(lines[:32], 16, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True, num_threads=4, prefetch=2,
+                       seed=5, backend=backend)
+            it = f.epoch(0)
+            b = next(it)
+            torch.cuda.synchronize()
+            first[backend] = [b.images.cpu()] + [y.cpu() for y in b.y_true]
+            it.close()
+            f.close()
+        same = all(torch.equal(x, y) for x, y in zip(first['thread'], first['process']))
+        print('first batch: process-backed feeder %s thread-backed feeder' % ('==' if same else '!='), flush=True)
     for native in args.native.split(','):
         os.environ['Y3_FEED_NATIVE'] = native
         for backend in args.backends.split(','):

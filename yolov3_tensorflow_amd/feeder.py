@@ -11,13 +11,16 @@ rebuilt for one process per GPU with the device-resident target assignment of th
     GIL, as PIL's JPEG decoder does; a worker holds the GIL for a little under a millisecond per image (which levels one
     process off at 1,000-1,200 images/s: profiles/r03_feeder_rate.txt).  So the workers are
     THREADS by default (backend='thread') and each writes its float32 image straight into its slot of the batch's pinned
-    host buffer: no pickling, no second pass.  backend='process' keeps the round-2 arrangement for the numpy / Pillow
-    pixel path (Y3_FEED_NATIVE=0, which holds the GIL most of the time): worker processes from a `forkserver` (one pool per
-    process and worker count, shared by the training and the validation feeder) hand back 8-bit images that the
-    coordinator divides into the pinned buffer.  Why a forkserver: forking the training process itself copies every
-    PINNED host page eagerly - measured 93 s for four workers once 8 GB were pinned, against 0.4 s in a fresh process
-    (tools/feeder_diag.py) - and the feeder is what pins them.  (As with any multiprocessing start method but fork, a
-    SCRIPT that builds a process-backed Feeder needs the usual `if __name__ == '__main__':` guard.)
+    host buffer: no pickling, no second pass.  backend='process' is the arrangement that scales past one interpreter's
+    GIL: worker processes from a `forkserver` (one pool per process and worker count, shared by the training and the
+    validation feeder) write their float32 slots into batch buffers that live in /dev/shm and that the parent has
+    page-locked for the device (hipHostRegister), so only boxes and labels travel through the pipes: 3,320 images/s with
+    32 workers.  (Without /dev/shm, and for the numpy / Pillow pixel path, Y3_FEED_NATIVE=0, the workers hand back 8-bit
+    images that the coordinator divides into a pinned buffer: the round-2 arrangement.)  Why a forkserver: forking the
+    training process itself copies every PINNED host page eagerly - measured 93 s for four workers once 8 GB were pinned,
+    against 0.4 s in a fresh process (tools/feeder_diag.py) - and the feeder is what pins them.  (As with any
+    multiprocessing start method but fork, a SCRIPT that builds a process-backed Feeder needs the usual
+    `if __name__ == '__main__':` guard.)
   * a coordinator thread keeps `prefetch` batches of jobs in flight, and copies each finished batch to the device on a
     SIDE stream; a bounded queue of `prefetch` batches (reference: prefetech_buffer = 5) decouples it from the train step,
     so decode / resize / H2D of batch i+1.. overlap the step on batch i.  The pinned buffers are recycled once their copy
@@ -47,6 +50,112 @@ def _worker_sample(job, out=None):
     line, size, mode, letterbox, key = job
     return parse_sample(line, size, mode, letterbox, rng=np.random.RandomState(key % (2 ** 31)), prng=random.Random(key),
                         as_uint8=out is None, out=out)
+
+
+_ATTACHED = {}        # (in a worker process) path of a shared batch buffer -> its mapping
+
+
+def _worker_sample_shared(job, path, shape, index):
+    """One sample in a worker PROCESS, written as float32 straight into slot `index` of the batch buffer the parent keeps in
+    shared memory at `path` ([n, h, w, 3]); only the boxes and labels travel back through the pipe."""
+    arr = _ATTACHED.get(path)
+    if arr is None:
+        if len(_ATTACHED) >= 32:            # the parent recycles a handful of buffers; anything older is gone
+            _ATTACHED.clear()
+        arr = _ATTACHED[path] = np.memmap(path, dtype=np.float32, mode='r+', shape=tuple(shape))
+    idx, _, boxes, labels = _worker_sample(job, out=arr[index])
+    return idx, None, boxes, labels
+
+
+class _SharedBuffers(object):
+    """Batch buffers for worker processes: files in /dev/shm mapped here and in the workers, page-locked for the device
+    (hipHostRegister) so that the upload reads them like any pinned buffer; recycled like _PinnedBuffers.  Where shared memory
+    or the registration is not available, `take` returns None and the feeder falls back to pickled 8-bit images."""
+
+    _live = []              # instances with files in /dev/shm: closed at interpreter exit at the latest
+
+    def __init__(self):
+        self.busy = []          # (event, entry)
+        self.entries = []       # every live entry: dict(path, map, array, tensor, registered)
+        self.broken = False
+        if not _SharedBuffers._live:
+            import atexit
+            atexit.register(_SharedBuffers._close_all)
+        _SharedBuffers._live.append(self)
+
+    @staticmethod
+    def _close_all():
+        for inst in list(_SharedBuffers._live):
+            inst.close()
+
+    def _create(self, shape):
+        import mmap
+        import os
+        import tempfile
+        import torch
+        nbytes = int(np.prod(shape)) * 4
+        fd, path = tempfile.mkstemp(prefix='y3feed_%d_' % os.getpid(), dir='/dev/shm')
+        try:
+            os.ftruncate(fd, nbytes)
+            mapping = mmap.mmap(fd, nbytes)
+        finally:
+            os.close(fd)
+        array = np.frombuffer(mapping, np.float32).reshape(shape)
+        tensor = torch.from_numpy(array)
+        registered = False
+        try:
+            registered = int(torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0)) == 0
+        except Exception:       # noqa: BLE001 - no such entry point / no device: the buffer still works, unpinned
+            registered = False
+        entry = dict(path=path, map=mapping, array=array, tensor=tensor, registered=registered)
+        self.entries.append(entry)
+        return entry
+
+    def take(self, shape):
+        if self.broken:
+            return None
+        shape = tuple(int(v) for v in shape)
+        free = [i for i, (ev, _) in enumerate(self.busy) if ev.query()]
+        for i in free:
+            if tuple(self.busy[i][1]['array'].shape) == shape:
+                return self.busy.pop(i)[1]
+        for i in reversed(free[:-4]):
+            self._release(self.busy.pop(i)[1])
+        try:
+            return self._create(shape)
+        except (OSError, ValueError):
+            self.broken = True
+            return None
+
+    def give(self, event, entry):
+        self.busy.append((event, entry))
+
+    def _release(self, entry):
+        import os
+        import torch
+        if entry in self.entries:
+            self.entries.remove(entry)
+        try:
+            if entry['registered']:
+                torch.cuda.cudart().cudaHostUnregister(entry['tensor'].data_ptr())
+        except Exception:       # noqa: BLE001
+            pass
+        entry['tensor'] = entry['array'] = None
+        try:
+            entry['map'].close()
+        except (BufferError, ValueError):       # a view is still alive somewhere: the mapping goes with it
+            pass
+        try:
+            os.unlink(entry['path'])
+        except OSError:
+            pass
+
+    def close(self):
+        self.busy = []
+        for entry in list(self.entries):
+            self._release(entry)
+        if self in _SharedBuffers._live:
+            _SharedBuffers._live.remove(self)
 
 
 class _PinnedBuffers(object):
@@ -191,8 +300,9 @@ class Feeder(object):
 
         pool = self._executor()
 
-        buffers = _PinnedBuffers()
         in_place = self.backend == 'thread'
+        buffers = _PinnedBuffers()
+        shared = None if in_place else _SharedBuffers()
 
         def produce():
             try:
@@ -207,19 +317,29 @@ class Feeder(object):
                         except StopIteration:
                             exhausted = True
                             break
-                        pinned = buffers.take((len(lines), size[1], size[0], 3))
-                        slots = pinned.numpy()
+                        shape = (len(lines), size[1], size[0], 3)
                         jobs = [self._job(epoch, b, j, line, size) for j, line in enumerate(lines)]
-                        if in_place:
-                            futs = [pool.submit(_worker_sample, job, slots[j]) for j, job in enumerate(jobs)]
+                        entry = shared.take(shape) if shared is not None else None
+                        if entry is not None:       # worker processes fill the shared, page-locked batch buffer
+                            pinned, owner = entry['tensor'], (shared, entry)
+                            futs = [pool.submit(_worker_sample_shared, job, entry['path'], shape, j)
+                                    for j, job in enumerate(jobs)]
                         else:
-                            futs = [pool.submit(_worker_sample, job) for job in jobs]
-                        pending.append((b, size, futs, pinned))
+                            pinned = buffers.take(shape)
+                            owner = (buffers, pinned)
+                            slots = pinned.numpy()
+                            if in_place:            # worker threads fill the pinned batch buffer
+                                futs = [pool.submit(_worker_sample, job, slots[j]) for j, job in enumerate(jobs)]
+                            else:                   # worker processes hand back 8-bit images
+                                futs = [pool.submit(_worker_sample, job) for job in jobs]
+                        pending.append((b, size, futs, pinned, owner))
                     if not pending:
                         break
-                    b, size, futs, pinned = pending.pop(0)
+                    b, size, futs, pinned, owner = pending.pop(0)
+                    slots = pinned.numpy()
                     samples = [f.result() for f in futs]
-                    ids, _, boxes, labels, counts = collate(samples, out_images=pinned.numpy())
+                    samples = [(s[0], slots[j] if s[1] is None else s[1], s[2], s[3]) for j, s in enumerate(samples)]
+                    ids, _, boxes, labels, counts = collate(samples, out_images=slots)
                     with torch.cuda.stream(copy_stream):
                         images = pinned.to(dev, non_blocking=True)
                         bx = torch.from_numpy(boxes).pin_memory().to(dev, non_blocking=True)
@@ -227,7 +347,7 @@ class Feeder(object):
                         ct = torch.from_numpy(counts.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(copy_stream)
-                    buffers.give(ev, pinned)
+                    owner[0].give(ev, owner[1])
                     item = (ids, size, images, bx, lb, ct, ev)
                     while not stop.is_set():
                         try:
@@ -261,6 +381,9 @@ class Feeder(object):
         finally:
             stop.set()
             th.join(timeout=5.0)
+            if shared is not None and not th.is_alive():
+                copy_stream.synchronize()
+                shared.close()
 
     def __iter__(self):
         return self.epoch(0)
