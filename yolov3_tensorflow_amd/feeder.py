@@ -15,8 +15,9 @@ rebuilt for one process per GPU with the device-resident target assignment of th
     GIL: worker processes from a `forkserver` (one pool per process and worker count, shared by the training and the
     validation feeder) write their float32 slots into batch buffers that live in /dev/shm and that the parent has
     page-locked for the device (hipHostRegister), so only boxes and labels travel through the pipes: 3,320 images/s with
-    32 workers.  (Without /dev/shm, and for the numpy / Pillow pixel path, Y3_FEED_NATIVE=0, the workers hand back 8-bit
-    images that the coordinator divides into a pinned buffer: the round-2 arrangement.)  Why a forkserver: forking the
+    32 workers; it is also the default for the numpy / Pillow pixel path (Y3_FEED_NATIVE=0), which holds the GIL most of the
+    time.  (Without /dev/shm the workers hand back 8-bit images that the coordinator divides into a pinned buffer: the
+    round-2 arrangement.)  Why a forkserver: forking the
     training process itself copies every PINNED host page eagerly - measured 93 s for four workers once 8 GB were pinned,
     against 0.4 s in a fresh process (tools/feeder_diag.py) - and the feeder is what pins them.  (As with any
     multiprocessing start method but fork, a SCRIPT that builds a process-backed Feeder needs the usual
