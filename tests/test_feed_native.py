@@ -43,6 +43,8 @@ def test_library_exports_what_the_header_declares(fn):
     assert b'interpolation' in fn.lib().y3f_last_error()
     with pytest.raises(RuntimeError, match='does not fit'):
         fn.sample(out, resized=(8, 8), out_size=(4, 4))
+    with pytest.raises(RuntimeError, match='out of range'):
+        fn.sample(out, window=(2 ** 30, 0, 4, 4), out_size=(4, 4))
 
 
 def test_hsv_conversions_equal_pillows_on_every_colour(fn):

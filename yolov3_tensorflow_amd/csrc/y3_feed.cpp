@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -223,11 +224,11 @@ Y3F_CLONES void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int d
                 continue;
             }
             for (int x = 0; x < dw; ++x) {
-                const int lo = std::max(kx.first[x], live.x0), hi = std::min(kx.first[x] + kx.count[x], live.x1);
-                const int32_t* k = &kx.coef[(size_t)x * kx.ksize] + (lo - kx.first[x]);
+                const int lo = std::max(kx.first[x], live.x0), hi = std::max(lo, std::min(kx.first[x] + kx.count[x], live.x1));
+                const int32_t* k = &kx.coef[(size_t)x * kx.ksize];
                 const uint8_t* p = in + 3 * lo;
                 int32_t s0 = 1 << (kCoefBits - 1), s1 = s0, s2 = s0;
-                for (int t = 0, n = hi - lo; t < n; ++t, p += 3) {
+                for (int t = lo - kx.first[x], n = hi - kx.first[x]; t < n; ++t, p += 3) {
                     s0 += p[0] * k[t];
                     s1 += p[1] * k[t];
                     s2 += p[2] * k[t];
@@ -260,7 +261,10 @@ Y3F_CLONES void resample(const uint8_t* src, int sh, int sw, uint8_t* dst, int d
 int resize_any(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, int interp, const Rect* known = nullptr) {
     if (!src || !dst || sh < 1 || sw < 1 || dh < 1 || dw < 1)
         return fail(Y3F_EINVAL, "resize: empty image or null pointer (%dx%d -> %dx%d)", sw, sh, dw, dh);
-    const Rect live = known ? *known : Rect{0, 0, sw, sh};
+    Rect live = known ? *known : Rect{0, 0, sw, sh};
+    live = {std::min(std::max(live.x0, 0), sw), std::min(std::max(live.y0, 0), sh), std::min(std::max(live.x1, 0), sw),
+            std::min(std::max(live.y1, 0), sh)};
+    if (live.x1 <= live.x0 || live.y1 <= live.y0) live = {0, 0, 0, 0};          // nothing but black
     try {
         switch (interp) {
             case Y3F_INTER_NEAREST: resize_nearest(src, sh, sw, dst, dh, dw); return Y3F_OK;
@@ -456,6 +460,10 @@ int run_job(const y3f_job& j, uint8_t* out_u8, float* out_f32) {
     if (j.pad_x < 0 || j.pad_y < 0 || j.pad_x + j.res_w > j.out_w || j.pad_y + j.res_h > j.out_h)
         return fail(Y3F_EINVAL, "sample: %dx%d at (%d,%d) does not fit the %dx%d output", j.res_w, j.res_h, j.pad_x, j.pad_y,
                     j.out_w, j.out_h);
+    const int32_t far = 1 << 28, big = 1 << 20;          // (keeps every sum of two coordinates inside int32)
+    if (j.win_w > big || j.win_h > big || j.out_w > big || j.out_h > big || j.h1 > big || j.w1 > big || j.h2 > big || j.w2 > big ||
+        std::abs(j.win_x) > far || std::abs(j.win_y) > far || std::abs(j.off_x) > far || std::abs(j.off_y) > far)
+        return fail(Y3F_EINVAL, "sample: coordinates out of range");
     if (!out_u8 && !out_f32) return Y3F_OK;
     try {
         // 1. the window of the canvas: black, except where the (mixed) image lies; those pixels are blended and jittered
