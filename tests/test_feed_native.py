@@ -221,3 +221,30 @@ def test_sample_geometry_against_a_numpy_construction(fn):
         np.testing.assert_array_equal(got, want, err_msg='case %d' % case)
         as_float = fn.sample(img1, img2, lam, colour, off, win, interp, res, out, pad, 77, flip, as_float=True)
         np.testing.assert_array_equal(as_float, want.astype(np.float32) / np.float32(255.))
+
+
+def test_a_c_host_links_the_library_and_gets_the_same_bytes(fn, tmp_path):
+    """examples/feed_sample.c: a plain C program against include/yolo355_feed.h (no Python in the process) runs one job;
+    the Python binding, given the same job, produces the same image."""
+    import shutil
+    import subprocess
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        pytest.skip('no C compiler on this machine')
+    csrc = os.path.join(ROOT, 'yolov3_tensorflow_amd', 'csrc')
+    exe = str(tmp_path / 'feed_sample')
+    subprocess.check_call([cc, '-O2', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'feed_sample.c'),
+                           '-o', exe, '-L', csrc, '-ly3feed', '-Wl,-rpath,' + csrc])
+    rng = np.random.RandomState(5)
+    img = _smooth(rng, 150, 210)
+    src, dst = str(tmp_path / 'in.ppm'), str(tmp_path / 'out.ppm')
+    with open(src, 'wb') as f:
+        f.write(b'P6\n210 150\n255\n' + img.tobytes())
+    text = subprocess.check_output([exe, src, dst]).decode()
+    raw = open(dst, 'rb').read()
+    assert raw.startswith(b'P6\n416 416\n255\n')
+    got = np.frombuffer(raw[len(b'P6\n416 416\n255\n'):], np.uint8).reshape(416, 416, 3)
+    want = fn.sample(img, colour=(9, -7, 1.25, 0.9), offset=(105, 75), window=(52, 37, 210, 150), interp=4,
+                     out_size=(416, 416), flip_x=True)
+    np.testing.assert_array_equal(got, want)
+    assert text.startswith('abi 1;') and ('%.6f' % (want[415, 0, 0] / np.float32(255.))) in text
