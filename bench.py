@@ -25,9 +25,10 @@ Prints ONE JSON line on rank 0.
 
 roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the two
 Winograd kernels of the stride-1 3x3 convs (32 launches, ~60 % of the step): conv_wino44_f32_kernel (F(4x4,3x3): the
-128->256 and 512->1024 convs when the launch fills the chip) and conv_wino8_f32_kernel (F(2x2,3x3): the others).
-`achieved` = the MFMA work those launches ISSUE - per layer 16/36 (F(2x2)) or 36/144 x tile padding (F(4x4)) of the
-direct-convolution FLOPs, by the kernel the library picks (winograd_issue_factors) - / the sum of their durations,
+convs with Cin >= 64 when the launch fills the chip) and conv_wino8_f32_kernel (F(2x2,3x3): the others).
+`achieved` = the useful MFMA work of those launches - per layer 16/36 (F(2x2)) or 36/144 (F(4x4); the zero tiles that pad
+a 13- / 26-grid to a multiple of 4 are issued but NOT counted) of the direct-convolution FLOPs, by the kernel the library
+picks (winograd_issue_factors) - / the sum of their durations,
 measured with hipEvents recorded on the launch stream inside the timed region; `peak` = 157.3 TFLOP/s (fp32 MFMA);
 `frac` = achieved / peak.  `achieved_algorithmic` counts the direct-convolution FLOPs (it may exceed `peak`: Winograd
 needs 2.25x / 4x fewer multiplies).  `whole_forward_frac` = sum over the 75 layers of max(bytes / 8 TB/s, issued FLOPs /
@@ -193,7 +194,8 @@ def cpu_baseline(model_vars, budget_s=12.0):
     for _ in range(reps):
         yolo_ref.forward(params, x)
     dt = time.time() - t0
-    return {"value": round(2 * reps / dt, 3), "unit": "images/s", "cores": int(threads), "kind": "port",
+    return {"value": round(2 * reps / dt, 3), "unit": "images/s", "cores": int(threads), "cores_note": "%d of the host's %d cores (the oracle's best operating point: oneDNN does not "
+            "scale on this graph, bs=32 on 64 threads runs at 3.2 images/s)" % (threads, ncpu), "kind": "port",
             "sample": "oracle.yolo_ref.forward (torch-CPU fp32 restatement of the reference graph; TF-CPU itself is "
                       "not installable here), %dx%d, same weights; %d batches of 2 images on %d threads of the %d-core "
                       "host (%.1f s)" % (SIZE, SIZE, reps, threads, ncpu, dt)}
@@ -617,8 +619,9 @@ def layer_input_grids(table, size):
 def winograd_issue_factors(table, precision, size):
     """Per layer: (is_winograd, MFMA work ISSUED / direct-convolution FLOPs) for the kernel the library runs in `precision`.
     F(2x2,3x3) layers issue 16/36 of the direct count; the layers y3_conv_wino44_preferred names run F(4x4,3x3) in the
-    inference forward: 36/144, times the padding of their 4x4 tiles on this grid (a 13-grid is covered by 4x4 tiles of 4x4:
-    256/169).  The factor follows the library's own choice, so `achieved` never counts work a kernel did not issue."""
+    inference forward: 36/144.  The 4x4 tiles that pad a 13-grid (to 16: x1.51) or a 26-grid (to 28: x1.16) ARE issued by
+    the kernel and are NOT counted (multiplying zeros is not achieved work), so `frac` is the useful fraction.
+    The factor follows the library's own choice of kernel per layer."""
     from yolov3_tensorflow_amd import engine
     is_w, fac = [], []
     grid_of = layer_input_grids(table, size)
@@ -628,8 +631,7 @@ def winograd_issue_factors(table, precision, size):
         f = 1.0
         if w:
             if engine.wino44_preferred(BATCH, g_in, g_in, k, s, cin, cout):
-                t = -(-g_in // 4) * 4
-                f = (36.0 / 144.0) * (t * t) / float(g_in * g_in)
+                f = 36.0 / 144.0          # USEFUL work only: the zero tiles a 13- or 26-grid is padded with are not counted
             else:
                 f = 16.0 / 36.0
         is_w.append(w)
@@ -872,9 +874,10 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else
               "the Winograd kernels of the stride-1 3x3 convs: conv_wino8_f32_kernel (F(2x2,3x3), %d launches) and "
-              "conv_wino44_f32_kernel (F(4x4,3x3), %d launches: the 128->256 and 512->1024 convs); `achieved` = MFMA work "
-              "ISSUED per second (16/36 resp. 36/144 x tile padding of the direct-convolution FLOPs, per layer by the kernel the "
-              "library picked); `achieved_algorithmic` counts the direct-convolution FLOPs" % (int(is_wino.sum()) - n_f44, n_f44)
+              "conv_wino44_f32_kernel (F(4x4,3x3), %d launches: the convs with Cin >= 64); `achieved` = useful MFMA work "
+              "per second (16/36 resp. 36/144 of the direct-convolution FLOPs, per layer by the kernel the library picked; "
+              "zero tiles padding a 13-/26-grid to a multiple of 4 are issued but not counted); `achieved_algorithmic` "
+              "counts the direct-convolution FLOPs" % (int(is_wino.sum()) - n_f44, n_f44)
               if wino else
               "conv_mfma_f32_kernel<128,128,2,2,3,false,true,false> (3x3 implicit-GEMM conv, stream-K schedule)")
     out = {

@@ -60,9 +60,11 @@ int y3_ctx_destroy(y3_ctx* ctx);
  * dispatched in increasing blockIdx order.  A consumer only ever waits for workgroups with SMALLER ids of its own
  * XCD group, so under that order it cannot wait for a workgroup that has not been dispatched; if a future dispatcher
  * broke the order, the bounded poll would expire and the failure would surface here, never as a silent wrong tensor.
- * Test hook: with Y3_STREAMK_FAULT=1 in the environment producers never raise their flag and consumers give up after
- * 2^10 polls (tests/test_conv_gpu.py::test_streamk_timeout_is_loud). */
+ * Test hook: after y3_debug_streamk_fault(1) producers never raise their flag and consumers give up after 2^10 polls,
+ * until y3_debug_streamk_fault(0) (process-wide; tests/test_conv_gpu.py::test_streamk_timeout_is_loud).  It is an
+ * explicit call on purpose: no environment variable changes what the product library does. */
 int y3_ctx_check(y3_ctx* ctx);
+void y3_debug_streamk_fault(int on);
 
 /* ---- parameter preparation (one-off, utils/misc_utils.py:114-124 produces HWIO) ---------------
  * w_hwio [k][k][cin][cout]  ->  w_packed [k*k][cout][cin]   (cin contiguous: 16-B loads along K).

@@ -308,9 +308,9 @@ def test_winograd_eligibility_and_errors():
                                torch.zeros(64, device=dev), 64, True)
 
 
-def test_streamk_timeout_is_loud(monkeypatch):
+def test_streamk_timeout_is_loud():
     """A stream-K hand-off that times out must never return a wrong tensor with rc 0 (include/yolo355.h, y3_ctx_check).
-    Y3_STREAMK_FAULT=1 makes the producers skip raising their flag and shortens the consumers' poll: the launch ends,
+    y3_debug_streamk_fault(1) makes the producers skip raising their flag and shortens the consumers' poll: the launch ends,
     the kernel ORs a code into the context's error word, the next call on the context refuses to launch (Y3_EHIP ->
     Y3Error), y3_ctx_check reports and clears it, and the context then works again, bit-exactly."""
     from yolov3_tensorflow_amd import engine, framework as fw, _lib
@@ -333,19 +333,19 @@ def test_streamk_timeout_is_loud(monkeypatch):
         for name, run in runs.items():
             good = run()
             fw.check_context()
-            monkeypatch.setenv('Y3_STREAMK_FAULT', '1')
+            _lib.lib().y3_debug_streamk_fault(1)
             run()                                      # launches; its result is garbage and says so:
             torch.cuda.synchronize()                   # (the kernel has to have run for the word to be set)
             with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
                 run()                                  # ... the next call on the context refuses to launch
             with pytest.raises(_lib.Y3Error, match='stream-K hand-off timed out'):
                 fw.check_context()                     # ... and the explicit check reports it (and clears it)
-            monkeypatch.delenv('Y3_STREAMK_FAULT')
+            _lib.lib().y3_debug_streamk_fault(0)
             fw.check_context()
             assert torch.equal(run(), good), name
             fw.check_context()
     finally:
-        monkeypatch.delenv('Y3_STREAMK_FAULT', raising=False)
+        _lib.lib().y3_debug_streamk_fault(0)
         try:
             fw.check_context()                         # never leave the session's context poisoned for later tests
         except _lib.Y3Error:

@@ -25,17 +25,18 @@ def timed(fn, iters=20):
 def main():
     from yolov3_tensorflow_amd import engine
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    print('shape (bs=%d)            F(2x2) us   F(4x4) us   ratio   F(4x4) TF/s issued (of 157.3)' % n)
+    print('shape (bs=%d)            F(2x2) us   F(4x4) us   ratio   F(4x4) TF/s issued (of 157.3)   F(4x4) persistent us' % n)
     for g, cin, cout in ((208, 32, 64), (104, 64, 128), (52, 128, 256), (26, 256, 512), (13, 512, 1024)):
         x = torch.rand((n, g, g, cin), device='cuda')
         w = torch.randn((3, 3, cin, cout), device='cuda') * 0.05
         sc, sh = torch.ones(cout, device='cuda'), torch.zeros(cout, device='cuda')
         w2, w4 = engine.pack_wino(w), engine.pack_wino44(w)
         t2 = timed(lambda: engine.conv2d_fwd_wino(x, w2, sc, sh, cout, True))
-        t4 = timed(lambda: engine.conv2d_fwd_wino44(x, w4, sc, sh, cout, True))
+        t4 = timed(lambda: engine.conv2d_fwd_wino44(x, w4, sc, sh, cout, True, use_workspace=False))
+        t4p = timed(lambda: engine.conv2d_fwd_wino44(x, w4, sc, sh, cout, True))
         tiles = n * ((g + 3) // 4) ** 2
         issued = tiles * 36 * cin * cout * 2 / (t4 * 1e-6) / 1e12
-        print('%3dx%-3d %4d->%-4d       %8.1f    %8.1f    %.2f    %.1f' % (g, g, cin, cout, t2, t4, t2 / t4, issued), flush=True)
+        print('%3dx%-3d %4d->%-4d       %8.1f    %8.1f    %.2f    %.1f    %8.1f' % (g, g, cin, cout, t2, t4, t2 / t4, issued, t4p), flush=True)
 
 
 if __name__ == '__main__':

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "y3_ctx_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
     "y3_ctx_destroy": (c_int, [c_void_p]),
     "y3_ctx_check": (c_int, [c_void_p]),
+    "y3_debug_streamk_fault": (None, [c_int]),
     "y3_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "y3_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "y3_conv_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),

@@ -89,6 +89,39 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# The sources with experiment switches (y3_exp_env, csrc/y3_internal.h): compiled a second time with -DY3_EXPERIMENTS
+# into libyolo355_exp.so, the library tools/ A/B runs and tests/test_conv_variants_gpu.py select with Y3_LIB_PATH.
+# The product library reads no environment variable.
+EXP_LIB = os.path.join(CSRC, "libyolo355_exp.so")
+EXP_SOURCES = ("y3_conv.hip", "y3_conv_bf16x.hip", "y3_conv_split.hip", "y3_conv_wino.hip", "y3_conv_wino44.hip",
+               "y3_wgrad.hip")
+
+
+def build_experiments(verbose=True):
+    """libyolo355_exp.so = the product objects, with EXP_SOURCES recompiled under -DY3_EXPERIMENTS."""
+    build(verbose=verbose)
+    deps = [os.path.join(CSRC, s) for s in EXP_SOURCES] + [LIB]
+    if os.path.exists(EXP_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(EXP_LIB) for d in deps):
+        return EXP_LIB
+    hipcc = _hipcc()
+    procs, objs = [], []
+    for src, extra in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if src in EXP_SOURCES:
+            obj = os.path.join(CSRC, src.replace(".hip", ".exp.o"))
+            cmd = [hipcc] + COMMON + extra + ["-DY3_EXPERIMENTS", "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", EXP_LIB] + objs)
+    return EXP_LIB
+
+
 def build(force=False, verbose=True):
     build_feed(force=force, verbose=verbose)
     if not force and not needs_build():
@@ -122,3 +155,5 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    if "--experiments" in sys.argv:
+        print(build_experiments())

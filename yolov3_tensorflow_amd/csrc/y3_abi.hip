@@ -72,9 +72,12 @@ int y3_ctx_stage_release(y3_ctx* ctx) {
     return Y3_OK;
 }
 
+// Fault injection for the loud-time-out test (include/yolo355.h, y3_debug_streamk_fault): an explicit call, not an
+// environment variable - nothing outside the process can switch it on.
+static int g_sk_fault = 0;
+extern "C" void y3_debug_streamk_fault(int on) { __atomic_store_n(&g_sk_fault, on ? 1 : 0, __ATOMIC_RELAXED); }
 void y3_sk_debug_env(unsigned* spin_limit, int* fault) {
-    const char* e = getenv("Y3_STREAMK_FAULT");      // read per launch: tests toggle it inside one process
-    *fault = (e && e[0] == '1') ? 1 : 0;
+    *fault = __atomic_load_n(&g_sk_fault, __ATOMIC_RELAXED);
     *spin_limit = *fault ? (1u << 10) : (1u << 22);
 }
 

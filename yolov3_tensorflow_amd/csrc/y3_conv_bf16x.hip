@@ -607,7 +607,7 @@ int launch_p(hipStream_t stream, const ConvArgsX& a) {
 int forced_tile() {
     static int v = -2;
     if (v == -2) {
-        const char* e = getenv("Y3_BF16X_TILE");
+        const char* e = y3_exp_env("Y3_BF16X_TILE");
         v = e ? (e[0] == 'A' ? 0 : e[0] == 'B' ? 1 : e[0] == 'C' ? 2 : -1) : -1;
     }
     return v;
@@ -633,7 +633,7 @@ int dispatch_x(hipStream_t stream, const ConvArgsX& a) {
     }
     static int pipe = -1;           // Y3_BF16X_PIPE=0: the two-stage kernel on the 256-row tiles too (A/B runs)
     if (pipe < 0) {
-        const char* e = getenv("Y3_BF16X_PIPE");
+        const char* e = y3_exp_env("Y3_BF16X_PIPE");
         pipe = (e && e[0] == '0') ? 0 : 1;
     }
     if (t == 0 && a.Cout >= 256)
@@ -653,7 +653,7 @@ int y3_conv_bf16x_takes(int k, int cin) {
     if (k != 3 || (cin != 32 && cin % 64 != 0)) return 0;
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("Y3_BF16X");
+        const char* e = y3_exp_env("Y3_BF16X");
         off = (e && e[0] == '0') ? 1 : 0;
     }
     return off ? 0 : 1;

@@ -454,7 +454,7 @@ inline bool use_streamk(const ConvArgs& a, int k, bool has_ws) {
     if (!has_ws || k != 3 || a.Cout < 128 || a.xu) return false;
     static int force = -2;
     if (force == -2) {
-        const char* e = getenv("Y3_CONV_STREAMK");
+        const char* e = y3_exp_env("Y3_CONV_STREAMK");
         force = e ? atoi(e) : -1;
     }
     if (force == 0) return false;

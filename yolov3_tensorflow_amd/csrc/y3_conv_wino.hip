@@ -725,7 +725,7 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
         // tails) - so the default stays the plain split.
         static int hyb = -1;
         if (hyb < 0) {
-            const char* e = getenv("Y3_WINO_SK_HYBRID");
+            const char* e = y3_exp_env("Y3_WINO_SK_HYBRID");
             hyb = e ? (atoi(e) != 0) : 0;
         }
         a.hybrid = hyb;
@@ -739,7 +739,7 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     {
         static int force = -2;
         if (force == -2) {
-            const char* e = getenv("Y3_WINO_ORDER");
+            const char* e = y3_exp_env("Y3_WINO_ORDER");
             force = e ? atoi(e) : -1;
         }
         a.bn_inner = force >= 0 ? (force != 0) : ((size_t)16 * d->cin * d->cout * sizeof(float) <= (size_t)(1u << 20));
@@ -766,7 +766,7 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     // would run partly empty); Y3_CONV_WINO_STREAMK=0/1 overrides (experiment hook)
     static int force = -2;
     if (force == -2) {
-        const char* e = getenv("Y3_CONV_WINO_STREAMK");
+        const char* e = y3_exp_env("Y3_CONV_WINO_STREAMK");
         force = e ? atoi(e) : -1;
     }
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino_workspace_bytes_impl(d) &&

@@ -56,13 +56,20 @@ struct W44Args {
     int fault;           // test hook: producers skip raising their flag
 };
 
-constexpr int BT = 32, BNC = 64, NTH = 512;
+#ifndef W44_BT
+#define W44_BT 16
+#endif
+constexpr int BT = W44_BT, BNC = 64, NTH = BT * 16;       // one wave per 16 tiles x 16 channels
+constexpr int NW = NTH / 64;
 constexpr int KC = 8;                          // input channels per K-step
 constexpr int ROWB = KC * 4;                   // LDS bytes per (position, tile) row
 constexpr int PLANE = BT * ROWB;               // one position's tiles
 constexpr int STAGE = 36 * PLANE;              // 36,864 B
 constexpr unsigned OOB = 0x80000000u;
-constexpr int BDEPTH = 6;                      // weight fragment loads in flight per wave: one load = one lane's 16 bytes for a PAIR of
+#ifndef W44_BDEPTH
+#define W44_BDEPTH 6
+#endif
+constexpr int BDEPTH = W44_BDEPTH;                      // weight fragment loads in flight per wave: one load = one lane's 16 bytes for a PAIR of
                                                // positions (divides 18: the window runs on across K-steps)
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -132,7 +139,16 @@ __device__ __forceinline__ void transform_job(const unsigned char* rs, unsigned 
     }
 }
 
-__global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p) {
+#ifdef W44_PROBE
+// Clock probe build (tools/wino44_probe.py; never in the product library): wave 0 of every workgroup stamps s_memtime at
+// its phase boundaries into g_w44_probe[block][16].
+__device__ unsigned long long* g_w44_probe = nullptr;
+#define W44_STAMP(i) do { if (g_w44_probe && tid == 0) g_w44_probe[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W44_STAMP(i) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(const W44Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // V: [2][36][BT][32 B], then raw patches: the same shape
     constexpr int RAW_OFF = 2 * STAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,7 +174,11 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
     long long lo = 0, hi = 0;
     int rem0 = 0;
     if (W > 0) {
+#ifdef W44_SK_KEEP
+        const int R = nblocks / W > W44_SK_KEEP ? nblocks / W - W44_SK_KEEP : 0;     // (probe) cut the last W44_SK_KEEP whole rounds too
+#else
         const int R = nblocks / W;
+#endif
         whole_left = R;
         rem0 = R * W;
         const long long items = (long long)(nblocks - rem0) * ksteps;
@@ -168,16 +188,28 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
     }
 
     // ---- per-thread constants ---------------------------------------------------------------------------------------
-    const int unit = tid & 127, job = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int st_off = (unit >> 2) * ROWB + (unit & 3) * 8;          // staging job: (tile, channel pair) inside a plane
+    const int unit = tid & (BT * 4 - 1), job = __builtin_amdgcn_readfirstlane(tid / (BT * 4));
+    const int st_off = (unit >> 2) * ROWB + (unit & 3) * 8;          // staging job: (tile, channel pair) inside a RAW plane ([tile][8 channels])
     const int row16 = lane & 15, quart = lane >> 4;
-    const int a_off = (wm * 16 + row16) * ROWB + quart * 8;          // activation fragment inside a position plane
+    // V planes are [channel pair][32 tiles][2 channels] with the tile index rotated by 4 per channel pair (v_off): the
+    // fragment reads come out of hipcc as ds_read2st64_b64, which the LDS serves in groups of 16 lanes over 32 banks -
+    // 16 tiles x 8 B of ONE channel pair must be 128 contiguous bytes (as [tile][8 channels] rows they hit every bank
+    // four times: 3.5k conflict cycles per K-step, profiles/r03_pmc_layers.txt) - and the rotation keeps the staging
+    // writes of a 16-lane group (4 tiles x 4 channel pairs) on 32 different banks as well.
+#ifdef W44_OLD_LAYOUT
+    auto v_off = [](int tile, int cp) { return tile * ROWB + cp * 8; };
+#else
+    auto v_off = [](int tile, int cp) { return cp * (BT * 8) + ((tile * 8 + cp * 32) & (BT * 8 - 1)); };
+#endif
+    const int sv_off = v_off(unit >> 2, unit & 3);
+    const int a_off = v_off(wm * 16 + row16, quart);                 // activation fragment inside a position plane
     const unsigned b_pos_stride = (unsigned)((size_t)ksteps * p.Cout * 2 * KC * 4);         // bytes between position pairs
     const unsigned b_ks_stride = (unsigned)(p.Cout * 2 * KC * 4);
     constexpr int RS = BNC + 4;                                      // staged output row stride in floats
     float* cs = reinterpret_cast<float*>(smem) + wm * (16 * 16 * RS);
-    int* tinfo = reinterpret_cast<int*>(smem + 2 * 16 * 16 * RS * 4);     // [BT][2]: pixel index of the tile's corner, valid rows | cols << 8
+    int* tinfo = reinterpret_cast<int*>(smem + (BT / 16) * 16 * 16 * RS * 4);     // [BT][2]: pixel index of the tile's corner, valid rows | cols << 8
 
+    W44_STAMP(0);
     while (whole_left > 0 || lo < hi) {
         // ---- this segment: block, K-range, role ------------------------------------------------------------------------
         int blk, ks0, ks1;
@@ -205,18 +237,25 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
         const int bt = blk / nbn, bn = blk - bt * nbn;     // the Cout/64 blocks of one tile block are neighbours
         const int t0 = bt * BT, n0 = bn * BNC;
 
-        // raw patches, global -> LDS by DMA: plane i = patch pixel (k, l) = (i / 6, i % 6) holds [32 tiles][8 channels];
-        // wave w moves planes w, w + 8, ...: lane = (tile, 16-byte half) -> 1 KB contiguous in the LDS per instruction
-        unsigned dvoff[5];
+        // raw patches, global -> LDS by DMA: plane i = patch pixel (k, l) = (i / 6, i % 6) holds [BT tiles][8 channels];
+        // one instruction moves 1 KB = PPI planes, wave w issues instructions w, w + NW, ...: lane = (plane, tile, 16-byte half)
+        constexpr int PPI = 1024 / PLANE, NDMA = 36 / PPI;
+#ifdef W44_DMA_HALF
+        constexpr int DW = NW / 2;        // only the first half of the waves issues DMAs (the half that transforms first)
+#else
+        constexpr int DW = NW;
+#endif
+        constexpr int DPW = (NDMA + DW - 1) / DW;
+        unsigned dvoff[DPW];
         {
-            const int t = t0 + (lane >> 1);
+            const int t = t0 + ((lane >> 1) & (BT - 1));
             const bool tok = t < p.T;
             const int n = t / (p.TH * p.TW);
             const int r = t - n * p.TH * p.TW;
             const int ty = r / p.TW, tx = r - ty * p.TW;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int i = wave + 8 * j;
+            for (int j = 0; j < DPW; ++j) {
+                const int i = (wave + DW * j) * PPI + lane / (2 * BT);
                 const int k = i / 6, l = i - 6 * k;
                 const int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + l;
                 const bool ok = tok && i < 36 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
@@ -226,12 +265,12 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
         auto dma_raw = [&](int ks, int buf) {
             const unsigned so = (unsigned)(ks * KC) * 4u;
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
-                if (wave + 8 * j < 36) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + 8 * j) * PLANE, dvoff[j], so);
+            for (int j = 0; j < DPW; ++j)
+                if (wave < DW && wave + DW * j < NDMA) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + DW * j) * 1024, dvoff[j], so);
         };
         auto transform = [&](int bufr, int bufv) {
             const unsigned char* rs = smem + RAW_OFF + bufr * STAGE + st_off;
-            unsigned char* vs = smem + bufv * STAGE + st_off;
+            unsigned char* vs = smem + bufv * STAGE + sv_off;
             if (job == 0) transform_job<0>(rs, vs);
             else if (job == 1) transform_job<1>(rs, vs);
             else if (job == 2) transform_job<2>(rs, vs);
@@ -252,23 +291,33 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
         };
 
         // ---- prologue: raw(ks0), raw(ks0+1) by DMA; V(ks0) = transform(raw(ks0)); the first weight fragments ---------------
+        W44_STAMP(1);
         dma_raw(ks0, 0);
         if (ks0 + 1 < ks1) dma_raw(ks0 + 1, 1);
 #pragma unroll
         for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, ks0);      // pairs 0 .. BDEPTH-1
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // the DMAs are older than the fragment loads
         __builtin_amdgcn_s_barrier();
+        W44_STAMP(2);
         transform(0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        W44_STAMP(3);
 
         for (int ks = ks0; ks < ks1; ++ks) {
             const int cur = (ks - ks0) & 1;
             const bool more = ks + 1 < ks1;
+#ifndef W44_KO_DMA
             if (ks + 2 < ks1) dma_raw(ks + 2, cur);            // raw[cur] held raw(ks): consumed a K-step ago
+#endif
             // V(ks+1) from raw(ks+1) - it landed before the last barrier - next to the MFMAs on V(ks) (on the last K-step it
             // transforms stale data into a buffer nobody reads: keeps the K-step's shape)
+#ifndef W44_KO_TRANSFORM
+#ifdef W44_DEPHASE
+            if (wave < NW / 2)
+#endif
             transform(cur ^ 1, cur ^ 1);
+#endif
             const unsigned char* vs = smem + cur * STAGE + a_off;
             constexpr int AD = 4;                                  // activation fragments read ahead (two pairs)
             f32x2 aq[AD];
@@ -278,17 +327,24 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
             for (int pr = 0; pr < 18; ++pr) {
                 const f32x2 a0 = aq[(2 * pr) % AD], a1 = aq[(2 * pr + 1) % AD];
                 const f32x4 b = bq[pr % BDEPTH];
-                if (2 * pr + AD < 36) {
+#ifndef W44_KO_AFRAG
+                if (2 * pr + AD < 36)
+#else
+                if (false)
+#endif
+                {
                     aq[(2 * pr) % AD] = *reinterpret_cast<const f32x2*>(vs + (2 * pr + AD) * PLANE);
                     aq[(2 * pr + 1) % AD] = *reinterpret_cast<const f32x2*>(vs + (2 * pr + 1 + AD) * PLANE);
                 }
                 // refill the slot with the pair BDEPTH pairs ahead (it runs on into the next K-step; past the last K-step it
                 // re-reads a valid address and is never used)
+#ifndef W44_KO_B
                 {
                     const int np = pr + BDEPTH;
                     if (np < 18) issue_b(pr % BDEPTH, np, ks);
                     else issue_b(pr % BDEPTH, np - 18, more ? ks + 1 : ks);
                 }
+#endif
                 acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], b[0], acc[2 * pr], 0, 0, 0);
                 acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], b[2], acc[2 * pr + 1], 0, 0, 0);
                 acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], b[1], acc[2 * pr], 0, 0, 0);
@@ -297,10 +353,19 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
                 // front of its MFMAs (lgkmcnt(0) / vmcnt(1..3) ahead of each pair: the LDS and L2 latencies in full, 72 times)
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef W44_DEPHASE
+            if (wave >= NW / 2) transform(cur ^ 1, cur ^ 1);
+#endif
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // this K-step's DMA has landed (older than the window)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#ifdef W44_PROBE
+            if (ks == ks0) W44_STAMP(4);
+            if (ks == ks0 + 1) W44_STAMP(5);
+            if (ks == ks1 - 2) W44_STAMP(6);
+#endif
         }
+        W44_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the window's last, unused fragments: their registers are reused)
 
         // ---- tail: A^T M A in registers -> LDS ([tile][pixel][64 channels] per 16-tile half: the K-loop's buffers are free
@@ -343,7 +408,9 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
                 row[(3 * 4 + q) * RS] = d1 + 8.f * d2 + tq[5][q];
             }
         }
+        W44_STAMP(8);
         __syncthreads();
+        W44_STAMP(9);
         const int gt = tid & 255;                          // thread inside the 16-tile half (four waves)
         const int c4 = (gt & 15) * 4;
         if (producer) {
@@ -410,7 +477,9 @@ __global__ void __launch_bounds__(NTH, 1) conv_wino44_f32_kernel(const W44Args p
                 }
             }
         }
+        W44_STAMP(10);
         __syncthreads();          // the next segment's DMA overwrites the staging tile
+        W44_STAMP(11);
     }
 }
 
@@ -460,29 +529,36 @@ __global__ void __launch_bounds__(256) pack_weights_wino44_kernel(const float* _
 
 }  // namespace
 
+#ifdef W44_PROBE
+extern "C" __attribute__((visibility("default"))) int y3_debug_w44_probe(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_w44_probe), &buf, sizeof(buf));
+}
+#endif
+
 int y3_conv_wino44_eligible_impl(const y3_conv_desc* d) {
     return d && d->k == 3 && d->stride == 1 && d->c_up == 0 && d->cin % 32 == 0 && d->cout % 64 == 0 &&
            d->n > 0 && d->h > 1 && d->w > 1;
 }
 
 // The convs y3_net_forward (dtype 4) runs on this kernel instead of the F(2x2,3x3) one, given the alternative packing
-// (y3_net_set_layer_alt): where it measured faster inside the forward (tools/layer_profile.py, profiles/r03_wino44.txt).
-//   candidate (shape only: what a caller packs for): the 128->256 convs (52-grid at 416x416: 0.245 -> 0.205 ms at bs=32) and
-//     the 512->1024 convs (13-grid: 0.241 -> 0.234 ms).  The 256->512 convs lose to block-count quantisation (392 blocks on
-//     256 CUs), the 32->64 / 64->128 ones to their 4-8 K-step blocks;
-//   preferred (this launch): a candidate whose blocks - 32 tiles x 64 channels, one workgroup each, no K-split - fill at
-//     least three quarters of the 256 CUs.  Below that the F(2x2) kernel's stream-K schedule wins by keeping every CU busy:
-//     a bs=4 forward measured 3.74 ms with it against 4.77 ms with this kernel on 32-88 blocks per layer.
-// Y3_WINO44=0 turns the kernel off, =2 takes every eligible conv whatever its size (A/B runs).
+// (y3_net_set_layer_alt): where it measured faster inside the bs=32 416x416 forward (tools/layer_profile.py,
+// profiles/r04_wino44.txt; ms per layer, F(2x2) | F(4x4) with 16-tile blocks, two workgroups per CU):
+//   64->128 @104: 0.280 | 0.260     128->256 @52: 0.244 | 0.186     256->512 @26: 0.222 | 0.205     512->1024 @13: 0.240 | 0.198
+//   32->64 @208: 0.361 | 0.372 - four K-steps per block, the block prologue and store tail dominate: stays on F(2x2).
+//   candidate (shape only: what a caller packs for): every eligible conv with Cin >= 64;
+//   preferred (this launch): a candidate whose blocks - 16 tiles x 64 channels, one workgroup each, no K-split - fill at
+//     least three quarters of the 512 workgroup slots.  Below that the F(2x2) kernel's stream-K schedule wins by keeping
+//     every CU busy: a bs=4 forward measured 3.74 ms with it against 4.77 ms with this kernel on 32-88 blocks per layer.
+// (experiments build only) Y3_WINO44=0 turns the kernel off, =2 takes every eligible conv whatever its size (A/B runs).
 static int wino44_mode() {
-    static const int mode = getenv("Y3_WINO44") ? atoi(getenv("Y3_WINO44")) : 1;
+    static const int mode = y3_exp_env("Y3_WINO44") ? atoi(y3_exp_env("Y3_WINO44")) : 1;
     return mode;
 }
 
 int y3_conv_wino44_candidate_impl(const y3_conv_desc* d) {
     if (wino44_mode() == 0 || !y3_conv_wino44_eligible_impl(d)) return 0;
     if (wino44_mode() == 2) return 1;
-    return (d->cin == 128 && d->cout == 256) || (d->cin == 512 && d->cout == 1024);
+    return d->cin >= 64;
 }
 
 int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
@@ -490,7 +566,7 @@ int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
     if (wino44_mode() == 2) return 1;
     const long long tiles = (long long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4);
     const long long blocks = ((tiles + BT - 1) / BT) * (d->cout / BNC);
-    return blocks >= 192;
+    return blocks >= 192 * (32 / BT);
 }
 
 int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {
@@ -501,7 +577,7 @@ int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int 
     return Y3_OK;
 }
 
-constexpr int W44_WORKERS = 256;     // one persistent workgroup per CU (147 KB of LDS, eight waves)
+constexpr int W44_WORKERS = 256 * (32 / BT);     // one persistent workgroup per CU slot (147 KB of LDS per 32 tiles)
 constexpr size_t W44_FLAGS_OFFSET = (size_t)W44_WORKERS * SLOT_FLOATS * sizeof(float);
 
 size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d) {
@@ -536,11 +612,15 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
     // forward one workgroup per block measured 11.72-11.74 ms per batch against 11.75-11.79 - the second, partly empty
     // round of blocks runs faster than a full one, and a cut block pays a second prologue and a 128 KB hand-off; stand-alone
     // the 26-grid 256->512 conv gains 5 %, the 52-grid one nothing.)  Y3_CONV_WINO44_STREAMK=0 turns it off everywhere.
-    static const int force = getenv("Y3_CONV_WINO44_STREAMK") ? atoi(getenv("Y3_CONV_WINO44_STREAMK")) : -1;
+    static const int force = y3_exp_env("Y3_CONV_WINO44_STREAMK") ? atoi(y3_exp_env("Y3_CONV_WINO44_STREAMK")) : -1;
     const bool has_ws = workspace != nullptr && workspace_bytes >= y3_conv_wino44_workspace_bytes_impl(d) &&
                         ((uintptr_t)workspace & 15) == 0;
     const int rem = blocks % W44_WORKERS;
+#ifdef W44_SK_KEEP
+    const bool use_sk = force != 0 && has_ws && (long long)blocks * ksteps >= 4LL * W44_WORKERS && blocks % W44_WORKERS != 0;
+#else
     const bool use_sk = force != 0 && has_ws && blocks > W44_WORKERS && rem != 0 && (long long)rem * ksteps >= 2LL * W44_WORKERS;
+#endif
     if (use_sk) {
         a.partial = static_cast<float*>(workspace);
         a.workers = W44_WORKERS;

@@ -38,6 +38,16 @@ int y3_conv_stats_blocks_impl(const y3_conv_desc* d, int wino);
 // the consumers give up after 2^10 polls, so the time-out path (error word -> Y3_EHIP) can be exercised.
 void y3_sk_debug_env(unsigned* spin_limit, int* fault);
 
+// Experiment switches (A/B runs of tools/ and tests/test_conv_variants_gpu.py) exist only in a -DY3_EXPERIMENTS build
+// (csrc/libyolo355_exp.so, `python -m yolov3_tensorflow_amd.build --experiments`): in the product library no environment
+// variable changes which kernel runs.
+#ifdef Y3_EXPERIMENTS
+#include <cstdlib>
+static inline const char* y3_exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* y3_exp_env(const char*) { return nullptr; }
+#endif
+
 void y3_set_error(const char* fmt, ...);
 
 #define Y3_CHECK_ARG(cond, ...)                \

@@ -298,7 +298,7 @@ static void wgrad_split(const y3_conv_desc* d, int* nsplit_out, int* chunk_out) 
     constexpr double SLOTS = 512.0;            // co-resident workgroups
     constexpr double T_K = 3.9, T_FIX = 6.0;   // us per K-step with two workgroups per CU; prologue + epilogue
     const double partial_us = 2.0 * (double)J * d->cout * 4.0 / 3.0e6;   // one partial tile set written + read at ~3 TB/s
-    if (const char* e = getenv("Y3_WGRAD_OLD_SPLIT"); e && e[0] == '1') {   // experiment hook: the round-1 rule
+    if (const char* e = y3_exp_env("Y3_WGRAD_OLD_SPLIT"); e && e[0] == '1') {   // experiment hook: the round-1 rule
         int nsplit = (1024 + tiles - 1) / tiles;
         if (nsplit > 512) nsplit = 512;
         if (nsplit > ksteps) nsplit = ksteps;
