@@ -34,7 +34,7 @@ def main():
         w4 = engine.pack_wino44(w)
         tiles = n * ((g + 3) // 4) ** 2
         blocks = ((tiles + bt - 1) // bt) * (cout // 64)
-        buf = torch.zeros((blocks, 16), dtype=torch.int64, device='cuda')
+        buf = torch.zeros((blocks, 32), dtype=torch.int64, device='cuda')
         for _ in range(3):
             engine.conv2d_fwd_wino44(x, w4, sc, sh, cout, True, residual=res, use_workspace=False)
         torch.cuda.synchronize()
@@ -56,6 +56,9 @@ def main():
             if nm == 'ksteps mid' and ks > 3:
                 extra = '  (%.0f per K-step over %d)' % (m[i] / (ks - 3), ks - 3)
             print('    %-12s %9.0f%s' % (nm, m[i], extra))
+        k = (t[:, 17:24] - t[:, 16:23]).mean(0)
+        print('    K-step ks0+3 of wave 0: dma issue + transform %.0f | frag preload + pair 0 %.0f | pairs 1-5 %.0f | pairs 6-11 %.0f | pairs 12-17 %.0f | waitcnt %.0f | barrier %.0f | sum %.0f'
+              % (k[0], k[1], k[2], k[3], k[4], k[5], k[6], k.sum()))
         span = (t[:, 11].max() - t[:, 0].min())
         print('    launch span %.0f cycles (s_memtime ticks at 100 MHz if constant: see README)' % span)
 

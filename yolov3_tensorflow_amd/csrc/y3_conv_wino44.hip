@@ -143,7 +143,7 @@ __device__ __forceinline__ void transform_job(const unsigned char* rs, unsigned 
 // Clock probe build (tools/wino44_probe.py; never in the product library): wave 0 of every workgroup stamps s_memtime at
 // its phase boundaries into g_w44_probe[block][16].
 __device__ unsigned long long* g_w44_probe = nullptr;
-#define W44_STAMP(i) do { if (g_w44_probe && tid == 0) g_w44_probe[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define W44_STAMP(i) do { if (g_w44_probe && tid == 0) g_w44_probe[(size_t)blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define W44_STAMP(i) do { } while (0)
 #endif
@@ -307,16 +307,26 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
         for (int ks = ks0; ks < ks1; ++ks) {
             const int cur = (ks - ks0) & 1;
             const bool more = ks + 1 < ks1;
+#ifdef W44_PROBE
+            const bool pk = ks == ks0 + 3;
+            if (pk) W44_STAMP(16);
+#endif
+            // DMA of raw(ks+2) (raw[cur] held raw(ks): consumed a K-step ago) and V(ks+1) from raw(ks+1) (it landed before the
+            // last barrier; on the last K-step it transforms stale data into a buffer nobody reads: keeps the K-step's shape)
+            auto stage_next = [&]() {
 #ifndef W44_KO_DMA
-            if (ks + 2 < ks1) dma_raw(ks + 2, cur);            // raw[cur] held raw(ks): consumed a K-step ago
+                if (ks + 2 < ks1) dma_raw(ks + 2, cur);
 #endif
-            // V(ks+1) from raw(ks+1) - it landed before the last barrier - next to the MFMAs on V(ks) (on the last K-step it
-            // transforms stale data into a buffer nobody reads: keeps the K-step's shape)
 #ifndef W44_KO_TRANSFORM
-#ifdef W44_DEPHASE
-            if (wave < NW / 2)
+                transform(cur ^ 1, cur ^ 1);
 #endif
-            transform(cur ^ 1, cur ^ 1);
+            };
+#ifndef W44_MIDPOS
+#define W44_MIDPOS -1
+#endif
+            if (W44_MIDPOS < 0) stage_next();
+#ifdef W44_PROBE
+            if (pk) W44_STAMP(17);
 #endif
             const unsigned char* vs = smem + cur * STAGE + a_off;
             constexpr int AD = 4;                                  // activation fragments read ahead (two pairs)
@@ -325,6 +335,10 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
             for (int s = 0; s < AD; ++s) aq[s] = *reinterpret_cast<const f32x2*>(vs + s * PLANE);
 #pragma unroll
             for (int pr = 0; pr < 18; ++pr) {
+                if (pr == W44_MIDPOS) {
+                    stage_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const f32x2 a0 = aq[(2 * pr) % AD], a1 = aq[(2 * pr + 1) % AD];
                 const f32x4 b = bq[pr % BDEPTH];
 #ifndef W44_KO_AFRAG
@@ -351,15 +365,22 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
                 acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[1], b[3], acc[2 * pr + 1], 0, 0, 0);
                 // keep the software pipeline as written: left alone, hipcc's scheduler moves every fragment read right in
                 // front of its MFMAs (lgkmcnt(0) / vmcnt(1..3) ahead of each pair: the LDS and L2 latencies in full, 72 times)
+#ifdef W44_PROBE
+                if (pk && pr == 0) W44_STAMP(18);
+                if (pk && pr == 5) W44_STAMP(19);
+                if (pk && pr == 11) W44_STAMP(20);
+                if (pk && pr == 17) W44_STAMP(21);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-#ifdef W44_DEPHASE
-            if (wave >= NW / 2) transform(cur ^ 1, cur ^ 1);
-#endif
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // this K-step's DMA has landed (older than the window)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef W44_PROBE
+            if (pk) W44_STAMP(22);
+#endif
             __builtin_amdgcn_s_barrier();
 #ifdef W44_PROBE
+            if (pk) W44_STAMP(23);
             if (ks == ks0) W44_STAMP(4);
             if (ks == ks0 + 1) W44_STAMP(5);
             if (ks == ks1 - 2) W44_STAMP(6);
