@@ -475,6 +475,48 @@ def test_train_step_is_deterministic_and_loss_decreases(isolated_graph):
     assert runs[0][0][-1] < runs[0][0][0]
 
 
+def test_train_workspace_follows_the_dtype_and_a_small_one_is_refused_before_launch(isolated_graph):
+    """(a) the step's workspace is sized per (shape, device, compute_dtype) - the allocation sequence differs
+    between 'f32', 'f32_wino' and 'f32_bf16x6' - so switching the mode on a live model must re-size it, and the steps
+    stay finite and deterministic per mode; (b) y3_net_train_forward compares the workspace with the dry-run peak for
+    the current dtype BEFORE it enqueues anything: a short workspace is Y3_EINVAL, nothing is written."""
+    import ctypes
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training, _lib, framework as fw
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    from oracle import yolo_ref, train_ref
+    params = yolo_ref.synthetic_params(80, seed=4)
+    x = blob_images(7, 2, 96)
+    yts = train_ref.synthetic_targets(8, 2, [96, 96], 80, COCO_ANCHORS, max_boxes=3)
+    model = _fresh_model(params, batch_norm_decay=0.99)
+    trainer = training.Trainer(model, config_optimizer('sgd', 1e-4))
+    sizes = {}
+    with y3.variable_scope('yolov3'):
+        for mode in ('f32', 'f32_wino', 'f32_bf16x6', 'f32'):
+            model.compute_dtype = mode
+            loss = trainer.step(x, yts)
+            assert np.isfinite(float(loss[0])), mode
+            st = training._train_state(model)
+            assert st['ws_shape'][-1] == mode
+            sizes.setdefault(mode, st['ws'].numel())
+        fw.check_context()
+        # (b) a workspace one byte-page short of the dry-run peak: refused, and the guard word behind it is untouched
+        st, net, _ = training._prepare(model, fw.as_device_f32(x))
+        L = _lib.lib()
+        need = L.y3_net_train_workspace_bytes(net, st['vars_all'], 2, 96, 96)
+        assert need > 4096
+        ws = torch.zeros(need + 256, dtype=torch.uint8, device=fw.default_device())
+        ws[need - 4096:] = 0xA5
+        opts, _anchors_keepalive = training._opts(model)
+    xt = fw.as_device_f32(x)
+    rc = L.y3_net_train_forward(net, st['vars_all'], fw.ptr(xt), 2, 96, 96, ctypes.byref(opts), fw.ptr(ws),
+                                ctypes.c_size_t(need - 4096), None, None, None)
+    torch.cuda.synchronize()
+    assert rc == _lib.Y3_EINVAL
+    assert 'workspace too small' in L.y3_last_error().decode()
+    assert bool((ws[need - 4096:] == 0xA5).all())
+
+
 def test_box_iou_matches_oracle():
     import yolov3_tensorflow_amd as y3
     from oracle import train_ref

@@ -491,6 +491,17 @@ extern "C" int y3_net_train_forward(y3_net* net, const y3_train_var* vars, const
     Y3_CHECK_ARG(x && opts && workspace, "y3_net_train_forward: null argument");
     Y3_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "y3_net_train_forward: workspace must be 256-byte aligned");
     if (!net->ctx) { y3_set_error("y3_net_train_forward: the net was created without a context"); return Y3_ESTATE; }
+    // Refuse a workspace that is too small BEFORE anything is launched: the dry run (host only, a few microseconds per layer)
+    // replays the allocation sequence of forward + loss + backward for THIS dtype, shape and variable table.  (The arena's
+    // own overflow flag is only read after a pass has been enqueued - too late to keep the device from writing past the end.)
+    {
+        const size_t need = y3_net_train_workspace_bytes(net, vars, n, h, w);
+        if (need == 0 || workspace_bytes < need) {
+            y3_set_error("y3_net_train_forward: workspace too small (%zu bytes given, %zu needed for this dtype / shape / variable table)",
+                         workspace_bytes, need);
+            return Y3_EINVAL;
+        }
+    }
     if (int rc = forward_impl(net, vars, x, n, h, w, opts, workspace, workspace_bytes, false)) return rc;
     y3_train_state& S = *net->train;
     float** out[3] = {fm1, fm2, fm3};

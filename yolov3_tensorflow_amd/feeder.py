@@ -108,6 +108,17 @@ class _SharedBuffers(object):
             registered = int(torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0)) == 0
         except Exception:       # noqa: BLE001 - no such entry point / no device: the buffer still works, unpinned
             registered = False
+        if not registered:
+            # The raw return code leaves HIP's per-thread last-error set (memlock ulimit, an unsupported /dev/shm mapping):
+            # clear it, or the next launch check of PyTorch on this thread reports an unrelated "HIP error".  And stop
+            # using shared buffers: an unpinned mapping would mean synchronous pageable copies - the pickled 8-bit path
+            # (take() -> None) is the better fallback.
+            try:
+                import ctypes
+                ctypes.CDLL('libamdhip64.so').hipGetLastError()
+            except OSError:
+                pass
+            self.broken = True
         entry = dict(path=path, map=mapping, array=array, tensor=tensor, registered=registered)
         self.entries.append(entry)
         return entry
@@ -123,10 +134,14 @@ class _SharedBuffers(object):
         for i in reversed(free[:-4]):
             self._release(self.busy.pop(i)[1])
         try:
-            return self._create(shape)
+            entry = self._create(shape)
         except (OSError, ValueError):
             self.broken = True
             return None
+        if self.broken:                 # (the mapping could not be page-locked)
+            self._release(entry)
+            return None
+        return entry
 
     def give(self, event, entry):
         self.busy.append((event, entry))
@@ -305,6 +320,16 @@ class Feeder(object):
         buffers = _PinnedBuffers()
         shared = None if in_place else _SharedBuffers()
 
+        def put(item):
+            # every hand-over gives up as soon as the consumer has stopped: a blocking put on a full queue that nobody
+            # drains any more would park this thread - and the device tensors / pinned buffers it holds - for good
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    continue
+
         def produce():
             try:
                 # keep up to `prefetch` batches of decode jobs in flight
@@ -350,15 +375,10 @@ class Feeder(object):
                         ev.record(copy_stream)
                     owner[0].give(ev, owner[1])
                     item = (ids, size, images, bx, lb, ct, ev)
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
-                q.put(None)
+                    put(item)
+                put(None)
             except BaseException as e:       # noqa: BLE001 - handed to the consumer
-                q.put(e)
+                put(e)
 
         th = threading.Thread(target=produce, name='y3-feeder', daemon=True)
         th.start()
@@ -381,9 +401,18 @@ class Feeder(object):
                 yield out
         finally:
             stop.set()
-            th.join(timeout=5.0)
-            if shared is not None and not th.is_alive():
-                copy_stream.synchronize()
+            while th.is_alive():              # drain what is queued so that nothing the producer holds outlives the epoch
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            copy_stream.synchronize()
+            if shared is not None:
                 shared.close()
 
     def __iter__(self):

@@ -163,7 +163,8 @@ def _prepare(model, x):
     if st.get('vars_key') != key:
         st['vars_all'], st['vars_keep'] = _var_table(layer_vars)
         st['vars_key'] = key
-    if st.get('ws_shape') != (n, h, w, str(dev)):
+    ws_key = (n, h, w, str(dev), model.compute_dtype)      # the allocation sequence depends on the net's dtype too
+    if st.get('ws_shape') != ws_key:
         need = L.y3_net_train_workspace_bytes(net, st['vars_all'], n, h, w)
         if need == 0:
             _lib.check(_lib.Y3_EINVAL)
@@ -171,7 +172,7 @@ def _prepare(model, x):
         if ws is None or ws.numel() < need or ws.device != dev:
             st['ws'] = None              # (free the old one first)
             st['ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
-        st['ws_shape'] = (n, h, w, str(dev))
+        st['ws_shape'] = ws_key
     st.update(layer_vars=layer_vars, batch=n, x=x, have_loss=False)
     return st, net, layer_vars
 
