@@ -119,6 +119,65 @@ def test_configs3_bs64_416_loss_and_every_gradient(isolated_graph):
         assert (err <= 2e-4 + 1e-4 * np.abs(r)).all(), 'direct train-mode feature map %d: %.3e' % (i + 1, err.max())
 
 
+def test_configs3_bs64_416_gradients_vs_fp64_autograd(isolated_graph):
+    """the HIP-vs-HIP comparison above would pass a bug COMMON to both backward families at the 64-image
+    split points (BN-backward reductions, the weight-gradient split sums, the loss gradient).  Here the whole bs=64 @416
+    step is differentiated by fp64 autograd on the host (the oracle, on the LeakyReLU branches the GPU took - see
+    tests/test_train_gpu.py for why) and EVERY gradient tensor of the 'f32_wino' step is held against it: 2e-4 of the
+    tensor's max magnitude, the tolerance of the 256 px / bs=4 and 416 px / bs=8 tests.  Slow (the fp64 backward of 64
+    images runs on the host cores): several minutes, ~100 GB of host memory."""
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    from oracle import yolo_ref, train_ref
+    import os
+    try:
+        avail_gb = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 2.0 ** 30
+    except (ValueError, OSError):
+        avail_gb = 0.0
+    if avail_gb < 160 or (os.cpu_count() or 1) < 32:
+        pytest.skip('the fp64 autograd oracle at bs=64 @416 needs ~100 GB of host memory and many cores (%.0f GB, %d cores here)'
+                    % (avail_gb, os.cpu_count() or 1))
+    n, lr = 64, 1e-4
+    params = yolo_ref.synthetic_params(80, seed=1)
+    x = blob_images(31, n, SIZE)
+    yts = train_ref.synthetic_targets(7, n, [SIZE, SIZE], 80, COCO_ANCHORS, max_boxes=6)
+    model = _fresh_model(params, batch_norm_decay=0.99, weight_decay=5e-4)
+    model.compute_dtype = 'f32_wino'
+    trainer = training.Trainer(model, config_optimizer('sgd', lr))
+    trainer.capture = []
+    with y3.variable_scope('yolov3'):
+        loss = trainer.step(x, yts)
+    masks = {}
+    for rec in trainer.capture:
+        if rec['z'] is None:
+            continue
+        pos = (rec['z'] * rec['stats'][2] + rec['stats'][3]) > 0
+        masks[_conv_name(rec['layer'])] = pos.permute(0, 3, 1, 2).cpu()
+    trainer.capture = None
+    grads = {k: v.cpu().numpy() for k, v in trainer.views.items()}
+    loss = [float(v) for v in loss]
+    del trainer
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(os.cpu_count() or 1, 128))
+    ref = train_ref.train_step(params, x, yts, COCO_ANCHORS, optimizer='sgd', lr=lr, weight_decay=5e-4, bn_decay=0.99,
+                               dtype=torch.float64, step=1, masks=masks)
+    for a, b in zip(loss, ref['loss']):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (loss, ref['loss'])
+    assert set(grads) == set(ref['grads']) and len(grads) == 222
+    errs = {name: rel_err(grads[name], gr) for name, gr in ref['grads'].items()}
+    worst = max(errs, key=errs.get)
+    head = [e for k, e in errs.items() if '/yolov3_head/' in k]
+    stem = [errs['yolov3/darknet53_body/%s/weights' % c] for c in ('Conv', 'Conv_1', 'Conv_2')]
+    bn = [e for k, e in errs.items() if k.endswith('/gamma') or k.endswith('/beta')]
+    print('bs=64 @416 f32_wino vs fp64 autograd on the GPU\'s branches: worst %.2e (%s), median %.2e over %d tensors; head '
+          'worst %.2e, first three body convs %s, BN gamma/beta worst %.2e'
+          % (errs[worst], worst, float(np.median(list(errs.values()))), len(errs), max(head),
+             ['%.2e' % e for e in stem], max(bn)))
+    for name, e in errs.items():
+        assert e < GRAD_TOL, '%s: grad rel err %.3e' % (name, e)
+
+
 def test_one_train_step_at_416_bs8_matches_oracle(isolated_graph):
     """The whole-step comparison of tests/test_train_gpu.py at the bench's map sizes (416 px: 13/26/52/104/208 grids)."""
     import yolov3_tensorflow_amd as y3
