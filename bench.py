@@ -407,12 +407,18 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_rank = {}       # name -> every rank's own seconds for the last timed region (reported as per_rank_ms_per_step)
+
     def max_over_ranks(seconds):
         if not distributed:
+            per_rank['last'] = [seconds]
             return seconds
         t = torch.tensor([seconds], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank['last'] = [float(v.item()) for v in every]
+        return max(per_rank['last'])
+    max_over_ranks.per_rank = per_rank
 
     if args.workload == 'c4':
         out = run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over_ranks)
@@ -670,6 +676,7 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
             loss = trainer.step(x, yt)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        rank_ms = [round(v / args.steps * 1e3, 3) for v in getattr(max_over_ranks, 'per_rank', {}).get('last', [elapsed])]
         fw.check_context()
         loss0 = float(loss[0])
         assert np.isfinite(loss0), "non-finite loss"
@@ -705,7 +712,8 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
     return {
         "metric": "images/sec, train step at 416x416 bs=%d per GPU (forward + loss + backward + gradient all-reduce + clip + SGD)" % BATCH,
         "value": round(world * BATCH * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "per_rank_ms_per_step": rank_ms,
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "precision": ("fp32 MFMA arithmetic; Winograd F(2x2,3x3) forms of the forward, the data gradient and the weight "
                       "gradient of the stride-1 3x3 convs, direct kernels elsewhere" if args.precision == 'f32_wino'
@@ -839,6 +847,7 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
             else:
                 direct = res
     elapsed = max_over_ranks(elapsed)
+    rank_ms = [round(v / args.steps * 1e3, 4) for v in getattr(max_over_ranks, 'per_rank', {}).get('last', [elapsed])]
     if rank != 0:
         return None
 
@@ -924,7 +933,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
         out["direct_path"] = direct
     if fast is not None:
         out["fast_path"] = fast
-    if not bf16 and not getattr(args, 'secondary', False):
+    out["per_rank_ms_per_step"] = rank_ms          # every rank's own timed region (value uses the slowest)
+    if world == 1 and not bf16 and not getattr(args, 'secondary', False):      # checker work: N = 1 only
         try:
             out["box_delta_vs_oracle"] = box_delta_vs_oracle(model, y3, x, fms)
         except Exception as e:      # a checker must never cost the line

@@ -1,6 +1,7 @@
-"""The data-parallel train step on DEVICE tensors with two ranks (north_star: "RCCL all-reduce of gradients"):
-the GPU boxes this suite runs on have ONE MI355X, so both ranks share cuda:0 and the process group is `gloo` (RCCL refuses
-two ranks on one device) — the product code path is the one RCCL takes: `training.Trainer(process_group=...)` ->
+"""The data-parallel train step on DEVICE tensors with two ranks (north_star: "RCCL all-reduce of gradients").
+With two or more GPUs visible each rank takes its own device and the process group is `nccl` (= RCCL over xGMI: the
+production transport); on the one-MI355X boxes this suite usually runs on both ranks share cuda:0 and the group is `gloo`
+(RCCL refuses two ranks on one device) — the product code path is the same either way: `training.Trainer(process_group=...)` ->
 `distributed.GradientExchange` issuing bucketed asynchronous all-reduces on slices of the flat device gradient buffer
 while backward is still launching kernels, `grad_scale = 1/world` folded into `y3_clip_update_multi`.
 
@@ -43,11 +44,22 @@ def _data(rank):
     return x, yts
 
 
+def _backend_and_device(rank):
+    """nccl (RCCL) with one device per rank when the box has at least two GPUs, gloo on the shared cuda:0 otherwise."""
+    if torch.cuda.device_count() >= 2:
+        return 'nccl', rank
+    return 'gloo', 0
+
+
 def _worker(rank, world, init_file, out_dir):
     from yolov3_tensorflow_amd import training
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
-    dist.init_process_group('gloo', init_method='file://' + init_file, rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    import yolov3_tensorflow_amd as y3_
+    backend, device = _backend_and_device(rank)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(device)
+    y3_.set_default_device('cuda:%d' % device)
+    dist.init_process_group(backend, init_method='file://' + init_file, rank=rank, world_size=world)
     y3, model = _setup()
     trainer = training.Trainer(model, config_optimizer('momentum', LR), process_group=dist.group.WORLD,
                                bucket_bytes=16 << 20)
@@ -62,7 +74,8 @@ def _worker(rank, world, init_file, out_dir):
     torch.cuda.synchronize()
     state = {v.op_name: v.numpy() for v in y3.global_variables(scope='yolov3')}
     np.savez(os.path.join(out_dir, 'r%d.npz' % rank), **state)
-    torch.save(dict(issued_before_end=issued_before_end, buckets=len(trainer.exchange.edges), world=trainer.exchange.world),
+    torch.save(dict(issued_before_end=issued_before_end, buckets=len(trainer.exchange.edges), world=trainer.exchange.world,
+                    backend=backend),
                os.path.join(out_dir, 'm%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -102,6 +115,8 @@ def test_two_rank_train_steps_on_device_tensors():
     r0, r1 = np.load(os.path.join(d, 'r0.npz')), np.load(os.path.join(d, 'r1.npz'))
     m0 = torch.load(os.path.join(d, 'm0.pt'))
     assert m0['world'] == 2 and m0['buckets'] >= 8
+    assert m0['backend'] == ('nccl' if torch.cuda.device_count() >= 2 else 'gloo')
+    print('two-rank step ran on backend %s' % m0['backend'])
     assert all(k >= 2 for k in m0['issued_before_end']), 'no bucket was issued before backward finished: nothing overlaps'
     # the trainable variables end identical on both ranks (the BN moving statistics are per rank: no sync-BN, like the reference)
     for k in r0.files:

@@ -5,6 +5,9 @@ consuming them but this loop - how far the host side is from what the train step
 multi-scale off, batch 64.
 
     python tools/feeder_rate.py [--workers 8,16,32] [--backends thread,process] [--native 1,0] [--batches 12]
+    python tools/feeder_rate.py --feeders 8 [--workers 10] [--backends thread]     # the host side of an 8-GPU node:
+        eight feeder PROCESSES (one per rank, as train.py runs them) at once on this host, aggregate images/s against
+        the 8 x 697 images/s eight train steps consume (VERDICT r3 #5b; every process uploads to cuda:0 here)
 """
 import argparse
 import os
@@ -39,8 +42,52 @@ def write_set(folder, n, seed=0):
     return lines
 
 
+def _one_feeder(rank, nfeed, lines, args, backend, workers, barrier, out):
+    """One rank's feeder in its own process: warm up, meet the others, serve `batches` batches, report the window."""
+    import torch
+    from yolov3_tensorflow_amd.feeder import Feeder
+    f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True, num_threads=workers,
+               prefetch=5, seed=1 + rank, backend=backend)
+    it = f.epoch(0)
+    for _ in range(3):
+        next(it)
+    torch.cuda.synchronize()
+    barrier.wait()
+    t0 = time.time()
+    for _ in range(args.batches):
+        next(it)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    out.put((rank, t0, t1))
+    barrier.wait()
+    it.close()
+    f.close()
+
+
+def concurrent_feeders(args, lines):
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    n = args.feeders
+    for backend in args.backends.split(','):
+        for workers in [int(v) for v in args.workers.split(',')]:
+            barrier, out = ctx.Barrier(n), ctx.Queue()
+            procs = [ctx.Process(target=_one_feeder, args=(r, n, lines, args, backend, workers, barrier, out)) for r in range(n)]
+            for p in procs:
+                p.start()
+            res = [out.get() for _ in range(n)]
+            for p in procs:
+                p.join()
+            span = max(r[2] for r in res) - min(r[1] for r in res)
+            per = [args.batches * args.batch_size / (r[2] - r[1]) for r in res]
+            total = n * args.batches * args.batch_size / span
+            print('%d feeders at once, backend=%s, %d workers each: aggregate %.0f images/s (per feeder min %.0f / mean %.0f / '
+                  'max %.0f) against %d x 697 = %d images/s consumed by %d train steps: %.2fx'
+                  % (n, backend, workers, total, min(per), sum(per) / n, max(per), n, n * 697, n, total / (n * 697.0)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--feeders', type=int, default=0, help="run this many feeder processes concurrently (one per rank of a node)")
     ap.add_argument('--workers', default='8,16,32')
     ap.add_argument('--backends', default='thread,process')
     ap.add_argument('--native', default='1,0')
@@ -54,6 +101,9 @@ def main():
     lines = write_set(pathlib.Path(tempfile.mkdtemp()), 256)
     lines = (lines * ((args.batches + 3) * args.batch_size // len(lines) + 1))[:(args.batches + 3) * args.batch_size]
     print('host threads available: %d' % len(os.sched_getaffinity(0)), flush=True)
+    if args.feeders > 0:
+        concurrent_feeders(args, lines)
+        return
     if args.check:
         first = {}
         for backend in ('thread', 'process'):

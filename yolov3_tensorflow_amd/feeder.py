@@ -104,11 +104,13 @@ class _SharedBuffers(object):
         array = np.frombuffer(mapping, np.float32).reshape(shape)
         tensor = torch.from_numpy(array)
         registered = False
-        try:
-            registered = int(torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0)) == 0
-        except Exception:       # noqa: BLE001 - no such entry point / no device: the buffer still works, unpinned
-            registered = False
-        if not registered:
+        have_device = torch.cuda.is_available()
+        if have_device:
+            try:
+                registered = int(torch.cuda.cudart().cudaHostRegister(tensor.data_ptr(), nbytes, 0)) == 0
+            except Exception:       # noqa: BLE001 - no such entry point
+                registered = False
+        if have_device and not registered:
             # The raw return code leaves HIP's per-thread last-error set (memlock ulimit, an unsupported /dev/shm mapping):
             # clear it, or the next launch check of PyTorch on this thread reports an unrelated "HIP error".  And stop
             # using shared buffers: an unpinned mapping would mean synchronous pageable copies - the pickled 8-bit path
