@@ -2,7 +2,7 @@
   * py_nms / cpu_nms against the goldens produced by the REFERENCE's own functions;
   * gpu_nms (TF semantics) and cpu_nms against the C oracle on identical inputs at full size
     (10,647 boxes x 80 classes, the thresholds of the reference's call sites), with ties, degenerate
-    boxes, empty results, > KCAP candidates per class, batching;
+    boxes, empty results, every tier of candidate counts per class, batching;
   * size-independent properties: idempotence, sortedness, max_boxes cap."""
 import numpy as np
 import pytest
@@ -54,7 +54,7 @@ def test_cpu_nms_reference_goldens(golden):
 
 @pytest.mark.parametrize('max_boxes,score_thresh,iou_thresh', [
     (200, 0.3, 0.45),    # test_single_image.py:57
-    (400, 0.01, 0.45),   # eval.py:47-54 (~10,000 candidates per class: the register-resident kernel, K > KCAP)
+    (400, 0.01, 0.45),   # eval.py:47-54 (~10,000 candidates per class: the sixteen-wave sorted form)
     (150, 0.9, 0.45),    # sparse candidates: the LDS path
     (50, 0.5, 0.5),      # the function defaults
 ])
@@ -78,27 +78,32 @@ def test_full_size_matches_c_oracle(mode, max_boxes, score_thresh, iou_thresh):
 
 
 @pytest.mark.parametrize('mode', ['tf', 'py'])
-def test_more_candidates_than_the_register_kernel_holds(mode):
-    """Three tiers of candidate storage per (image, class): LDS (K <= 1,536), registers of a twelve-wave workgroup
-    (K <= 10,752), global memory beyond (a 608x608 image has 22,743 boxes).  One call with all three: class 0 keeps every
-    one of 12,000 boxes, class 1 about 4,000, class 2 about 120 - bit-exact against the C oracle."""
+def test_every_tier_of_candidate_counts(mode):
+    """Three kernels by the number of candidates K of an (image, class): the sorted form on ONE wave (K <= 512), on sixteen
+    waves (K <= 16,384: keys in the LDS), and the arg-max form on global memory beyond (a 608x608 image has 22,743 boxes).
+    One call with all of them - class 0 keeps every one of 20,000 boxes, class 1 about 7,000, class 2 about 600 (just past
+    the one-wave form), class 3 about 200 - bit-exact against the C oracle, with max_boxes below and above what the classes
+    can fill (early exit and exhaustion)."""
     from yolov3_tensorflow_amd.utils import nms_utils
     from yolov3_tensorflow_amd import _lib
     from oracle import nms_ref
-    boxes, scores = stress_inputs(seed=7, B=12000, C=3)
+    boxes, scores = stress_inputs(seed=7, B=20000, C=4)
     scores[:, 0] = 0.5 + 0.5 * scores[:, 0]            # all above the threshold
-    scores[:, 2] *= 0.25                                # ~1 % above it
-    ob, osc, ol, oi = nms_ref.c_per_class(mode, boxes, scores, 3, 300, 0.2, 0.45)
-    counts = [(scores[:, c] >= 0.2).sum() for c in range(3)]
-    assert counts[0] > 10752 >= counts[1] > 1536 >= counts[2] > 0, counts
+    scores[:, 1] = np.where(scores[:, 1] > 0.3, scores[:, 1], 0.1)
+    scores[:, 2] = np.where(scores[:, 2] > 0.75, scores[:, 2], 0.1)
+    scores[:, 3] = np.where(scores[:, 3] > 0.85, scores[:, 3], 0.1)
+    counts = [int((scores[:, c] >= 0.2).sum()) for c in range(4)]
+    assert counts[0] > 16384 >= counts[1] > 512 and 16384 >= counts[2] > 512 >= counts[3] > 0, counts
     m = _lib.Y3_NMS_TF if mode == 'tf' else _lib.Y3_NMS_PY
-    gb, gs, gl, gi, cnt = nms_utils._run_nms(m, torch.from_numpy(boxes).cuda()[None], torch.from_numpy(scores).cuda()[None],
-                                             3, 300, 0.2, 0.45)
-    k = int(cnt[0])
-    assert k == len(ob), 'selected %d, oracle %d' % (k, len(ob))
-    np.testing.assert_array_equal(gi[0, :k].cpu().numpy(), oi)
-    np.testing.assert_array_equal(gl[0, :k].cpu().numpy(), ol)
-    np.testing.assert_array_equal(gs[0, :k].cpu().numpy(), osc)
+    for max_boxes in (40, 300, 1500, 2500):      # (2,500 selected boxes do not fit the LDS beside the keys: arg-max form for all)
+        ob, osc, ol, oi = nms_ref.c_per_class(mode, boxes, scores, 4, max_boxes, 0.2, 0.45)
+        gb, gs, gl, gi, cnt = nms_utils._run_nms(m, torch.from_numpy(boxes).cuda()[None], torch.from_numpy(scores).cuda()[None],
+                                                 4, max_boxes, 0.2, 0.45)
+        k = int(cnt[0])
+        assert k == len(ob), 'max_boxes %d: selected %d, oracle %d' % (max_boxes, k, len(ob))
+        np.testing.assert_array_equal(gi[0, :k].cpu().numpy(), oi)
+        np.testing.assert_array_equal(gl[0, :k].cpu().numpy(), ol)
+        np.testing.assert_array_equal(gs[0, :k].cpu().numpy(), osc)
 
 
 def test_gpu_nms_api_and_empty_result():

@@ -46,22 +46,57 @@ def _one_feeder(rank, nfeed, lines, args, backend, workers, barrier, out):
     """One rank's feeder in its own process: warm up, meet the others, serve `batches` batches, report the window."""
     import torch
     from yolov3_tensorflow_amd.feeder import Feeder
-    f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True, num_threads=workers,
-               prefetch=5, seed=1 + rank, backend=backend)
-    it = f.epoch(0)
-    for _ in range(3):
-        next(it)
-    torch.cuda.synchronize()
-    barrier.wait()
-    t0 = time.time()
-    for _ in range(args.batches):
-        next(it)
-    torch.cuda.synchronize()
-    t1 = time.time()
-    out.put((rank, t0, t1))
-    barrier.wait()
-    it.close()
-    f.close()
+    try:
+        f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True, num_threads=workers,
+                   prefetch=5, seed=1 + rank, backend=backend)
+        if args.host_only:
+            # the host half alone (decode, augmentation chain, resize into a float32 batch buffer, collate): no device call at
+            # all, so eight of these on a one-GPU box measure the HOST of an eight-GPU node (with uploads, eight processes
+            # time-slice the one device here and the figure is the slicing, not the host)
+            from yolov3_tensorflow_amd import feeder as fd
+            from yolov3_tensorflow_amd.utils.data_utils import collate
+            pool, plan = f._executor(), f._plan(0)
+
+            def submit(entry):
+                b, size, mine = entry
+                slots = np.empty((len(mine), size[1], size[0], 3), np.float32)
+                return slots, [pool.submit(fd._worker_sample, f._job(0, b, j, line, size), slots[j]) for j, line in enumerate(mine)]
+
+            def finish(item):
+                slots, futs = item
+                samples = [x.result() for x in futs]
+                collate([(s_[0], slots[j] if s_[1] is None else s_[1], s_[2], s_[3]) for j, s_ in enumerate(samples)], out_images=slots)
+            pending = [submit(e) for e in plan[:5]]
+            nxt = 5
+            for _ in range(3):
+                finish(pending.pop(0))
+                pending.append(submit(plan[nxt])); nxt += 1
+            barrier.wait(timeout=180)
+            t0 = time.time()
+            for _ in range(args.batches):
+                finish(pending.pop(0))
+                if nxt < len(plan):
+                    pending.append(submit(plan[nxt])); nxt += 1
+            t1 = time.time()
+            out.put((rank, t0, t1, None))
+            f.close()
+            return
+        it = f.epoch(0)
+        for _ in range(3):
+            next(it)
+        torch.cuda.synchronize()
+        barrier.wait(timeout=180)
+        t0 = time.time()
+        for _ in range(args.batches):
+            next(it)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        out.put((rank, t0, t1, None))
+        it.close()
+        f.close()
+    except BaseException as e:      # noqa: BLE001 - reported by the parent; never leave the others at the barrier
+        barrier.abort()
+        out.put((rank, 0.0, 0.0, '%s: %s' % (type(e).__name__, e)))
 
 
 def concurrent_feeders(args, lines):
@@ -74,19 +109,32 @@ def concurrent_feeders(args, lines):
             procs = [ctx.Process(target=_one_feeder, args=(r, n, lines, args, backend, workers, barrier, out)) for r in range(n)]
             for p in procs:
                 p.start()
-            res = [out.get() for _ in range(n)]
+            res = []
+            try:
+                for _ in range(n):
+                    res.append(out.get(timeout=420))
+            except Exception:       # noqa: BLE001 - queue.Empty: a feeder never reported
+                pass
             for p in procs:
-                p.join()
+                p.join(timeout=20)
+                if p.is_alive():
+                    p.terminate()
+            bad = [r for r in res if r[3]]
+            if len(res) < n or bad:
+                print('%d feeders, backend=%s, %d workers: FAILED (%d reports; %s)' % (n, backend, workers, len(res),
+                                                                                      '; '.join(str(r[3]) for r in bad)), flush=True)
+                continue
             span = max(r[2] for r in res) - min(r[1] for r in res)
             per = [args.batches * args.batch_size / (r[2] - r[1]) for r in res]
             total = n * args.batches * args.batch_size / span
-            print('%d feeders at once, backend=%s, %d workers each: aggregate %.0f images/s (per feeder min %.0f / mean %.0f / '
+            print('%d feeders at once%s, backend=%s, %d workers each: aggregate %.0f images/s (per feeder min %.0f / mean %.0f / '
                   'max %.0f) against %d x 697 = %d images/s consumed by %d train steps: %.2fx'
-                  % (n, backend, workers, total, min(per), sum(per) / n, max(per), n, n * 697, n, total / (n * 697.0)), flush=True)
+                  % (n, ' (host half only)' if args.host_only else '', backend, workers, total, min(per), sum(per) / n, max(per), n, n * 697, n, total / (n * 697.0)), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--host-only', action='store_true', help="with --feeders: the host half only (no upload, no device)")
     ap.add_argument('--feeders', type=int, default=0, help="run this many feeder processes concurrently (one per rank of a node)")
     ap.add_argument('--workers', default='8,16,32')
     ap.add_argument('--backends', default='thread,process')
@@ -99,7 +147,7 @@ def main():
     import torch
     from yolov3_tensorflow_amd.feeder import Feeder
     lines = write_set(pathlib.Path(tempfile.mkdtemp()), 256)
-    lines = (lines * ((args.batches + 3) * args.batch_size // len(lines) + 1))[:(args.batches + 3) * args.batch_size]
+    lines = (lines * ((args.batches + 9) * args.batch_size // len(lines) + 1))[:(args.batches + 9) * args.batch_size]
     print('host threads available: %d' % len(os.sched_getaffinity(0)), flush=True)
     if args.feeders > 0:
         concurrent_feeders(args, lines)

@@ -4,30 +4,32 @@
 //   Y3_NMS_PY : utils/nms_utils.py:51-123 `py_nms`/`cpu_nms`; +1 on the intersection w/h only,
 //               a candidate survives only while ovr <= thresh (NaN does not survive).
 //
-// Formulation (no sort): greedy NMS == repeatedly take the best-scoring live candidate, then kill every
-// live candidate that overlaps it.  One workgroup per (image, class); the kill pass and the search for
-// the next best are fused in ONE sweep over the candidates per selected box; the arg-max is a 64-bit key
-// {orderable score bits, ~box index} reduced with wave shuffles, which also fixes the tie-break to
-// (score descending, box index ascending) deterministically.  Candidate records live in LDS when the
-// class has <= KCAP candidates (always, outside adversarial inputs) and are re-derived from global memory
-// otherwise.  All IoU arithmetic is plain fp32 in the reference's operation order (compiled with
-// -ffp-contract=off) so selections are bit-exact against the CPU oracle.
+// Greedy NMS == visit the candidates of a class in the order (score descending, box index ascending) and keep one iff no
+// kept box suppresses it.  The order is a 64-bit key {orderable score bits, ~box index}, which makes the tie-break
+// deterministic.  Two forms, one workgroup per (image, class) each:
+//   * nms_select_sorted_kernel (every class with up to RCAP = 16,384 candidates): keys sorted in the LDS, candidates
+//     visited in chunks - parallel test against the kept boxes, in-order resolution inside the chunk, early exit at
+//     max_boxes (round 4; it replaced an arg-max sweep per selected box whose heaviest class took 2.7 ms alone);
+//   * nms_select_kernel (more than RCAP candidates in one class): no sort - repeatedly take the best live candidate
+//     (wave-shuffle arg-max on the keys) and kill what it overlaps, candidates re-derived from global memory.
+// All IoU arithmetic is plain fp32 in the reference's operation order (compiled with -ffp-contract=off) so selections are
+// bit-exact against the CPU oracle.
 //
 // Pipeline: collect (threshold + per-class compaction, LDS-aggregated atomics) -> select -> gather.
 #include "y3_internal.h"
 
 namespace {
 
-constexpr int KCAP = 1536;  // candidates per (image,class) cached in LDS: 1536 * 28 B = 42 KB
-// above KCAP and up to RCAP candidates: twelve waves with the candidates in registers (nms_select_reg_kernel)
-constexpr int RTHREADS = 768, RSLOTS = 14, RCAP = RTHREADS * RSLOTS;      // 10,752 >= the 10,647 boxes of a 416x416 image
-                                                                         // (twelve waves = three per SIMD: 170 registers each)
+// classes with up to RCAP candidates run on the sorted forms (nms_select_sorted_kernel: their keys live in the LDS); the
+// arg-max form below keeps only what is left: more than RCAP candidates in ONE class (a dense score map at 608x608)
+constexpr int RCAP = 16384;
 
 struct NmsWs {
     int32_t* cand_count;  // [n*C]
     int32_t* cand_idx;    // [n*C][B]
     int32_t* sel_count;   // [n*C]
     int32_t* sel_idx;     // [n*C][max_boxes]
+    int rcap;             // classes with up to this many candidates run on the sorted forms (0: max_boxes too large for them)
 };
 
 __global__ void __launch_bounds__(256) nms_collect_kernel(const float* __restrict__ scores, int B, int C,
@@ -148,7 +150,6 @@ template <int MODE>
 __global__ void __launch_bounds__(256) nms_select_kernel(const float* __restrict__ boxes,
                                                          const float* __restrict__ scores, int B, int C,
                                                          int max_boxes, float iou_thr, NmsWs ws) {
-    __shared__ Cand lcand[KCAP];
     __shared__ unsigned long long skey[4];
     __shared__ int spos[4];
     __shared__ Cand sel;
@@ -161,10 +162,11 @@ __global__ void __launch_bounds__(256) nms_select_kernel(const float* __restrict
         if (threadIdx.x == 0) ws.sel_count[blockIdx.x] = 0;
         return;
     }
-    if (K > KCAP && K <= RCAP) return;          // nms_select_reg_kernel's share
+    if (K <= ws.rcap) return;                   // nms_select_sorted_kernel's share
     const float* boxes_n = boxes + (size_t)n * B * 4;
     const float* scores_n = scores + (size_t)n * B * C;
-    const bool in_lds = K <= KCAP;
+    constexpr bool in_lds = false;              // (candidates are re-derived from global memory on every sweep)
+    Cand* lcand = nullptr;
 
     // ---- load candidates and find the first best ---------------------------------------------------
     unsigned long long lkey = 0ull;
@@ -220,84 +222,131 @@ __global__ void __launch_bounds__(256) nms_select_kernel(const float* __restrict
     if (threadIdx.x == 0) ws.sel_count[blockIdx.x] = nsel;
 }
 
-// The same greedy selection for the classes with KCAP < K <= RCAP candidates (dense score maps: an untrained head at
-// eval.py's 0.01 threshold puts most of the 10,647 boxes of a 416x416 image above it in every class).  Twelve waves, every
-// thread keeps up to RSLOTS candidates in REGISTERS (thread t owns positions t, t + 768, ...), so the fused kill /
-// arg-max sweep per selected box touches no memory at all; only the selected record goes through the LDS.  (The form
-// this replaces re-derived every candidate from global memory on every sweep: 41 / 174 ms per bs=32 batch at 200 / 400
-// selections per class.)  Same arithmetic, same keys: bit-identical selections.
-template <int MODE>
-__global__ void __launch_bounds__(RTHREADS) nms_select_reg_kernel(const float* __restrict__ boxes,
-                                                                  const float* __restrict__ scores, int B, int C,
-                                                                  int max_boxes, float iou_thr, NmsWs ws) {
-    __shared__ unsigned long long skey[RTHREADS / 64];
-    __shared__ int spos[RTHREADS / 64];
-    __shared__ Cand sel;
+// Greedy selection on SORTED candidates, for every class with 1 .. RCAP candidates.  The arg-max forms pay one
+// workgroup-wide reduction (two barriers) and one sweep over ALL live candidates per SELECTED box - 190 dependent sweeps
+// per class in the bench's detector regime at eval.py's parameters, 400 on its heaviest classes (5-10k candidates:
+// 2.7 ms for ONE workgroup, the critical path of the whole batch, profiles/r04_postproc.txt).  Here:
+//   1. keys {orderable score bits, ~box index} of the K candidates are sorted descending in the LDS (bitonic); greedy NMS
+//      visits candidates in exactly that order - same keys, same tie-break as the arg-max form;
+//   2. chunks of NT consecutive candidates, one per thread: (a) every thread tests its candidate against the boxes
+//      selected so far (LDS broadcast reads, all threads in parallel); (b) the survivors are resolved in order: wave by
+//      wave, and inside a wave the lowest live lane is selected (v_readlane), the lanes behind it that it overlaps die
+//      (one ballot per selection); the later waves test their survivors against what the wave before them selected;
+//   3. the loop ends as soon as max_boxes are selected - a heavy class never looks at its tail.
+// Three instantiations by the class's candidate count, so that the LDS a workgroup holds (its keys) matches what it needs and
+// several classes share a CU: ONE wave up to SK1 candidates (4 KB of keys), four waves up to SK4 (32 KB; the bench's
+// detector regime at eval.py's threshold has 1,064 of its 2,560 classes here, 2,330 candidates at most), sixteen waves up
+// to RCAP (128 KB: one class per CU).  Same arithmetic (suppressed<MODE>, make_cand<MODE>) on the same pairs, same order of
+// decisions: the selections are bit-identical to the arg-max kernels' (tests/test_nms_gpu.py against the C oracle).
+#ifndef Y3_NMS_SK1
+#define Y3_NMS_SK1 256
+#endif
+constexpr int SK1 = Y3_NMS_SK1, SK4 = 4096;
+
+template <int MODE, int NT>
+__global__ void __launch_bounds__(NT) nms_select_sorted_kernel(const float* __restrict__ boxes,
+                                                               const float* __restrict__ scores, int B, int C,
+                                                               int max_boxes, float iou_thr, NmsWs ws) {
+    constexpr int NW = NT / 64;
+    constexpr int KMAX = NW == 1 ? SK1 : NW == 4 ? SK4 : RCAP;      // keys the LDS holds (a power of two >= the largest K of this form)
+    constexpr int KLO = NW == 1 ? 0 : NW == 4 ? SK1 : SK4;          // this form's classes: KLO < K <= KMAX
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(nms_lds);                 // [KMAX]
+    f32x4* sbox = reinterpret_cast<f32x4*>(nms_lds + (size_t)KMAX * 8);                         // [max_boxes] selected corners
+    float* sarea = reinterpret_cast<float*>(nms_lds + (size_t)KMAX * 8 + (size_t)max_boxes * 16);   // [max_boxes]
+    int* s_nsel = reinterpret_cast<int*>(nms_lds + (size_t)KMAX * 8 + (size_t)max_boxes * 20);       // [2]
     const int K = ws.cand_count[blockIdx.x];
-    if (K <= KCAP || K > RCAP) return;          // nms_select_kernel's share
+    if (K <= KLO || K > KMAX) return;           // (K == 0: nms_select_kernel wrote the zero count)
     const int n = blockIdx.x / C, c = blockIdx.x - n * C;
     const int32_t* cidx = ws.cand_idx + (size_t)blockIdx.x * B;
     int32_t* sidx = ws.sel_idx + (size_t)blockIdx.x * max_boxes;
     const float* boxes_n = boxes + (size_t)n * B * 4;
     const float* scores_n = scores + (size_t)n * B * C;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // six registers per candidate (the area is recomputed from the corners: the same expression, the same bits)
-    float q0[RSLOTS], q1[RSLOTS], q2[RSLOTS], q3[RSLOTS], qs[RSLOTS];
-    int qi[RSLOTS];
-    auto slot_cand = [&](int s) {
-        Cand k;
-        k.c0 = q0[s]; k.c1 = q1[s]; k.c2 = q2[s]; k.c3 = q3[s];
-        k.area = (k.c2 - k.c0) * (k.c3 - k.c1);
-        k.score = qs[s]; k.idx = qi[s];
-        return k;
-    };
-    unsigned long long lkey = 0ull;
-    int lpos = -1;
-#pragma unroll
-    for (int s = 0; s < RSLOTS; ++s) {
-        const int j = tid + RTHREADS * s;
-        q0[s] = q1[s] = q2[s] = q3[s] = qs[s] = 0.f;
-        qi[s] = -1;
+    int KP = 64;
+    while (KP < K) KP <<= 1;
+    for (int j = tid; j < KP; j += NT) {
+        unsigned long long key = 0ull;          // padding sorts last (a real key is never 0: its low half is ~idx, idx >= 0)
         if (j < K) {
-            Cand k;
-            make_cand<MODE>(boxes_n, scores_n, C, c, cidx[j], k);
-            q0[s] = k.c0; q1[s] = k.c1; q2[s] = k.c2; q3[s] = k.c3; qs[s] = k.score; qi[s] = k.idx;
-            const unsigned long long key = make_key(k.score, k.idx);
-            if (key > lkey) { lkey = key; lpos = j; }
+            const int idx = cidx[j];
+            key = make_key(scores_n[(size_t)idx * C + c], idx);
+        }
+        keys[j] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= KP; size <<= 1) {             // bitonic sort, descending
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (KP >> 1); t += NT) {
+                const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const int hi = lo | stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
         }
     }
-    int best = block_argmax<RTHREADS / 64>(lkey, lpos, skey, spos);
-    int nsel = 0;
-    while (best >= 0 && nsel < max_boxes) {
-        const int slot = best / RTHREADS;
-        if (best - slot * RTHREADS == tid) {             // the owner publishes and retires the selected candidate
-#pragma unroll
-            for (int s = 0; s < RSLOTS; ++s)
-                if (s == slot) {
-                    sel = slot_cand(s);
-                    sidx[nsel] = qi[s];
-                    qi[s] = ~qi[s];
-                }
+
+    int nsel = 0;                               // uniform over the workgroup
+    auto test_against = [&](const Cand& k, bool& alive, int s0, int s1) {
+#pragma unroll 4
+        for (int s = s0; s < s1; ++s) {
+            Cand sc;
+            const f32x4 sb = sbox[s];
+            sc.c0 = sb[0]; sc.c1 = sb[1]; sc.c2 = sb[2]; sc.c3 = sb[3];
+            sc.area = sarea[s];
+            if (alive && suppressed<MODE>(sc, k, iou_thr)) alive = false;
         }
-        ++nsel;
-        __syncthreads();
-        const Cand sc = sel;
-        lkey = 0ull;
-        lpos = -1;
-        if (nsel < max_boxes) {
-#pragma unroll
-            for (int s = 0; s < RSLOTS; ++s) {
-                if (qi[s] < 0) continue;
-                if (suppressed<MODE>(sc, slot_cand(s), iou_thr)) {
-                    qi[s] = ~qi[s];
-                } else {
-                    const unsigned long long key = make_key(qs[s], qi[s]);
-                    if (key > lkey) { lkey = key; lpos = tid + RTHREADS * s; }
+    };
+    for (int base = 0; base < K && nsel < max_boxes; base += NT) {
+        const int j = base + tid;
+        bool alive = j < K;
+        Cand k;
+        k.c0 = k.c1 = k.c2 = k.c3 = k.area = k.score = 0.f;
+        k.idx = 0;
+        if (alive) {
+            const int idx = (int)~(unsigned)(keys[j] & 0xffffffffull);
+            make_cand<MODE>(boxes_n, scores_n, C, c, idx, k);
+        }
+        test_against(k, alive, 0, nsel);        // (a) against the boxes selected from earlier chunks
+        for (int w = 0; w < NW && nsel < max_boxes; ++w) {       // (b) in order: wave by wave, lane by lane
+            if (base + w * 64 >= K) break;
+            int mine = nsel;
+            if (wave == w) {
+                unsigned long long mask = __ballot(alive);
+                while (mask != 0ull && mine < max_boxes) {
+                    const int l = __builtin_ctzll(mask);
+                    Cand sc;
+                    sc.c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k.c0), l));
+                    sc.c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k.c1), l));
+                    sc.c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k.c2), l));
+                    sc.c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k.c3), l));
+                    sc.area = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, k.area), l));
+                    if (lane == l) {
+                        sbox[mine] = f32x4{k.c0, k.c1, k.c2, k.c3};
+                        sarea[mine] = k.area;
+                        sidx[mine] = k.idx;
+                        alive = false;
+                    }
+                    ++mine;
+                    if (alive && lane > l && suppressed<MODE>(sc, k, iou_thr)) alive = false;
+                    mask = __ballot(alive);
                 }
+                if (NW > 1 && lane == 0) s_nsel[w & 1] = mine;
+            }
+            if (NW > 1) {
+                // (the slot of step w is rewritten at step w + 2, which no wave reaches before every wave has passed the
+                //  barrier of step w + 1, i.e. after it has read this one)
+                __syncthreads();
+                const int upto = s_nsel[w & 1];
+                if (wave > w) test_against(k, alive, nsel, upto);
+                nsel = upto;
+            } else {
+                nsel = mine;
             }
         }
-        best = block_argmax<RTHREADS / 64>(lkey, lpos, skey, spos);
+        __syncthreads();      // this chunk's selections are in the LDS before the next chunk reads them
     }
     if (tid == 0) ws.sel_count[blockIdx.x] = nsel;
 }
@@ -365,6 +414,10 @@ extern "C" int y3_nms(y3_ctx* ctx, int mode, const float* boxes, const float* sc
     ws.sel_count = reinterpret_cast<int32_t*>(p);  p += align256(nc * 4);
     ws.cand_idx = reinterpret_cast<int32_t*>(p);   p += align256(nc * num_boxes * 4);
     ws.sel_idx = reinterpret_cast<int32_t*>(p);
+    // the sorted forms keep a class's keys AND its selected boxes in the LDS: beyond ~1,600 boxes per class the arg-max form
+    // takes every class
+    const bool sorted_ok = (size_t)16384 * 8 + (size_t)max_boxes * 20 + 16 <= (size_t)160 * 1024;
+    ws.rcap = sorted_ok ? RCAP : 0;
     hipStream_t st = ctx->stream;
     Y3_CHECK_HIP(hipMemsetAsync(ws.cand_count, 0, nc * 4, st));
     const int bpb = 64;  // boxes per collect block
@@ -379,15 +432,27 @@ extern "C" int y3_nms(y3_ctx* ctx, int mode, const float* boxes, const float* sc
         hipLaunchKernelGGL(nms_select_kernel<Y3_NMS_PY>, dim3((unsigned)nc), dim3(256), 0, st, boxes, scores,
                            num_boxes, class_num, max_boxes, iou_thresh, ws);
     Y3_CHECK_HIP(hipGetLastError());
-    if (num_boxes > KCAP) {      // classes with more candidates than the LDS form holds (each kernel returns at once
-                                 // on the other's classes: the counts live on the device)
-        if (mode == Y3_NMS_TF)
-            hipLaunchKernelGGL(nms_select_reg_kernel<Y3_NMS_TF>, dim3((unsigned)nc), dim3(RTHREADS), 0, st, boxes, scores,
-                               num_boxes, class_num, max_boxes, iou_thresh, ws);
-        else
-            hipLaunchKernelGGL(nms_select_reg_kernel<Y3_NMS_PY>, dim3((unsigned)nc), dim3(RTHREADS), 0, st, boxes, scores,
-                               num_boxes, class_num, max_boxes, iou_thresh, ws);
-        Y3_CHECK_HIP(hipGetLastError());
+    if (sorted_ok) {
+        // every class with 1 .. RCAP candidates on the sorted forms: one wave up to SK1 candidates, sixteen waves above (each
+        // kernel returns at once on the others' classes: the counts live on the device)
+        const size_t sel_bytes = (size_t)max_boxes * 20 + 16;
+        auto launch_tier = [&](auto kern, int threads, size_t keys) -> int {
+            const size_t lds = keys * 8 + sel_bytes;
+            Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)nc), dim3(threads), lds, st, boxes, scores, num_boxes, class_num, max_boxes,
+                               iou_thresh, ws);
+            Y3_CHECK_HIP(hipGetLastError());
+            return Y3_OK;
+        };
+        const bool tf = mode == Y3_NMS_TF;
+        if (int rc = tf ? launch_tier(nms_select_sorted_kernel<Y3_NMS_TF, 64>, 64, SK1)
+                        : launch_tier(nms_select_sorted_kernel<Y3_NMS_PY, 64>, 64, SK1)) return rc;
+        if (num_boxes > SK1)
+            if (int rc = tf ? launch_tier(nms_select_sorted_kernel<Y3_NMS_TF, 256>, 256, SK4)
+                            : launch_tier(nms_select_sorted_kernel<Y3_NMS_PY, 256>, 256, SK4)) return rc;
+        if (num_boxes > SK4)
+            if (int rc = tf ? launch_tier(nms_select_sorted_kernel<Y3_NMS_TF, 1024>, 1024, RCAP)
+                            : launch_tier(nms_select_sorted_kernel<Y3_NMS_PY, 1024>, 1024, RCAP)) return rc;
     }
     hipLaunchKernelGGL(nms_gather_kernel, dim3(n), dim3(256), (class_num + 1) * sizeof(int), st, boxes,
                        scores, num_boxes, class_num, max_boxes, ws, out_boxes, out_scores, out_labels,

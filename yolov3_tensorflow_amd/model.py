@@ -277,11 +277,13 @@ class yolov3(object):
         """SURVEY §8(f) row 2 — the whole inference path for a batch with everything resident on the device:
         forward -> predict (+ fused conf*prob) -> per-class NMS for all N images in one launch set.  Replaces
         the per-image `sess.run` round trips of eval.py:114-123 / utils/eval_utils.py:237-261.
-        Returns a list of N tuples (boxes [K,4], scores [K], labels [K] int32) of device tensors."""
+        Returns N tuples (boxes [K,4], scores [K], labels [K] int32) of device tensors as a list-like LazyDetections: the
+        per-image counts come back asynchronously and the host waits for them only when the result is first indexed or
+        iterated, so the next batch can be enqueued before this one is read."""
         from .utils import nms_utils
         fms = self.forward(inputs, False)
         boxes, _, _, scores = self.predict(fms, with_scores=True)
-        return nms_utils.gpu_nms_batched(boxes, scores, self.class_num, max_boxes, score_thresh, nms_thresh)
+        return nms_utils.gpu_nms_batched(boxes, scores, self.class_num, max_boxes, score_thresh, nms_thresh, lazy=True)
 
     # ------------------------------------------------------------------------------------------
     # loss (training path)

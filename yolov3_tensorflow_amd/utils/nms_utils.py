@@ -19,6 +19,53 @@ from .. import _lib
 from .. import framework as fw
 
 
+_WS_CACHE = {}      # (device index, stream) -> uint8 tensor: y3_nms's scratch, reused by every call on that stream
+
+
+def _workspace(dev, nbytes):
+    """The library's scratch for one y3_nms call.  One buffer per (device, stream), grown on demand: calls on a stream are
+    ordered, so the next call may overwrite what the previous one used (the results live in tensors of their own)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS_CACHE[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return ws
+
+
+class LazyDetections(object):
+    """What gpu_nms_batched(lazy=True) / yolov3.detect return: behaves like the list of per-image (boxes, scores, labels[,
+    index]) tuples, but the per-image counts travel to the host asynchronously (pinned buffer + event) and the list is built
+    on first access - so a caller can enqueue the next batch's forward before it reads this batch's detections, and no
+    host round trip sits between two device batches (eval.py:114-123 did one per image)."""
+
+    def __init__(self, tensors, counts_host, event, device, return_index):
+        self._t, self._cnt, self._ev, self._dev, self._ri = tensors, counts_host, event, device, return_index
+        self._items = None
+
+    def _materialise(self):
+        if self._items is None:
+            self._ev.synchronize()
+            fw.check_context(self._dev)     # surfaces a device-side failure of the forward, if any (stream idle or not)
+            ob, osc, ol, oi = self._t
+            out = []
+            for i, k in enumerate(self._cnt.tolist()):
+                item = (ob[i, :k], osc[i, :k], ol[i, :k])
+                if self._ri:
+                    item = item + (oi[i, :k],)
+                out.append(item)
+            self._items, self._t = out, None
+        return self._items
+
+    def __len__(self):
+        return int(self._cnt.shape[0])
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+
 def _run_nms(mode, boxes, scores, num_classes, max_boxes, score_thresh, iou_thresh):
     """boxes [n,B,4], scores [n,B,C] device tensors -> (out_boxes, out_scores, out_labels, out_index,
     counts) with per-image capacity C*max_boxes."""
@@ -31,7 +78,7 @@ def _run_nms(mode, boxes, scores, num_classes, max_boxes, score_thresh, iou_thre
     if wsb == 0:
         raise ValueError("nms: non-positive dimension (n=%d, boxes=%d, classes=%d, max_boxes=%d)" %
                          (n, B, C, max_boxes))
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ws = _workspace(dev, wsb)
     ob = torch.empty((n, cap, 4), dtype=torch.float32, device=dev)
     osc = torch.empty((n, cap), dtype=torch.float32, device=dev)
     ol = torch.empty((n, cap), dtype=torch.int32, device=dev)
@@ -65,11 +112,18 @@ def gpu_nms(boxes, scores, num_classes, max_boxes=50, score_thresh=0.5, nms_thre
 
 
 def gpu_nms_batched(boxes, scores, num_classes, max_boxes=50, score_thresh=0.5, nms_thresh=0.5,
-                    return_index=False):
-    """Extension: the same op over a batch [N,B,4]/[N,B,C] in one launch set; returns per-image lists."""
+                    return_index=False, lazy=False):
+    """Extension: the same op over a batch [N,B,4]/[N,B,C] in one launch set; returns per-image lists.
+    lazy=True: a LazyDetections (same indexing / iteration; the host waits for the counts on first access only)."""
     b = fw.as_device_f32(boxes)
     s = fw.as_device_f32(scores)
     ob, osc, ol, oi, cnt = _run_nms(_lib.Y3_NMS_TF, b, s, num_classes, max_boxes, score_thresh, nms_thresh)
+    if lazy:
+        cnt_h = torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True)
+        cnt_h.copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(b.device))
+        return LazyDetections((ob, osc, ol, oi), cnt_h, ev, b.device, return_index)
     cnt_h = cnt.cpu().tolist()
     fw.check_context(b.device)      # the stream is idle here: surface a device-side failure of the forward, if any
     out = []
