@@ -704,8 +704,15 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
     s13 = np.array([wino and bool(engine.wino_eligible(k, s, ci, co)) for (k, s, ci, co, _) in table])
     wgw = s13 & np.array([ci % 64 == 0 and co % 64 == 0 for (_, _, ci, co, _) in table])
     visited = np.arange(len(table)) >= (52 if args.head_only else 0)
-    issued = (per_layer * np.where(s13, 16.0 / 36.0, 1.0)).sum() \
-        + (per_layer * visited * np.where(s13, 16.0 / 36.0, 1.0)).sum() \
+    # forward and data gradient of the layers y3_conv_wino44_preferred names run F(4x4,3x3): 36/144 (useful work; padding tiles
+    # not counted); the data gradient is the conv with the channel axes swapped
+    grids = layer_input_grids(table, SIZE)
+    f_fwd = np.array([(36.0 / 144.0 if (bn and engine.wino44_preferred(BATCH, g, g, k, s, ci, co)) else 16.0 / 36.0) if w_ else 1.0
+                      for (k, s, ci, co, bn), g, w_ in zip(table, grids, s13)])
+    f_dg = np.array([(36.0 / 144.0 if engine.wino44_preferred(BATCH, g, g, k, s, co, ci) else 16.0 / 36.0) if w_ else 1.0
+                     for (k, s, ci, co, bn), g, w_ in zip(table, grids, s13)])
+    issued = (per_layer * f_fwd).sum() \
+        + (per_layer * visited * f_dg).sum() \
         + (per_layer * visited * np.where(wgw, 16.0 / 36.0, 1.0)).sum()
     issued_tflops = float(issued) / (ms * 1e-3) / 1e12
     grad_bytes = int(trainer.flat.numel() * 4)
@@ -715,8 +722,9 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "per_rank_ms_per_step": rank_ms,
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "precision": ("fp32 MFMA arithmetic; Winograd F(2x2,3x3) forms of the forward, the data gradient and the weight "
-                      "gradient of the stride-1 3x3 convs, direct kernels elsewhere" if args.precision == 'f32_wino'
+        "precision": ("fp32 MFMA arithmetic; Winograd forms of the stride-1 3x3 convs - F(4x4,3x3) for the forward and the data "
+                      "gradient where the launch fills the chip (Cin >= 64), F(2x2,3x3) elsewhere and for the weight "
+                      "gradient -, direct kernels for the other layers" if args.precision == 'f32_wino'
                       else PRECISION_TEXT[args.precision]),
         "data": "synthetic",
         "config": {"workload": "configs[3]: train step, synthetic COCO-80 batches, 416x416 bs=%d per GPU, SGD, %s, "

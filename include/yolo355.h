@@ -147,8 +147,8 @@ size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d);   /* stream-K scratc
 int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino, const float* scale,
                        const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
 /* The same conv in its Winograd F(4x4,3x3) form (36 multiplies per 4x4 output tile and channel pair: 1.78x less
- * matrix-pipe work again; inference only: no statistics output).  With a workspace, block counts that do not fill the last
- * round of the 256 resident workgroups run a persistent schedule: whole rounds of blocks first, the remaining blocks cut
+ * matrix-pipe work again).  A workgroup owns 16 tiles x 64 channels, two workgroups per CU.  With a workspace, block counts
+ * that do not fill the last round of the 512 resident workgroups may run a persistent schedule: whole rounds of blocks first, the remaining blocks cut
  * along K and finished inside the kernel (same hand-off protocol and failure reporting as y3_conv2d_fwd_wino).  y3_conv_wino44_eligible accepts
  * (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cout %% 64 == 0).  w_wino44 = G g G^T with the 6x3 G of the
  * interpolation points 0, +-1, +-2, inf, packed [18 position pairs][cin/8][cout][4 channel pairs][2 positions][2 channels]
@@ -162,6 +162,18 @@ int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int c
 size_t y3_conv_wino44_workspace_bytes(const y3_conv_desc* d);   /* scratch of the persistent schedule; workspace = NULL is allowed */
 int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44, const float* scale,
                          const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
+/* Training uses of the F(4x4,3x3) kernel (train.py:105-115; round 4):
+ *   y3_conv2d_fwd_wino44_stats: the conv plus the column sums of y and y^2 per 16-tile block - stats
+ *     [y3_conv_stats_blocks(d, 2)][2][cout] floats, for y3_bn_train_stats_partials (same contract as
+ *     y3_conv2d_fwd_wino_stats: no residual; one workgroup per block, no workspace);
+ *   y3_pack_conv_weights_wino44_dgrad + y3_conv2d_dgrad_wino44: the data gradient of a stride-1 3x3 conv as the same kernel
+ *     on dz with the flipped, channel-swapped kernel (same arguments as y3_conv2d_dgrad_wino; w_wino44_d = 36 * dz_stride *
+ *     cin floats; needs dz_stride %% 32 == 0 and cin %% 64 == 0). */
+int y3_conv2d_fwd_wino44_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44, const float* scale,
+                               const float* shift, float* y, float* stats);
+int y3_pack_conv_weights_wino44_dgrad(y3_ctx* ctx, const float* w_d, int cin, int dz_stride, float* w_wino44_d);
+int y3_conv2d_dgrad_wino44(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride, const float* w_wino44_d,
+                           const float* ones, const float* zeros, int accumulate, float* dx);
 
 /* ---- fp32 on the bf16 matrix pipe ----------------------------------------------------------------------------
  * Same contract and tensors as y3_conv2d_fwd (fp32 NHWC in, fp32 out, same epilogue, same workspace rule); every
@@ -273,8 +285,8 @@ int y3_bn_train_stats(y3_ctx* ctx, const float* z, long long rows, int c, const 
  * epilogue where the tile is in registers (the training forward calls them with scale = 1, shift = 0, act = 0, so y = z);
  * y3_bn_train_stats_partials then finishes exactly like y3_bn_train_stats (fixed-order fp64 combination: deterministic).
  * y3_conv_stats_blocks returns 0 for convs without this support (the Cin = 3 stem, Cout %% 4 != 0, fused upsample
- * inputs; wino != 0: convs y3_conv_wino_eligible rejects).  Same arguments as y3_conv2d_fwd / y3_conv2d_fwd_wino
- * otherwise (no x_up, no residual). */
+ * inputs; wino = 1: convs y3_conv_wino_eligible rejects; wino = 2: the F(4x4,3x3) kernel, convs y3_conv_wino44_eligible
+ * rejects).  Same arguments as y3_conv2d_fwd / y3_conv2d_fwd_wino otherwise (no x_up, no residual). */
 int y3_conv_stats_blocks(const y3_conv_desc* d, int wino);
 int y3_conv2d_fwd_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w, const float* scale,
                         const float* shift, float* y, float* stats, void* workspace, size_t workspace_bytes);

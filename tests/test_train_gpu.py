@@ -157,6 +157,31 @@ def test_winograd_weight_gradient_matches_autograd(n, h, w, cin, cout):
                                             ctypes.c_size_t(sc.numel())))
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 13, 13, 64, 128), (4, 52, 52, 128, 256), (1, 20, 28, 256, 96)])
+def test_winograd_f4x4_data_gradient_matches_autograd(n, h, w, cin, cout):
+    """y3_conv2d_dgrad_wino44: the data gradient of a stride-1 3x3 SAME conv (ref: TF autodiff of slim.conv2d, train.py:112)
+    as the F(4x4,3x3) kernel on dz with the flipped, channel-swapped kernel, against fp64 autograd (2e-4 of the gradient's
+    max magnitude, the tolerance of the other data-gradient kernels), plain and accumulating into an existing gradient."""
+    from yolov3_tensorflow_amd import engine, framework as fw
+    dev = fw.default_device()
+    rng = np.random.RandomState(n + h + cin + cout)
+    x = rng.standard_normal((n, h, w, cin))
+    wt = rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))
+    dz = rng.standard_normal((n, h, w, cout))
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), torch.tensor(wt).permute(3, 2, 0, 1), padding=1)
+    y.backward(torch.tensor(dz).permute(0, 3, 1, 2))
+    want = xt.grad.numpy()
+    got = engine.conv2d_dgrad_wino44(torch.tensor(dz, dtype=torch.float32, device=dev),
+                                     torch.tensor(wt, dtype=torch.float32, device=dev), cin)
+    scale = np.abs(want).max()
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-4 * scale
+    base = torch.tensor(rng.standard_normal((n, h, w, cin)), dtype=torch.float32, device=dev)
+    acc = engine.conv2d_dgrad_wino44(torch.tensor(dz, dtype=torch.float32, device=dev),
+                                     torch.tensor(wt, dtype=torch.float32, device=dev), cin, accumulate_into=base.clone())
+    assert np.abs(acc.cpu().numpy() - (want + base.cpu().numpy())).max() <= 2e-4 * scale + 1e-6
+
+
 @pytest.mark.parametrize('n,h,w,k,stride,cin,cout,wino', [
     (3, 20, 28, 1, 1, 128, 64, 0),      # 128x64 tiles
     (3, 20, 28, 1, 1, 256, 128, 0),     # 64x64 tiles (1x1, Cout > 64)
@@ -166,6 +191,8 @@ def test_winograd_weight_gradient_matches_autograd(n, h, w, cin, cout):
     (3, 13, 13, 3, 1, 64, 128, 1),      # Winograd, odd map (outputs that do not exist must not be counted)
     (16, 52, 52, 3, 1, 128, 256, 1),    # Winograd on the stream-K schedule
     (2, 26, 26, 3, 1, 64, 64, 0),       # direct 3x3 stride 1
+    (3, 13, 13, 3, 1, 64, 128, 2),      # F(4x4,3x3), odd map: 4x4 tiles hang over the edge (not counted), ragged last block
+    (8, 52, 52, 3, 1, 128, 256, 2),     # F(4x4,3x3), several blocks per image
 ])
 def test_conv_epilogue_statistics_equal_the_separate_pass(n, h, w, k, stride, cin, cout, wino):
     """Training forward (ref: model.py:35-41 with is_training=True): the conv writes per-row-block column sums of its
@@ -184,7 +211,10 @@ def test_conv_epilogue_statistics_equal_the_separate_pass(n, h, w, k, stride, ci
     d = _lib.ConvDesc(n, h, w, cin, 0, cout, k, stride, 0)
     nblk = L.y3_conv_stats_blocks(ctypes.byref(d), wino)
     assert nblk > 0
-    if wino:
+    if wino == 2:
+        wp = engine.pack_wino44(wt)
+        conv = lambda stats: engine.conv2d_fwd_wino44(x, wp, ones, zeros, cout, False, use_workspace=False, stats=stats)
+    elif wino:
         wp = engine.pack_wino(wt)
         conv = lambda stats: engine.conv2d_fwd_wino(x, wp, ones, zeros, cout, False, stats=stats)
     else:

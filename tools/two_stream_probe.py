@@ -15,9 +15,12 @@ def main():
     import yolov3_tensorflow_amd as y3
     import bench
     nsplit = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    dtype = sys.argv[2] if len(sys.argv) > 2 else 'f32_wino'
+    size = int(sys.argv[3]) if len(sys.argv) > 3 else 416
+    bs = int(sys.argv[4]) if len(sys.argv) > 4 else 32
     model = y3.yolov3(80, bench.ANCHORS)
-    model.compute_dtype = 'f32_wino'
-    x = torch.rand((32, 416, 416, 3), device='cuda')
+    model.compute_dtype = dtype
+    x = torch.rand((bs, size, size, 3), device='cuda')
     streams = [torch.cuda.Stream() for _ in range(nsplit)]
     parts = list(x.chunk(nsplit))
     with y3.variable_scope('yolov3'):
@@ -50,8 +53,8 @@ def main():
                 model.forward(parts[0])
             torch.cuda.synchronize()
             half = (time.perf_counter() - t0) / 20 * 1e3
-    print('one stream bs=32: %.3f ms   %d streams bs=%d each: %.3f ms per 32 images   (one part alone: %.3f ms)'
-          % (one, nsplit, 32 // nsplit, two, half))
+    print('%s %d: one stream bs=%d: %.3f ms   %d streams bs=%d each: %.3f ms per batch   (one part alone: %.3f ms)'
+          % (dtype, size, bs, one, nsplit, bs // nsplit, two, half))
 
 
 if __name__ == '__main__':

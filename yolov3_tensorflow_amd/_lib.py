@@ -61,6 +61,9 @@ PROTOTYPES = {
     "y3_conv_wino44_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv2d_fwd_wino44": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t]),
+    "y3_conv2d_fwd_wino44_stats": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_pack_conv_weights_wino44_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "y3_conv2d_dgrad_wino44": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "y3_conv2d_fwd_wino": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t]),
     "y3_pack_conv_weights_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

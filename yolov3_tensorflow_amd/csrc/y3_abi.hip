@@ -212,6 +212,40 @@ extern "C" int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const fl
     return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, residual, y, workspace, workspace_bytes, &o);
 }
 
+extern "C" int y3_conv2d_fwd_wino44_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44,
+                                          const float* scale, const float* shift, float* y, float* stats) {
+    Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_wino44_stats");
+    Y3_CHECK_ARG(stats && d && y3_conv_stats_blocks_impl(d, 2) > 0,
+                 "y3_conv2d_fwd_wino44_stats: null stats, or a conv the F(4x4,3x3) kernel does not take");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    o.stats = stats;
+    return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, nullptr, y, nullptr, 0, &o);
+}
+
+extern "C" int y3_pack_conv_weights_wino44_dgrad(y3_ctx* ctx, const float* w_d, int cin, int dz_stride, float* w_wino44_d) {
+    Y3_CHECK_ARG(ctx && w_d && w_wino44_d, "y3_pack_conv_weights_wino44_dgrad: null argument");
+    Y3_CHECK_ARG(cin > 0 && dz_stride > 0 && dz_stride % 8 == 0,
+                 "y3_pack_conv_weights_wino44_dgrad: dz_stride must be a positive multiple of 8");
+    return y3_launch_pack_wino44(ctx->stream, w_d, dz_stride, cin, w_wino44_d, 1);
+}
+
+extern "C" int y3_conv2d_dgrad_wino44(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
+                                      const float* w_wino44_d, const float* ones, const float* zeros, int accumulate,
+                                      float* dx) {
+    Y3_CHECK_CTX(ctx, "y3_conv2d_dgrad_wino44");
+    Y3_CHECK_ARG(fwd && dz && w_wino44_d && ones && zeros && dx, "y3_conv2d_dgrad_wino44: null pointer argument");
+    Y3_CHECK_ARG(fwd->k == 3 && fwd->stride == 1 && fwd->c_up == 0 && dz_stride >= fwd->cout,
+                 "y3_conv2d_dgrad_wino44: needs a 3x3 stride-1 conv and dz_stride >= Cout");
+    y3_conv_desc g = *fwd;
+    g.cin = dz_stride; g.cout = fwd->cin; g.act = 0;
+    Y3_CHECK_ARG(y3_conv_wino44_eligible_impl(&g), "y3_conv2d_dgrad_wino44: needs dz_stride %% 32 == 0 and Cin %% 64 == 0");
+    y3_sk_opts o;
+    o.err = ctx->err_host;
+    // accumulate: dx is read as the residual and written by the same thread for the same element (no cross-thread hazard)
+    return y3_launch_conv_wino44(ctx->stream, &g, dz, w_wino44_d, ones, zeros, accumulate ? dx : nullptr, dx, nullptr, 0, &o);
+}
+
 // Data gradient of a stride-1 3x3 conv in its Winograd form: dx (+)= conv_same(dz, flipped / channel-swapped kernel) is
 // itself a stride-1 3x3 SAME conv [n,h,w,dz_stride] -> [n,h,w,cin], so the forward Winograd kernel runs it unchanged.
 static int wino_dgrad_desc(const y3_conv_desc* fwd, int dz_stride, y3_conv_desc* g) {

@@ -447,6 +447,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
 // Row blocks of the `stats` output (= output rows / the BM the dispatch above picks); the Winograd kernel: 64-tile blocks.
 int y3_conv_stats_blocks_impl(const y3_conv_desc* d, int wino) {
     if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cout % 4 != 0 || d->cin == 3 || d->c_up > 0) return 0;
+    if (wino == 2) return y3_conv_wino44_stats_blocks_impl(d);
     if (wino) {
         if (!y3_conv_wino_eligible_impl(d)) return 0;
         const long long T = (long long)d->n * ((d->h + 1) / 2) * ((d->w + 1) / 2);

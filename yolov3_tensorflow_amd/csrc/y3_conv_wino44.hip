@@ -54,6 +54,8 @@ struct W44Args {
     unsigned spin_limit; // polls per awaited flag before giving up
     int workers;         // grid size of the persistent schedule (0 = one workgroup per block)
     int fault;           // test hook: producers skip raising their flag
+    float* stats;        // STATS instantiation: [tile blocks][2][Cout] column sums of y and y^2 per 16-tile block (one workgroup
+                         // per block schedule only), the training forward's batch-norm statistics (y3_bn_train_stats_partials)
 };
 
 #ifndef W44_BT
@@ -148,6 +150,7 @@ __device__ unsigned long long* g_w44_probe = nullptr;
 #define W44_STAMP(i) do { } while (0)
 #endif
 
+template <bool STATS>
 __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(const W44Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // V: [2][36][BT][32 B], then raw patches: the same shape
     constexpr int RAW_OFF = 2 * STAGE;
@@ -475,6 +478,7 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
                 sc = *reinterpret_cast<const f32x4*>(p.scale + co);
                 sh = *reinterpret_cast<const f32x4*>(p.shift + co);
             }
+            f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int rowi = it * 16 + (gt >> 4);            // (tile, pixel) row of this half: 256 rows
@@ -495,6 +499,27 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
                     const size_t o = (size_t)(pix + py * p.W + pxx) * p.Cout + co;
                     if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
                     *reinterpret_cast<f32x4*>(p.y + o) = v;
+                    if (STATS) { st1 += v; st2 += v * v; }
+                }
+            }
+            if (STATS) {
+                // column sums of this block's outputs: the 16 threads that share a channel quad (one per pixel slot, it = tile)
+                // add up through the LDS in a fixed order -> deterministic
+                __syncthreads();
+                float* red = reinterpret_cast<float*>(smem);      // [wm][16 pixel slots][2][64]
+                *reinterpret_cast<f32x4*>(red + ((wm * 16 + (gt >> 4)) * 2 + 0) * BNC + c4) = st1;
+                *reinterpret_cast<f32x4*>(red + ((wm * 16 + (gt >> 4)) * 2 + 1) * BNC + c4) = st2;
+                __syncthreads();
+                if (tid < 16 && co < p.Cout) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < (BT / 16) * 16; ++k) {
+                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BNC + c4);
+                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BNC + c4);
+                    }
+                    float* st = p.stats + (size_t)bt * 2 * p.Cout;
+                    *reinterpret_cast<f32x4*>(st + co) = a;
+                    *reinterpret_cast<f32x4*>(st + p.Cout + co) = b;
                 }
             }
         }
@@ -505,8 +530,10 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
 }
 
 // U = G g G^T for every (ci, co), G the 6x3 matrix of F(4x4,3x3); out[pos/2][ci/8][co][(ci%8)/2][pos%2][ci%2]
+// dgrad != 0: w is the FORWARD kernel as [9][cout][cin] (its HWIO layout, the forward's input channels = this conv's cout):
+// the data gradient's kernel g'[a][b][ci][co] = w[2-a][2-b][co][ci] (flipped taps, channel axes swapped)
 __global__ void __launch_bounds__(256) pack_weights_wino44_kernel(const float* __restrict__ w_hwio, float* __restrict__ out,
-                                                                  int cin, int cout) {
+                                                                  int cin, int cout, int dgrad) {
     const long long total = (long long)cin * cout;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int cil = (int)(e % KC);
@@ -518,7 +545,9 @@ __global__ void __launch_bounds__(256) pack_weights_wino44_kernel(const float* _
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
+            for (int b = 0; b < 3; ++b)
+                g[a][b] = dgrad ? w_hwio[((size_t)((2 - a) * 3 + (2 - b)) * cout + co) * cin + ci]
+                                : w_hwio[((size_t)(a * 3 + b) * cin + ci) * cout + co];
         // rows of G: [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]
         float t[6][3];
 #pragma unroll
@@ -590,10 +619,17 @@ int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
     return blocks >= 192 * (32 / BT);
 }
 
-int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out) {
+// rows of the `stats` output of the STATS instantiation: one per 16-tile block
+int y3_conv_wino44_stats_blocks_impl(const y3_conv_desc* d) {
+    if (!y3_conv_wino44_eligible_impl(d)) return 0;
+    const long long tiles = (long long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4);
+    return (int)((tiles + BT - 1) / BT);
+}
+
+int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out, int dgrad) {
     const long long total = (long long)cin * cout;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_weights_wino44_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout);
+    hipLaunchKernelGGL(pack_weights_wino44_kernel, dim3(blocks), dim3(256), 0, stream, w_hwio, out, cin, cout, dgrad);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }
@@ -620,11 +656,12 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
     a.TH = (d->h + 3) / 4; a.TW = (d->w + 3) / 4; a.T = d->n * a.TH * a.TW;
     a.partial = nullptr; a.flags = nullptr; a.err = nullptr; a.spin_limit = 0; a.workers = 0; a.fault = 0;
-    static bool attr_set = false;      // benign race (idempotent)
-    if (!attr_set) {
-        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino44_f32_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE));
-        attr_set = true;
+    a.stats = sk ? sk->stats : nullptr;
+    auto kern = a.stats ? conv_wino44_f32_kernel<true> : conv_wino44_f32_kernel<false>;
+    static bool attr_set[2] = {false, false};      // benign race (idempotent)
+    if (!attr_set[a.stats ? 1 : 0]) {
+        Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE));
+        attr_set[a.stats ? 1 : 0] = true;
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = d->cout / BNC;
     const int blocks = nbt * nbn, ksteps = d->cin / KC;
@@ -640,7 +677,8 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
 #ifdef W44_SK_KEEP
     const bool use_sk = force != 0 && has_ws && (long long)blocks * ksteps >= 4LL * W44_WORKERS && blocks % W44_WORKERS != 0;
 #else
-    const bool use_sk = force != 0 && has_ws && blocks > W44_WORKERS && rem != 0 && (long long)rem * ksteps >= 2LL * W44_WORKERS;
+    const bool use_sk = force != 0 && has_ws && blocks > W44_WORKERS && rem != 0 && (long long)rem * ksteps >= 2LL * W44_WORKERS &&
+                        !a.stats;       // (the statistics epilogue runs on whole blocks only)
 #endif
     if (use_sk) {
         a.partial = static_cast<float*>(workspace);
@@ -653,9 +691,9 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
             a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + W44_FLAGS_OFFSET);
             Y3_CHECK_HIP(hipMemsetAsync(a.flags, 0, (size_t)W44_WORKERS * sizeof(unsigned), stream));
         }
-        hipLaunchKernelGGL(conv_wino44_f32_kernel, dim3(W44_WORKERS), dim3(NTH), 4 * STAGE, stream, a);
+        hipLaunchKernelGGL(kern, dim3(W44_WORKERS), dim3(NTH), 4 * STAGE, stream, a);
     } else {
-        hipLaunchKernelGGL(conv_wino44_f32_kernel, dim3(blocks), dim3(NTH), 4 * STAGE, stream, a);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(NTH), 4 * STAGE, stream, a);
     }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;

@@ -201,14 +201,20 @@ int forward_impl(y3_net* net, const y3_train_var* vars, const float* x, int n, i
         const int cout = l.cout, ho = d.h / l.stride, wo = d.w / l.stride;
         const long long rows = (long long)n * ho * wo;
         const bool wino = wino_layer(net, d);
+        // the F(4x4,3x3) kernel where it fills the chip (y3_conv_wino44_preferred: the layers with Cin >= 64 at the bench sizes)
+        const bool wino44 = wino && l.bn && y3_conv_wino44_preferred(&d) == 1;
         const int planes = split_planes(net, l);
-        const int nblk = (l.bn && !planes) ? y3_conv_stats_blocks(&d, wino ? 1 : 0) : 0;
+        const int nblk = (l.bn && !planes) ? y3_conv_stats_blocks(&d, wino44 ? 2 : wino ? 1 : 0) : 0;
         Buf part = nblk ? A.alloc((size_t)nblk * 2 * cout * 4) : Buf();
         // the kernel in this step's packing (the variable changes every step)
         const size_t kelems = (size_t)l.k * l.k * l.cin * cout;
         Buf wp;
         const void* wdev = v.weights;                       // Cin = 3 stem: HWIO as it is
-        if (wino) {
+        if (wino44) {
+            wp = A.alloc((size_t)36 * l.cin * cout * 4);
+            Y3_TRY(y3_pack_conv_weights_wino44(ctx, v.weights, l.cin, cout, A.p(wp)));
+            wdev = A.p(wp);
+        } else if (wino) {
             wp = A.alloc((size_t)16 * l.cin * cout * 4);
             Y3_TRY(y3_pack_conv_weights_wino(ctx, v.weights, l.cin, cout, A.p(wp)));
             wdev = A.p(wp);
@@ -226,7 +232,9 @@ int forward_impl(y3_net* net, const y3_train_var* vars, const float* x, int n, i
         if (l.bn) {
             S.z[i] = A.alloc((size_t)rows * cout * 4);
             float* z = A.p(S.z[i]);
-            if (wino)
+            if (wino44)
+                Y3_TRY(y3_conv2d_fwd_wino44_stats(ctx, &d, xin, static_cast<const float*>(wdev), ones, zeros, z, A.p(part)));
+            else if (wino)
                 Y3_TRY(y3_conv2d_fwd_wino_stats(ctx, &d, xin, static_cast<const float*>(wdev), ones, zeros, z, A.p(part), skp, skb));
             else if (planes)
                 Y3_TRY(y3_conv2d_fwd_split(ctx, &d, planes, xin, nullptr, wdev, ones, zeros, nullptr, z, skp, skb));
@@ -399,8 +407,12 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
             y3_conv_desc g = d;
             g.cin = dz_stride; g.cout = cin; g.k = 3; g.stride = 1;
             const bool wino_d = net->dtype == 4 && up < 0 && l.k == 3 && l.stride == 1 && y3_conv_wino_eligible(&g) == 1;
+            const bool wino44_d = wino_d && y3_conv_wino44_preferred(&g) == 1;
             Buf wk;
-            if (wino_d) {
+            if (wino44_d) {
+                wk = A.alloc((size_t)36 * cin * dz_stride * 4);
+                Y3_TRY(y3_pack_conv_weights_wino44_dgrad(ctx, w_d, cin, dz_stride, A.p(wk)));
+            } else if (wino_d) {
                 wk = A.alloc((size_t)16 * cin * dz_stride * 4);
                 Y3_TRY(y3_pack_conv_weights_wino_dgrad(ctx, w_d, cin, dz_stride, A.p(wk)));
             } else if (planes) {
@@ -408,7 +420,9 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
                 Y3_TRY(y3_pack_conv_weights_split_dgrad(ctx, w_d, l.k, cin, dz_stride, planes, A.p(wk)));
             }
             auto dgrad = [&](int accumulate, float* dx) -> int {
-                if (wino_d)
+                if (wino44_d)
+                    Y3_TRY(y3_conv2d_dgrad_wino44(ctx, &d, dz, dz_stride, A.p(wk), ones, zeros, accumulate, dx));
+                else if (wino_d)
                     Y3_TRY(y3_conv2d_dgrad_wino(ctx, &d, dz, dz_stride, A.p(wk), ones, zeros, accumulate, dx, skp, skb));
                 else if (planes)
                     Y3_TRY(y3_conv2d_dgrad_split(ctx, &d, planes, dz, dz_stride, A.p(wk), ones, zeros, accumulate, dx, skp, skb));

@@ -227,13 +227,19 @@ def pack_wino44(w_hwio):
     return out
 
 
-def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None, use_workspace=True):
-    """3x3 stride-1 conv in its Winograd F(4x4,3x3) form (y3_conv2d_fwd_wino44, inference); w_wino44 from pack_wino44.
-    use_workspace=False forces the one-workgroup-per-block schedule."""
+def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None, use_workspace=True, stats=None):
+    """3x3 stride-1 conv in its Winograd F(4x4,3x3) form (y3_conv2d_fwd_wino44); w_wino44 from pack_wino44.
+    use_workspace=False forces the one-workgroup-per-block schedule.  stats: a [y3_conv_stats_blocks(d, 2), 2, cout] tensor
+    -> the training form y3_conv2d_fwd_wino44_stats (column sums of y and y^2 per 16-tile block; no residual)."""
     n, h, w, cin = x.shape
     d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 1 if act else 0)
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     L = _lib.lib()
+    if stats is not None:
+        assert residual is None
+        _lib.check(L.y3_conv2d_fwd_wino44_stats(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44),
+                                                fw.ptr(scale), fw.ptr(shift), fw.ptr(y), fw.ptr(stats)))
+        return y
     ws, ws_bytes = None, 0
     if use_workspace:
         ws_bytes = L.y3_conv_wino44_workspace_bytes(ctypes.byref(d))
@@ -241,6 +247,21 @@ def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None, use_w
     _lib.check(L.y3_conv2d_fwd_wino44(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44), fw.ptr(scale),
                                       fw.ptr(shift), fw.ptr(residual), fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y
+
+
+def conv2d_dgrad_wino44(dz, w_hwio, cin, accumulate_into=None):
+    """Data gradient of a stride-1 3x3 conv in F(4x4,3x3) form (y3_pack_conv_weights_wino44_dgrad + y3_conv2d_dgrad_wino44):
+    dz [n,h,w,cout] (cout % 32 == 0), w_hwio the forward kernel [3,3,cin,cout] (cin % 64 == 0) -> dx [n,h,w,cin]."""
+    n, h, w, cout = dz.shape
+    L, ctx = _lib.lib(), fw.context(dz.device)
+    d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 0)
+    wk = torch.empty(36 * cin * cout, dtype=torch.float32, device=dz.device)
+    _lib.check(L.y3_pack_conv_weights_wino44_dgrad(ctx, fw.ptr(w_hwio), cin, cout, fw.ptr(wk)))
+    ones, zeros = torch.ones(cin, device=dz.device), torch.zeros(cin, device=dz.device)
+    dx = accumulate_into if accumulate_into is not None else torch.empty((n, h, w, cin), dtype=torch.float32, device=dz.device)
+    _lib.check(L.y3_conv2d_dgrad_wino44(ctx, ctypes.byref(d), fw.ptr(dz), cout, fw.ptr(wk), fw.ptr(ones), fw.ptr(zeros),
+                                        1 if accumulate_into is not None else 0, fw.ptr(dx)))
+    return dx
 
 
 def upsample_nearest(x, out_h, out_w):
