@@ -173,16 +173,29 @@ def traffic_from_profile(names):
     return None, stale
 
 
+def cpu_quota_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one (the GPU boxes show 256 logical CPUs and
+    cpu.max = 16 cores), else the logical CPU count."""
+    ncpu = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            return max(1, min(ncpu, int(round(int(quota) / float(period))))), ncpu
+    except (OSError, ValueError):
+        pass
+    return ncpu, ncpu
+
+
 def cpu_baseline(model_vars, budget_s=12.0):
     """Time the oracle's torch-CPU fp32 forward (checker code, never the product) on ONE bounded sample: batches of 2
-    images on 16 threads for about `budget_s` seconds.  That is the oracle's best operating point on the 256-core hosts
-    of the GPU boxes (measured in round 2: 16-21 images/s; a bs=32 batch runs at 3.2 images/s on 64 threads and 0.26 on
-    256 - oneDNN does not scale on this graph - so those samples only burned ~130 s of the driver's budget)."""
+    images on min(16, CPU quota) threads for about `budget_s` seconds.  The GPU boxes show 256 logical CPUs but their cgroup
+    grants 16 cores (cpu.max = 1600000 100000, found in round 4): that is why 16 threads measured best in round 2 (16-21
+    images/s) and 64 / 256 threads only oversubscribed (3.2 / 0.26 images/s)."""
     import torch
     from oracle import yolo_ref
     params = {v.op_name: v.numpy() for v in model_vars}
-    ncpu = os.cpu_count() or 1
-    threads = min(ncpu, 16)
+    quota, ncpu = cpu_quota_cores()
+    threads = min(quota, 16)
     x = np.random.RandomState(123).rand(2, SIZE, SIZE, 3).astype(np.float32)
     torch.set_num_threads(threads)
     yolo_ref.forward(params, x[:1])                     # warm-up (thread pool, oneDNN primitives)
@@ -194,8 +207,9 @@ def cpu_baseline(model_vars, budget_s=12.0):
     for _ in range(reps):
         yolo_ref.forward(params, x)
     dt = time.time() - t0
-    return {"value": round(2 * reps / dt, 3), "unit": "images/s", "cores": int(threads), "cores_note": "%d of the host's %d cores (the oracle's best operating point: oneDNN does not "
-            "scale on this graph, bs=32 on 64 threads runs at 3.2 images/s)" % (threads, ncpu), "kind": "port",
+    return {"value": round(2 * reps / dt, 3), "unit": "images/s", "cores": int(threads), "cores_note": "%d threads; the process may use %d cores (cgroup cpu.max) of the host's %d logical "
+            "CPUs - more threads than the quota only oversubscribe (bs=32 on 64 threads measured 3.2 images/s)"
+            % (threads, quota, ncpu), "kind": "port",
             "sample": "oracle.yolo_ref.forward (torch-CPU fp32 restatement of the reference graph; TF-CPU itself is "
                       "not installable here), %dx%d, same weights; %d batches of 2 images on %d threads of the %d-core "
                       "host (%.1f s)" % (SIZE, SIZE, reps, threads, ncpu, dt)}

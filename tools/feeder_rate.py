@@ -57,15 +57,19 @@ def _one_feeder(rank, nfeed, lines, args, backend, workers, barrier, out):
             from yolov3_tensorflow_amd.utils.data_utils import collate
             pool, plan = f._executor(), f._plan(0)
 
+            free = []           # batch buffers are recycled, as the feeder's pinned buffers are (no page faults per batch)
+
             def submit(entry):
                 b, size, mine = entry
-                slots = np.empty((len(mine), size[1], size[0], 3), np.float32)
+                shape = (len(mine), size[1], size[0], 3)
+                slots = free.pop() if free and free[-1].shape == shape else np.empty(shape, np.float32)
                 return slots, [pool.submit(fd._worker_sample, f._job(0, b, j, line, size), slots[j]) for j, line in enumerate(mine)]
 
             def finish(item):
                 slots, futs = item
                 samples = [x.result() for x in futs]
                 collate([(s_[0], slots[j] if s_[1] is None else s_[1], s_[2], s_[3]) for j, s_ in enumerate(samples)], out_images=slots)
+                free.append(slots)
             pending = [submit(e) for e in plan[:5]]
             nxt = 5
             for _ in range(3):
