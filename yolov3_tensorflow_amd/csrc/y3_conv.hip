@@ -67,12 +67,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         item = skw.begin;
         item_end = skw.end;
     } else {
-        // workgroup b runs on XCD b%8 (observed): give each XCD a contiguous eighth of the tile ids
+        // workgroup b runs on XCD b%8 (observed): give each XCD a contiguous eighth of the tile ids, and each of the XCD's
+        // workgroups a contiguous, balanced run of WHOLE tiles of it - one tile when the grid has a workgroup per tile; with
+        // fewer workgroups than tiles (the resident-grid launch of the 1x1 convs, launch_data_parallel) a workgroup walks
+        // its tiles, the next tile's first loads issued under the current tile's epilogue
         const int nt = gridDim.x;
-        const int q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int tile_id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-        item = (long long)tile_id * S;
-        item_end = item + S;
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int wx = (nt >> 3) + ((nt & 7) > x ? 1 : 0);                     // workgroups of this launch on XCD x
+        const int t0x = (int)sk_begin32(ntiles, 8, x), t1x = (int)sk_begin32(ntiles, 8, x + 1);
+        const int tb = t0x + (int)sk_begin32(t1x - t0x, wx, k), te = t0x + (int)sk_begin32(t1x - t0x, wx, k + 1);
+        item = (long long)tb * S;
+        item_end = (long long)te * S;
     }
     if (item >= item_end) return;
 
@@ -297,7 +302,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             advance();                   // prepare K-step t+2 (scalar branch on a tap change)
             __syncthreads();
         }
-        if (STREAMK && seg_end < item_end) {
+        if (seg_end < item_end) {
             set_loader(seg_end);         // prefetch across the tile boundary; stored after the epilogue
             issue_loads();
             advance();
@@ -314,10 +319,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             if (STREAMK && seg_end < tile_end) sk_consume<BM, BN, WGM, WGN>(p, skw, ntiles, S, tile_end, acc);
             epilogue<BM, BN, WGM, WGN, TMODE, STATS>(p, smem, acc, m0, n0);
         }
-        if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
+        if (STREAMK || seg_end < item_end) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
     }
 }
+
+constexpr int RESIDENT_64 = 1024;      // 64x64-tile workgroups resident at once: four per CU (37 KB of LDS, 72 VGPRs)
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = false, bool STATS = false>
 int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
@@ -330,7 +337,15 @@ int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     }
     const int nbm = (a.M + BM - 1) / BM;
     const int nbn = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(256), G::LDS_BYTES, stream, a);
+    int grid = nbm * nbn;
+    // 64x64 tiles (the 1x1 convs), more tiles than the 1,024 resident workgroups but only a few rounds of them: a RESIDENT
+    // grid whose workgroups walk balanced runs of whole tiles.  The hardware dispatcher hands the tiles of a partly filled
+    // last round to the first slots that come free - four per CU on a quarter of the CUs while the rest idle (measured on
+    // the F(4x4) kernel: 1.5 rounds cost 2, tools/wino44_quant.py); a resident grid spreads them one or two per CU, and
+    // a workgroup fetches its next tile under the current one's store tail.
+    if (BM == 64 && BN == 64 && grid > RESIDENT_64 && grid < 8 * RESIDENT_64 && y3_exp_env("Y3_CONV_RESIDENT_OFF") == nullptr)
+        grid = RESIDENT_64;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;
 }

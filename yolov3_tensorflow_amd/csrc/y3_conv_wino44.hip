@@ -479,6 +479,26 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
                 sh = *reinterpret_cast<const f32x4*>(p.shift + co);
             }
             f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+            // all sixteen residual loads of the thread in flight at once (inside the store loop each one is a dependent
+            // load behind a branch: sixteen memory latencies in a row)
+            f32x4 rv[16];
+            if (p.resid) {
+                const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(p.resid), 0, (unsigned)((size_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int rowi = it * 16 + (gt >> 4);
+                    const int tl = rowi >> 4, px = rowi & 15;
+                    const int pix = tinfo[2 * (wm * 16 + tl)], vv = tinfo[2 * (wm * 16 + tl) + 1];
+                    const int py = px >> 2, pxx = px & 3;
+                    const bool ok = py < (vv & 0xff) && pxx < (vv >> 8) && co < p.Cout;
+                    rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                 rs_res, ok ? (unsigned)(((pix + py * p.W + pxx) * p.Cout + co) * 4) : OOB, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int rowi = it * 16 + (gt >> 4);            // (tile, pixel) row of this half: 256 rows
@@ -497,7 +517,7 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                     }
                     const size_t o = (size_t)(pix + py * p.W + pxx) * p.Cout + co;
-                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    v += rv[it];
                     *reinterpret_cast<f32x4*>(p.y + o) = v;
                     if (STATS) { st1 += v; st2 += v * v; }
                 }
