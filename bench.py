@@ -897,8 +897,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                                                 'f32_bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
     bound_ms = np.maximum(nbytes / (PEAK_HBM_TBPS * 1e12), issued / (peak * 1e12)) * 1e3      # per layer
     traffic, traffic_src = (None, None) if split else traffic_from_profile(
-        ['r03_pmc_traffic_bf16.json'] if bf16 else
-        ['r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
+        ['r04_pmc_traffic_bf16.json', 'r03_pmc_traffic_bf16.json'] if bf16 else
+        ['r04_pmc_traffic_wino.json', 'r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
     kernel = ("conv_bf16x_kernel / conv_bf16p_kernel (3x3 implicit-GEMM convs with Cout > 64 on LDS-DMA staged 128x128 / "
               "256x128 / 256x256 tiles, bf16 storage; see DESIGN.md)" if bf16 else
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "

@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
             if (pk) W44_STAMP(17);
 #endif
             const unsigned char* vs = smem + cur * STAGE + a_off;
-            constexpr int AD = 4;                                  // activation fragments read ahead (two pairs)
+#ifndef W44_AD
+#define W44_AD 4
+#endif
+            constexpr int AD = W44_AD;                             // activation fragments read ahead (two pairs)
             f32x2 aq[AD];
 #pragma unroll
             for (int s = 0; s < AD; ++s) aq[s] = *reinterpret_cast<const f32x2*>(vs + s * PLANE);
