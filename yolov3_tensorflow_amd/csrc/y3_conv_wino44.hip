@@ -617,11 +617,15 @@ int y3_conv_wino44_eligible_impl(const y3_conv_desc* d) {
 // (y3_net_set_layer_alt): where it measured faster inside the bs=32 416x416 forward (tools/layer_profile.py,
 // profiles/r04_wino44.txt; ms per layer, F(2x2) | F(4x4) with 16-tile blocks, two workgroups per CU):
 //   64->128 @104: 0.280 | 0.260     128->256 @52: 0.244 | 0.186     256->512 @26: 0.222 | 0.205     512->1024 @13: 0.240 | 0.198
-//   32->64 @208: 0.361 | 0.372 - four K-steps per block, the block prologue and store tail dominate: stays on F(2x2).
-//   candidate (shape only: what a caller packs for): every eligible conv with Cin >= 64;
+//   32->64 @208: 0.361 | 0.372 - four K-steps per block, the block prologue and store tail dominate: stays on F(2x2) at bs=32.
+// Smaller batches (ms per layer at bs = 4 / 8 / 16, F(2x2) stream-K | F(4x4); blocks = 16-tile x 64-channel workgroups):
+//   32->64 0.070 | 0.055 (676 blocks), 0.108 | 0.084 (1,352), 0.188 | 0.160 (2,704);  64->128 0.058 | 0.043 (338), 0.089 | 0.071, 0.161 | 0.117;
+//   128->256 0.047 | 0.047 (172), 0.082 | 0.064 (340), 0.134 | 0.104;  256->512 0.076 | 0.078 (104), 0.079 | 0.080 (200), 0.126 | 0.104 (392);
+//   512->1024 - | 0.137 (64), 0.137 | 0.137 (128), 0.143 | 0.139 (256)       (profiles/r04_wino44.txt)
+//   candidate (shape only: what a caller packs for): every eligible conv;
 //   preferred (this launch): a candidate whose blocks - 16 tiles x 64 channels, one workgroup each, no K-split - fill at
-//     least three quarters of the 512 workgroup slots.  Below that the F(2x2) kernel's stream-K schedule wins by keeping
-//     every CU busy: a bs=4 forward measured 3.74 ms with it against 4.77 ms with this kernel on 32-88 blocks per layer.
+//     least half of the 512 workgroup slots (below that the F(2x2) kernel's stream-K schedule keeps every CU busy and ties
+//     or wins); the four-K-step Cin = 32 shape only up to 4,096 blocks.
 // (experiments build only) Y3_WINO44=0 turns the kernel off, =2 takes every eligible conv whatever its size (A/B runs).
 static int wino44_mode() {
     static const int mode = y3_exp_env("Y3_WINO44") ? atoi(y3_exp_env("Y3_WINO44")) : 1;
@@ -630,8 +634,7 @@ static int wino44_mode() {
 
 int y3_conv_wino44_candidate_impl(const y3_conv_desc* d) {
     if (wino44_mode() == 0 || !y3_conv_wino44_eligible_impl(d)) return 0;
-    if (wino44_mode() == 2) return 1;
-    return d->cin >= 64;
+    return 1;
 }
 
 int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
@@ -639,7 +642,7 @@ int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
     if (wino44_mode() == 2) return 1;
     const long long tiles = (long long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4);
     const long long blocks = ((tiles + BT - 1) / BT) * (d->cout / BNC);
-    return blocks >= 192 * (32 / BT);
+    return blocks >= 128 * (32 / BT) && (d->cin >= 64 || blocks <= 4096);
 }
 
 // rows of the `stats` output of the STATS instantiation: one per 16-tile block
