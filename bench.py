@@ -22,6 +22,11 @@ Workloads
   feeder: the host side of c4 alone - one feeder per rank (10 worker threads, prefetch 5: the reference's defaults) decoding
      synthetic JPEGs, augmenting, resizing to 416x416 and uploading bs=64 batches that nothing consumes (run_feeder).
 Prints ONE JSON line on rank 0.
+Inference workloads (c2, c5, detect) run the batch as --streams equal parts on that many HIP streams of the GPU (default 2:
+model.inference_streams; BASELINE north star "independent per-GPU streams for inference") - except the forwards that carry
+per-layer hipEvents (every 8th step of the timed region), which run on one stream: `roofline` is computed from those, i.e.
+from undisturbed whole-batch launches.  `--streams 1` is the one-stream command (what the rocprof kernel statistics under
+profiles/ are taken with, so that their per-launch averages are comparable with `roofline.avg_launch_ms`).
 
 roofline (c2): the forward is bound by the fp32 matrix pipe.  The dominant kernel family is the two
 Winograd kernels of the stride-1 3x3 convs (32 launches, ~60 % of the step): conv_wino44_f32_kernel (F(4x4,3x3): the
@@ -357,6 +362,9 @@ def parse_args(argv):
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=2,
+                    help="HIP streams per GPU for the inference workloads (c2, c5, detect): the batch runs as that many equal "
+                         "parts, one per stream (model.inference_streams; forwards with per-layer events on stay on one stream)")
     ap.add_argument('--no-secondary', action='store_true',
                     help="c2 only: skip the secondary objects (fast_path / direct_path, detect, c5, c4, feeder) measured after the "
                          "timed region of `value`")
@@ -548,6 +556,7 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
     worst case of the greedy per-class NMS)."""
     from yolov3_tensorflow_amd import framework as fw
     model = y3.yolov3(CLASS_NUM, ANCHORS)
+    model.inference_streams = max(1, int(getattr(args, 'streams', 1)))
     model.compute_dtype = args.precision
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda',
                    generator=torch.Generator(device='cuda').manual_seed(100 + rank))
@@ -612,7 +621,7 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
             "config": {"workload": "configs[2]-shaped: the c2 forward + y3_decode + y3_nms (TF semantics), random "
                                    "weights, 416x416 bs=%d; `value` = detector-like scores with test_single_image.py's "
                                    "parameters (200 / 0.3 / 0.45); all four (regime, parameter set) pairs in `regimes`"
-                                   % BATCH},
+                                   % BATCH, "streams_per_gpu": model.inference_streams},
             "roofline": {"bound": "mfma+hbm", "unit": "ms",
                          "peak": round(fwd_bound + post_bound, 4), "achieved": head["ms_per_batch"],
                          "frac": round((fwd_bound + post_bound) / head["ms_per_batch"], 4),
@@ -803,6 +812,7 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
     from yolov3_tensorflow_amd import engine, framework as fw
     bf16 = args.workload == 'c5'
     model = y3.yolov3(CLASS_NUM, ANCHORS)
+    model.inference_streams = max(1, int(getattr(args, 'streams', 1)))
     model.compute_dtype = 'bf16' if bf16 else args.precision
     split = (not bf16) and args.precision in ('f32_bf16x6', 'f32_bf16x3')
     wino = (not bf16) and args.precision == 'f32_wino'
@@ -932,7 +942,15 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                                 "configs[1]: Darknet-53 + 3-scale head forward, random weights, "
                                 "416x416 bs=32 fp32 per GPU, input resident in HBM"),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE,
-                   "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)"},
+                   "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)",
+                   "streams_per_gpu": model.inference_streams,
+                   "streams_note": ("the batch runs as %d equal parts on %d HIP streams of the GPU (north star: independent per-GPU "
+                                    "streams for inference; one part's kernel tails and partly filled rounds of workgroups are "
+                                    "filled by the other's kernels: A/B in one process 11.00 -> 10.65 ms for c2, 4.16 -> 3.86 ms for "
+                                    "c5, tools/streams_ab.py); the forwards that carry per-layer hipEvents (every 8th step of "
+                                    "the timed region: the `roofline` figures) run on ONE stream, so kernel durations are those "
+                                    "of undisturbed launches of the whole batch" % (model.inference_streams, model.inference_streams))
+                                   if model.inference_streams > 1 else "one stream"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 2),
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_src,

@@ -106,6 +106,36 @@ def test_forward_is_deterministic_and_batch_independent(gpu_model):
         assert torch.allclose(p[2], s[0], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f32_wino'])
+def test_forward_on_two_streams_equals_one_stream(gpu_model, with_dtype, dtype):
+    """model.inference_streams = 2 (BASELINE north star: "independent per-GPU streams for inference"): the batch as two
+    halves on two HIP streams, each through its own net / context / workspace, writing slices of the same outputs.  Same
+    kernels on the same images: equal to the one-stream forward to fp32 rounding (stream-K split points and the kernel
+    choice depend on the batch size), run-to-run bit-exact, no cross-stream hazard over repeated calls, and a forward
+    with layer profiling on stays on one stream."""
+    import yolov3_tensorflow_amd as y3
+    model, _ = gpu_model
+    with_dtype(dtype)
+    x = torch.from_numpy(blob_images(9, 8, 256)).cuda()
+    try:
+        with y3.variable_scope('yolov3'):
+            one = [t.clone() for t in model.forward(x, False)]
+            model.inference_streams = 2
+            runs = [[t.clone() for t in model.forward(x, False)] for _ in range(3)]
+            torch.cuda.synchronize()
+            assert len(model._side_streams) == 1
+            model.set_layer_profiling(True)
+            prof = [t.clone() for t in model.forward(x, False)]
+            model.set_layer_profiling(False)
+            model.read_layer_ms()
+        for a, b, c, p, o in zip(runs[0], runs[1], runs[2], prof, one):
+            assert torch.equal(a, b) and torch.equal(a, c)
+            assert torch.allclose(a, o, rtol=1e-4, atol=1e-4)
+            assert torch.equal(p, o)                      # profiled forward = the one-stream path
+    finally:
+        model.inference_streams = 1
+
+
 def test_bad_input_raises(gpu_model):
     import yolov3_tensorflow_amd as y3
     model, _ = gpu_model

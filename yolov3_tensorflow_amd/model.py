@@ -36,6 +36,8 @@ class yolov3(object):
         self.weight_decay = weight_decay
         self.use_static_shape = use_static_shape
         self._nets = {}   # (ctx key, scope, dtype) -> dict(handle, version, keepalive, workspace)
+        self._side_streams = {}   # (device index, parts) -> side streams of _forward_on_streams
+        self.inference_streams = 1    # > 1: inference forwards split the batch over that many HIP streams (opt-in)
         self.img_size = None
         # 'f32' (the reference's precision), 'f32_bf16x6' / 'f32_bf16x3' (fp32 tensors, products on the bf16
         # matrix pipe, see NET_DTYPES) or 'bf16' (bf16 storage, fp32 accumulation; BASELINE configs[4]);
@@ -130,6 +132,18 @@ class yolov3(object):
         if is_training:
             from . import training
             return training.forward_train(self, x)
+        det = 3 * (5 + self.class_num)
+        fms = [torch.empty((n, h // s, w // s, det), dtype=torch.float32, device=x.device) for s in (32, 16, 8)]
+        ns = int(getattr(self, 'inference_streams', 1) or 1)
+        if ns > 1 and n % ns == 0 and n // ns >= 4 and not getattr(self, '_profiling_on', False):
+            self._forward_on_streams(x, fms, ns)
+        else:
+            self._forward_chunk(x, fms)
+        return fms[0], fms[1], fms[2]
+
+    def _forward_chunk(self, x, fms):
+        """One y3_net_forward on torch's CURRENT stream (the net, its context and its workspace belong to that stream)."""
+        n, h, w, _ = x.shape
         ent = self._get_net(x.device)
         L = _lib.lib()
         need = L.y3_net_workspace_bytes(ent['handle'], n, h, w)
@@ -138,12 +152,33 @@ class yolov3(object):
         if ent['ws'] is None or ent['ws_bytes'] < need:
             ent['ws'] = torch.empty(need, dtype=torch.uint8, device=x.device)
             ent['ws_bytes'] = need
-        det = 3 * (5 + self.class_num)
-        fms = [torch.empty((n, h // s, w // s, det), dtype=torch.float32, device=x.device) for s in (32, 16, 8)]
         _lib.check(L.y3_net_forward(ent['handle'], fw.ptr(x), n, h, w, fw.ptr(ent['ws']),
                                     ctypes.c_size_t(ent['ws_bytes']), fw.ptr(fms[0]), fw.ptr(fms[1]),
                                     fw.ptr(fms[2])))
-        return fms[0], fms[1], fms[2]
+
+    def _forward_on_streams(self, x, fms, ns):
+        """Inference shards by image (eval-mode BN): the batch as `ns` equal parts, part 0 on the caller's stream, the others
+        on side streams of this model, every part through its own net / context / workspace, all writing into slices of the
+        same output tensors.  One part's kernel tails, partly filled last rounds of blocks and launch gaps are filled by
+        the other's kernels (BASELINE north star: "independent per-GPU streams for inference"; measured in
+        profiles/r04_wino44.txt 8).  Opt-in: model.inference_streams = 2; forwards with layer profiling on stay on one
+        stream, so per-layer event times are those of undisturbed kernels."""
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        pool = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns - 1)])
+        c = x.shape[0] // ns
+        self._get_net(dev)                  # (parameters are prepared / packed on the caller's stream, once for all parts)
+        for side in pool:
+            side.wait_stream(main)          # the input and the packed parameters are ready - taken BEFORE part 0 is enqueued,
+                                            # or the side streams would wait for part 0's kernels too
+        self._forward_chunk(x[:c], [f[:c] for f in fms])
+        for i, side in enumerate(pool, start=1):
+            with torch.cuda.stream(side):
+                self._forward_chunk(x[i * c:(i + 1) * c], [f[i * c:(i + 1) * c] for f in fms])
+            for t in [x] + fms:
+                t.record_stream(side)
+        for side in pool:
+            main.wait_stream(side)
 
     def forward_composed(self, inputs):
         """The same graph built op by op exactly as reference model.py:50-78 composes it (unfused
@@ -178,6 +213,7 @@ class yolov3(object):
         """Turn per-layer hipEvent recording on/off for the fused plan on the current stream."""
         ent = self._get_net(device if device is not None else fw.default_device())
         _lib.check(_lib.lib().y3_net_set_profiling(ent['handle'], 1 if enabled else 0))
+        self._profiling_on = bool(enabled)      # (profiled forwards run on ONE stream: see _forward_on_streams)
 
     def read_layer_ms(self, device=None):
         """Per-layer ms averaged over the forwards recorded since the last read (synchronises), plus the
