@@ -231,6 +231,10 @@ def main(argv=None):
     best_mAP = -np.inf
     history = {'loss': [], 'recall': [], 'mAP': [], 'global_step_start': int(trainer.global_step)}
     from yolov3_tensorflow_amd.feeder import Feeder
+    if not args.augment and (args.multi_scale_train or args.use_mix_up) and rank == 0:
+        # ('val' mode has neither multi-scale sizes nor mix-up - say so instead of dropping them silently)
+        print("train.py: --augment false feeds the network in 'val' mode: --multi_scale_train and --use_mix_up are OFF for this run",
+              file=sys.stderr)
     feeder = Feeder(train_lines, args.batch_size, args.class_num, args.img_size, args.anchors,
                     mode='train' if args.augment else 'val', shuffle=True,
                     multi_scale=args.multi_scale_train, use_mix_up=args.use_mix_up, letterbox_resize=args.letterbox_resize,
