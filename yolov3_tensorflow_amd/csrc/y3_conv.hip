@@ -295,18 +295,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         store_tile(0);
         __syncthreads();
         for (int t = 0; t + 1 < nsteps; ++t) {
-#ifndef Y3C_KO_LOADS
             issue_loads();               // K-step t+1
-#endif
-#ifndef Y3C_KO_MFMA
             compute_tile(t & 1);
-#endif
-#ifndef Y3C_KO_LDSW
             store_tile((t + 1) & 1);
-#endif
-#if !defined(Y3C_KO_LOADS) && !defined(Y3C_KO_MFMA) && !defined(Y3C_KO_LDSW)
             pipeline_hint();
-#endif
             advance();                   // prepare K-step t+2 (scalar branch on a tap change)
             __syncthreads();
         }
