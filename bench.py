@@ -48,6 +48,11 @@ the CPU oracle in fp32 and fp64 (BASELINE metric: "box delta vs ref"), with the 
 detect / c5 / c4 / feeder: the other BASELINE configurations, and the host side of c4, as secondary objects of the c2 line
 (measured after everything above).
 """
+import os as _os
+# Two HIP streams per GPU only overlap when they sit on different hardware queues; with the runtime's default of 4 queues and
+# RCCL initialised in the process the side stream of the inference workloads was seen to alias (12.1 ms against 10.4): ask for
+# 8 before HIP starts (a no-op if the caller already set it), and let choose_inference_streams() measure anyway.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import argparse
 import json
 import os
@@ -565,6 +570,8 @@ def run_detect(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
     with y3.variable_scope('yolov3'):
         model.forward(torch.zeros((1, 64, 64, 3), device='cuda'))
         random_init(seed=1)
+        if model.inference_streams > 1:
+            model.choose_inference_streams(x, candidates=(1, model.inference_streams))
         heads = [v for v in y3.global_variables(scope='yolov3/yolov3_head') if v.op_name.endswith('/biases')]
         for regime in ('detector', 'dense'):
             saved = [v.tensor.clone() for v in heads]
@@ -831,6 +838,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                 wino = False
                 args.precision = 'f32'
                 model.compute_dtype = 'f32'
+        if model.inference_streams > 1:      # keep two streams only where they measure faster on THIS box / process
+            model.choose_inference_streams(x, candidates=(1, model.inference_streams))
         for i in range(args.warmup):
             # (two warm-up steps run with layer profiling on, so that the event objects the timed region records into
             # already exist: creating them inside the timed region stalled the host for milliseconds on a cold box)
@@ -946,8 +955,9 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                    "streams_per_gpu": model.inference_streams,
                    "streams_note": ("the batch runs as %d equal parts on %d HIP streams of the GPU (north star: independent per-GPU "
                                     "streams for inference; one part's kernel tails and partly filled rounds of workgroups are "
-                                    "filled by the other's kernels: A/B in one process 11.00 -> 10.65 ms for c2, 4.16 -> 3.86 ms for "
-                                    "c5, tools/streams_ab.py); the forwards that carry per-layer hipEvents (every 8th step of "
+                                    "filled by the other's kernels: A/B in one process 10.87 -> 10.33 ms for c2, 4.07 -> 3.77 ms for "
+                                    "c5, tools/streams_ab.py; kept only because choose_inference_streams() measured it faster "
+                                    "than one stream in THIS process before the warm-up); the forwards that carry per-layer hipEvents (every 8th step of "
                                     "the timed region: the `roofline` figures) run on ONE stream, so kernel durations are those "
                                     "of undisturbed launches of the whole batch" % (model.inference_streams, model.inference_streams))
                                    if model.inference_streams > 1 else "one stream"},

@@ -22,9 +22,10 @@ def main():
         with y3.variable_scope('yolov3'):
             model.forward(torch.zeros((1, 64, 64, 3), device='cuda'))
             bench.random_init(1)
-            res = {1: [], 2: []}
+            counts = [int(v) for v in os.environ.get('Y3_STREAMS_AB', '1,2').split(',')]
+            res = {c: [] for c in counts}
             for rep in range(4):
-                for ns in (1, 2):
+                for ns in counts:
                     model.inference_streams = ns
                     for _ in range(3):
                         model.forward(x)
@@ -34,8 +35,7 @@ def main():
                         model.forward(x)
                     torch.cuda.synchronize()
                     res[ns].append((time.perf_counter() - t0) / 20 * 1e3)
-        print('%s %dx%d bs=%d: one stream %s ms; two streams %s ms' % (dtype, size, size, bs,
-              ' '.join('%.3f' % v for v in res[1]), ' '.join('%.3f' % v for v in res[2])), flush=True)
+        print('%s %dx%d bs=%d: %s' % (dtype, size, size, bs, '; '.join('%d stream(s) %s ms' % (c, ' '.join('%.3f' % v for v in res[c])) for c in counts)), flush=True)
 
 
 if __name__ == '__main__':

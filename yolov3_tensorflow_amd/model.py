@@ -141,6 +141,29 @@ class yolov3(object):
             self._forward_chunk(x, fms)
         return fms[0], fms[1], fms[2]
 
+    def choose_inference_streams(self, inputs, candidates=(1, 2), iters=3):
+        """Measure the inference forward of `inputs` with each stream count (a few synchronised forwards each) and keep the
+        fastest in self.inference_streams.  Whether two streams overlap depends on how the HIP runtime maps streams to its
+        hardware queues (GPU_MAX_HW_QUEUES, 4 by default): with RCCL initialised in the process the same code measured 12.1 ms
+        on two streams against 10.9 on one, and 10.4 with 2 or 8 hardware queues (profiles/r04_streams_ab.txt) - so a caller
+        that cannot set the variable before HIP starts asks the hardware."""
+        import time
+        x = fw.as_device_f32(inputs)
+        best, best_t = 1, None
+        for ns in candidates:
+            self.inference_streams = ns
+            self.forward(x, False)
+            torch.cuda.synchronize(x.device)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                self.forward(x, False)
+            torch.cuda.synchronize(x.device)
+            t = time.perf_counter() - t0
+            if best_t is None or t < best_t:
+                best, best_t = ns, t
+        self.inference_streams = best
+        return best
+
     def _forward_chunk(self, x, fms):
         """One y3_net_forward on torch's CURRENT stream (the net, its context and its workspace belong to that stream)."""
         n, h, w, _ = x.shape
