@@ -124,3 +124,25 @@ def test_process_backed_feeder_fills_shared_pinned_buffers_and_equals_the_thread
     for (ids_t, img_t, y_t), (ids_p, img_p, y_p) in zip(first['thread'], first['process']):
         assert ids_t == ids_p and torch.equal(img_t, img_p) and all(torch.equal(a, b) for a, b in zip(y_t, y_p))
     assert not glob.glob('/dev/shm/y3feed_%d_*' % os.getpid())
+
+
+def test_closing_an_epoch_early_releases_the_producer_at_once(tmp_path):
+    """with the queue full (the feeder runs ahead of its consumer) an early `close()` of the epoch left the
+    producer thread in a blocking `q.put` for good - a 5 s stall per close, and the prefetched device batches and pinned
+    buffers stayed alive.  Now every hand-over gives up once the consumer has stopped, the queue is drained and the
+    thread is gone when `close()` returns."""
+    import threading
+    from yolov3_tensorflow_amd.feeder import Feeder
+    lines = _write_set(tmp_path, 48)
+    for backend in ('thread', 'process'):
+        f = Feeder(lines, 4, 80, [224, 224], COCO_ANCHORS, mode='train', use_mix_up=True, num_threads=4, prefetch=4, seed=2,
+                   backend=backend)
+        it = f.epoch(0)
+        next(it)
+        time.sleep(1.0)                       # the producer fills the queue and blocks on the next hand-over
+        t0 = time.perf_counter()
+        it.close()
+        dt = time.perf_counter() - t0
+        f.close()
+        assert dt < 2.5, '%s backend: closing the epoch took %.1f s' % (backend, dt)
+        assert not [t for t in threading.enumerate() if t.name == 'y3-feeder' and t.is_alive()], backend

@@ -201,3 +201,20 @@ def test_inference_after_head_only_training_uses_the_updated_moving_statistics(i
     for g, r, b in zip(after, ref, before):
         _cmp(g.cpu().numpy(), r, 'inference after head-only training step')
         assert float((g - b).abs().max()) > 1e-4
+
+
+def test_choose_inference_streams_keeps_a_measured_candidate(gpu_model):
+    """yolov3.choose_inference_streams: times the forward with each candidate stream count and leaves the fastest in
+    model.inference_streams (how bench.py guards the two-stream mode against a runtime that maps both streams to one
+    hardware queue)."""
+    import yolov3_tensorflow_amd as y3
+    model, _ = gpu_model
+    x = torch.from_numpy(blob_images(3, 8, 128)).cuda()
+    try:
+        with y3.variable_scope('yolov3'):
+            best = model.choose_inference_streams(x, candidates=(1, 2), iters=2)
+            assert best in (1, 2) and model.inference_streams == best
+            out = model.forward(x, False)
+        assert all(torch.isfinite(t).all().item() for t in out)
+    finally:
+        model.inference_streams = 1
