@@ -223,7 +223,11 @@ int y3_decode(y3_ctx* ctx, const float* fm1, const float* fm2, const float* fm3,
  * Outputs per image i, concatenated by class ascending, selection order within a class:
  *   out_boxes [n][cap][4], out_scores [n][cap], out_labels [n][cap] (int32),
  *   out_index [n][cap] (int32 box index into the B inputs; NULL to skip), out_counts [n] (int32),
- *   with cap = class_num * max_boxes.  All device pointers; counts are read by the caller. */
+ *   with cap = class_num * max_boxes.  All device pointers; counts are read by the caller (nothing in the call waits for
+ *   the host: copy them back asynchronously and read them when the batch is consumed).  The scratch may be reused by the next
+ *   call on the same stream.  Classes with up to 16,384 candidates are selected from keys sorted in the LDS, in chunks, with an
+ *   early exit at max_boxes; beyond that, and for max_boxes above ~1,600 (the selected boxes of a class live in the LDS too), an
+ *   arg-max form on global memory takes over - same selections either way. */
 #define Y3_NMS_TF 0
 #define Y3_NMS_PY 1
 size_t y3_nms_workspace_bytes(int n, int num_boxes, int class_num, int max_boxes);

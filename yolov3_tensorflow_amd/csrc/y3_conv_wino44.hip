@@ -1,7 +1,8 @@
-// Winograd F(4x4, 3x3) form of the stride-1 3x3 conv (+ folded BN + LeakyReLU + residual) for INFERENCE, fp32
-// arithmetic (products and sums in fp32; the transforms round, see the numerics line below) on v_mfma_f32_16x16x4_f32.  Replaces the same reference code as y3_conv.hip / y3_conv_wino.hip
-// (utils/layer_utils.py:9-22,25-32): 36 multiplies per 4x4 output tile and channel pair instead of 144 (direct) or 64
-// (F(2x2,3x3)) - 1.78x less MFMA work than y3_conv_wino.hip.
+// Winograd F(4x4, 3x3) form of the stride-1 3x3 conv (+ folded BN + LeakyReLU + residual; training: + batch-norm column
+// sums, and the data gradient as the same conv on dz), fp32 arithmetic (products and sums in fp32; the transforms round, see
+// the numerics line below) on v_mfma_f32_16x16x4_f32.  Replaces the same reference code as y3_conv.hip / y3_conv_wino.hip
+// (utils/layer_utils.py:9-22,25-32; train.py:105-115 for the training uses): 36 multiplies per 4x4 output tile and channel
+// pair instead of 144 (direct) or 64 (F(2x2,3x3)) - 1.78x less MFMA work than y3_conv_wino.hip.
 //
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 4x4 output tile (6x6 input patch), summed over input channels,
 //   interpolation points 0, +-1, +-2, inf (Lavin & Gray).  Numerics on THIS network (tests/probes/winograd_numerics.py, fp32
@@ -10,10 +11,11 @@
 //
 //   * weights U = G g G^T transformed once at load time and packed [18 position pairs][Cin/8][Cout][4 channel pairs][2 positions]
 //     [2 channels] (y3_pack_conv_weights_wino44): a lane's fragments of two neighbouring positions are 16 contiguous bytes;
-//   * a workgroup = eight waves owns 32 tiles x 64 output channels for ALL 36 transform positions; wave (wm, wn) holds
-//     16 tiles x 16 channels of every position as v_mfma_f32_16x16x4_f32 accumulators (36 x 4 = 144 registers, two waves
-//     per SIMD), so the 36 position sums of one (tile, channel) sit in ONE lane and A^T M A needs no exchange between
-//     waves at all;
+//   * a workgroup = FOUR waves owns 16 tiles x 64 output channels for ALL 36 transform positions (BT = 16: 72 KB of LDS, 256
+//     registers per wave -> TWO workgroups per CU, one's prologue / transform / store tail under the other's MFMAs: round 4,
+//     -9 ... -24 % per layer shape against the 32-tile, eight-wave block of round 3); wave wn holds 16 tiles x 16 channels
+//     of every position as v_mfma_f32_16x16x4_f32 accumulators (36 x 4 = 144 registers), so the 36 position sums of one
+//     (tile, channel) sit in ONE lane and A^T M A needs no exchange between waves at all;
 //   * K-step = 8 input channels = 72 MFMAs per wave, ONE barrier.  Raw 6x6 patches go global -> LDS by DMA
 //     (buffer_load ... lds: no registers, padding = out-of-range lanes = zeros), two K-steps ahead; inside a K-step thread
 //     (tile, channel pair, job) reads the patch rows its job needs from the LDS, transforms them on float2s and writes one
@@ -22,14 +24,21 @@
 //     a lane's 16 bytes for two positions, 1 KB contiguous per wave load - straight from global memory through a rolling
 //     window of six loads (twelve positions) that runs on across K-step boundaries.  The order is pinned with scheduling
 //     barriers: left alone, hipcc moves every fragment read right in front of its MFMAs;
+//   * V = B^T d B planes are [channel pair][tile][2 channels] with the tile index rotated by 4 per channel pair (v_off):
+//     hipcc emits the fragment reads as ds_read2st64_b64, served in 16-lane groups over 32 banks - as [tile][8 channels] rows
+//     they hit every bank four times (SQ_LDS_BANK_CONFLICT 3.8e7 per launch in round 3, 1.0e6 now);
 //   * lane quarter q = lane / 16 reads channels 2q, 2q+1 of both operands (one ds_read_b64 / one 8-byte load) and MFMA
 //     m = 0, 1 consumes channel 2q + m - which of the 8 channels plays "k" where is free as long as both operands agree;
 //   * tail: A^T M A per accumulator register in registers (120 adds / multiplies by 2, 4, 8 per 4x4 tile), staged through
 //     the LDS ([tile][pixel][64 channels]) so that scale / shift, LeakyReLU and the residual run on 16-byte pieces and an
-//     output pixel's 64 channels leave as 256 contiguous bytes;
+//     output pixel's 64 channels leave as 256 contiguous bytes; the sixteen residual loads of a thread are issued together
+//     ahead of the store loop; STATS instantiation: column sums of y and y^2 per block for the training forward's batch norm;
 //   * with a workspace: persistent schedule (whole rounds of blocks, the remaining blocks cut along K and finished inside
-//     the kernel, same hand-off as y3_conv_wino.hip).  y3_net_forward does not use it (profiles/r03_wino44.txt has the
-//     measurements, and those of every variant tried on the way).
+//     the kernel, same hand-off as y3_conv_wino.hip).  y3_net_forward does not use it (profiles/r03_wino44.txt and
+//     profiles/r04_wino44.txt have the measurements, and those of every variant tried on the way).
+//   Build-time switches (-D, tools/build_variant.py; never set in the product): W44_BT=32 (round 3's block), W44_PROBE (s_memtime
+//   stamps for tools/wino44_probe.py), W44_KO_* (knock-outs), W44_MIDPOS / W44_BDEPTH / W44_AD / W44_SK_KEEP / W44_DMA_HALF (variants
+//   measured in profiles/r04_wino44.txt).
 #include <cstdlib>
 #include "y3_internal.h"
 
