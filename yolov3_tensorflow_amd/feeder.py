@@ -39,6 +39,7 @@ from __future__ import division, print_function
 import queue
 import random
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -403,9 +404,10 @@ class Feeder(object):
                 yield out
         finally:
             stop.set()
-            while th.is_alive():              # drain what is queued so that nothing the producer holds outlives the epoch
-                try:
-                    q.get_nowait()
+            deadline = time.monotonic() + 30.0
+            while th.is_alive() and time.monotonic() < deadline:      # drain what is queued so that nothing the producer
+                try:                                                  # holds outlives the epoch (bounded: a worker that
+                    q.get_nowait()                                    # never returns must not hang the caller's close())
                 except queue.Empty:
                     th.join(timeout=0.05)
             while True:
