@@ -1,9 +1,9 @@
-"""The Winograd code paths that sit behind environment switches of the EXPERIMENTS build of the library
-(csrc/libyolo355_exp.so; the product library reads no environment variable; read once per process, so each runs
-in its own interpreter): the four-wave kernel (Y3_WINO8=0, the round-1/2 kernel, still shipped) and the hybrid
-stream-K schedule (Y3_WINO_SK_HYBRID=1), each against the fp64 reference and the direct kernel through the same
-cases as the default path (tests/test_conv_gpu.py::test_winograd_conv_matches_fp64), plus the statistics epilogue and
-the Winograd data gradient of the train step."""
+"""The conv code paths that sit behind environment switches of the EXPERIMENTS build of the library
+(csrc/libyolo355_exp.so; the product library reads no environment variable; the switches are read once per process, so
+each case runs in its own interpreter): the hybrid stream-K schedule of the F(2x2,3x3) kernel (Y3_WINO_SK_HYBRID=1) and
+the data-parallel schedules forced where the product picks stream-K (Y3_CONV_WINO_STREAMK=0 + Y3_CONV_STREAMK=0), each
+against the fp64 reference through the same cases as the default path (tests/test_conv_gpu.py), plus the statistics
+epilogue and the data / weight gradients of the train step."""
 import os
 import subprocess
 import sys
@@ -16,10 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize('env', [
-    {'Y3_WINO8': '0'},
-    {'Y3_WINO8': '0', 'Y3_WINO_SK_HYBRID': '1'},
-    {'Y3_WINO8': '1', 'Y3_WINO_SK_HYBRID': '1'},
-], ids=['four_wave', 'four_wave_hybrid', 'eight_wave_hybrid'])
+    {'Y3_WINO_SK_HYBRID': '1'},
+    {'Y3_CONV_WINO_STREAMK': '0', 'Y3_CONV_STREAMK': '0'},
+], ids=['wino_hybrid_schedule', 'data_parallel_schedules'])
 def test_switched_winograd_paths(env):
     from yolov3_tensorflow_amd import build
     e = dict(os.environ)
