@@ -222,8 +222,9 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
 
     // ---- epilogue --------------------------------------------------------------------------------------
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-    if ((p.Cout & 3) != 0) {
-        // detection convs: 3*(5+C) channels, fp32 output, rows not 16-byte aligned -> scalar stores
+    if ((p.Cout & 3) != 0 && (!p.out_f32 || p.resid)) {
+        // Cout % 4 != 0 with bf16 output or a residual (no layer of the network): scalar stores.  The detection convs
+        // (3*(5+C) channels, fp32 output) take the staged path below with 4-byte-aligned dwordx4 stores.
         float* yf = static_cast<float*>(p.y);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -251,10 +252,18 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
     const int tc = (tid % C4) * 4, tr = tid / C4;
     const int col = n0 + tc;
     const bool cok = col < p.Cout;
+    const bool full = col + 3 < p.Cout;          // (cok && !full: the column quad that crosses an odd Cout)
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (cok) {
-        sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-        sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+    if (full) {                                  // (one dwordx4 each; no alignment assumed)
+        sc = *reinterpret_cast<const f32x4_u*>(p.scale + col);
+        sh = *reinterpret_cast<const f32x4_u*>(p.shift + col);
+    } else if (cok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (col + q < p.Cout) {
+                sc[q] = p.scale[col + q];
+                sh[q] = p.shift[col + q];
+            }
     }
 #pragma unroll
     for (int half = 0; half < BM / 64; ++half) {
@@ -293,7 +302,13 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
                         v[3] += __uint_as_float(rv[1] & 0xFFFF0000u);
                     }
                     if (p.out_f32) {
-                        *reinterpret_cast<f32x4*>(static_cast<float*>(p.y) + o) = v;
+                        float* yp = static_cast<float*>(p.y) + o;
+                        if (full) *reinterpret_cast<f32x4_u*>(yp) = v;
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (col + q < p.Cout) yp[q] = v[q];
+                        }
                     } else {
                         u32x2 pk;
                         pk[0] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);

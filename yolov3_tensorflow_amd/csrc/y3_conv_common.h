@@ -97,22 +97,33 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
         const int y = rem / p.W, x = rem - y * p.W;
         return ((size_t)(n * 2 * p.H + 2 * y + p.cy)) * (2 * p.W) + 2 * x + p.cx;
     };
-    if ((p.Cout & 3) == 0) {
+    {
+        // Rows of the output are Cout floats: 16-byte aligned only when Cout % 4 == 0.  The detection heads (Cout =
+        // 3*(5+C) = 255) take the same staged path with 4-byte-aligned dwordx4 accesses (f32x4_u; gfx950 global memory
+        // serves them) and a per-element tail for the one column quad that crosses Cout.
         constexpr int C4 = BN / 4;     // float4 columns per tile row
         constexpr int RPP = 256 / C4;  // rows covered per pass
         constexpr int PASSES = BM / RPP;
         const int tc = (tid % C4) * 4, tr = tid / C4;
         const int col = n0 + tc;
         const bool cok = col < p.Cout;
+        const bool full = col + 3 < p.Cout;      // (cok && !full: the quad that crosses Cout, odd Cout only)
         // residual tile first: its HBM/L2 latency overlaps the LDS staging below
         f32x4 res[PASSES];
         if (p.resid) {
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const int row = m0 + tr + i * RPP;
-                res[i] = (cok && row < p.M)
-                             ? *reinterpret_cast<const f32x4*>(p.resid + out_pixel(row) * p.Cout + col)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
+                res[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cok && row < p.M) {
+                    const float* rp = p.resid + out_pixel(row) * p.Cout + col;
+                    if (full) res[i] = *reinterpret_cast<const f32x4_u*>(rp);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (col + q < p.Cout) res[i][q] = rp[q];
+                    }
+                }
             }
         }
         float* cs = smem;
@@ -127,8 +138,18 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
         __syncthreads();
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};      // column sums of y, y^2 over this thread's rows
         if (cok) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (full) {                               // (one dwordx4 each; no alignment assumed)
+                sc = *reinterpret_cast<const f32x4_u*>(p.scale + col);
+                sh = *reinterpret_cast<const f32x4_u*>(p.shift + col);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (col + q < p.Cout) {
+                        sc[q] = p.scale[col + q];
+                        sh[q] = p.shift[col + q];
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const int rr = tr + i * RPP;
@@ -141,7 +162,14 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                     }
                     if (p.resid) v += res[i];
-                    *reinterpret_cast<f32x4*>(p.y + out_pixel(row) * p.Cout + col) = v;
+                    float* yp = p.y + out_pixel(row) * p.Cout + col;
+                    if (full) *reinterpret_cast<f32x4_u*>(yp) = v;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (col + q < p.Cout) yp[q] = v[q];
+                            else v[q] = 0.f;             // (keeps the column sums below clean)
+                    }
                     if (STATS) {
                         s1 += v;
                         s2 += v * v;
@@ -164,34 +192,19 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                     b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BN + tc);
                 }
                 float* st = p.stats + (size_t)(m0 / BM) * 2 * p.Cout;
-                *reinterpret_cast<f32x4*>(st + col) = a;
-                *reinterpret_cast<f32x4*>(st + p.Cout + col) = b;
-            }
-            __syncthreads();                           // (the LDS goes back to the caller)
-        }
-        return;
-    }
-    // Cout not a multiple of 4 (detection heads, 3*(5+C)): rows are not 16-byte aligned -> scalar stores
+                if (full) {
+                    *reinterpret_cast<f32x4_u*>(st + col) = a;
+                    *reinterpret_cast<f32x4_u*>(st + p.Cout + col) = b;
+                } else {
 #pragma unroll
-    for (int ni = 0; ni < G::NI; ++ni) {
-        const int col = n0 + wn * G::WTN + ni * 32 + col_l;
-        const bool cok = col < p.Cout;
-        const float sc = cok ? p.scale[col] : 0.f;
-        const float sh = cok ? p.shift[col] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < G::MI; ++mi) {
-            const int rbase = m0 + wm * G::WTM + mi * 32 + row_l;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (cok && row < p.M) {
-                    float v = acc[mi][ni][r] * sc + sh;
-                    if (p.act) v = v > 0.f ? v : 0.1f * v;
-                    const size_t o = out_pixel(row) * p.Cout + col;
-                    if (p.resid) v += p.resid[o];
-                    p.y[o] = v;
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < p.Cout) {
+                            st[col + q] = a[q];
+                            st[p.Cout + col + q] = b[q];
+                        }
                 }
             }
+            __syncthreads();                           // (the LDS goes back to the caller)
         }
     }
 }

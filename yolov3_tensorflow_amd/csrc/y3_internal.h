@@ -69,6 +69,7 @@ void y3_set_error(const char* fmt, ...);
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));   // a float4 at a 4-byte-aligned address (one dwordx4 access)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Launchers implemented in the .hip files (all asynchronous on `stream`).
