@@ -228,3 +228,39 @@ def test_worker_processes_fill_shared_batch_buffers(tmp_path):
     shared.close()
     assert not os.path.exists(path) and shared.take((1, 2, 2, 3)) is not None       # (usable again after close)
     shared.close()
+
+
+@pytest.mark.parametrize('native', ['1', '0'])
+def test_fix_crop_labels_keeps_each_box_with_its_class(tmp_path, monkeypatch, native):
+    """Default: the reference's pairing (the crop filters boxes, not labels - utils/data_utils.py:150-153): after a crop that
+    dropped an earlier box the survivors carry their predecessors' classes.  Y3_FIX_CROP_LABELS=1 (train.py
+    --fix_crop_labels): the class rides through the chain with its box.  Same draws, same pixels, same boxes either way."""
+    from PIL import Image
+    from yolov3_tensorflow_amd.utils.data_utils import parse_sample, collate
+    monkeypatch.setenv('Y3_FEED_NATIVE', native)
+    path = str(tmp_path / 'two.jpg')
+    Image.fromarray(np.random.RandomState(1).randint(0, 256, (120, 160, 3)).astype(np.uint8)).save(path, quality=90)
+    line = '0 %s 160 120 0 2 2 30 30 2 100 70 150 110' % path        # class 0 top-left, class 2 bottom-right
+
+    def crop_around_second_box(bbox, size, **kw):                    # (stands in for the random window search)
+        x0, y0, x1, y1 = [int(v) for v in bbox[1, :4]]
+        win = (x0 - 4, y0 - 4, x1 - x0 + 8, y1 - y0 + 8)
+        assert win[0] + win[2] <= size[0] and win[1] + win[3] <= size[1]
+        return data_aug.bbox_crop(bbox, win, allow_outside_center=False), win
+
+    monkeypatch.setattr(data_aug, 'random_crop_with_constraints', crop_around_second_box)
+    for seed in range(6):                                            # with and without expansion / flip
+        got = {}
+        for flag in ('0', '1'):
+            monkeypatch.setenv('Y3_FIX_CROP_LABELS', flag)
+            got[flag] = parse_sample(line, [96, 64], 'train', True, rng=np.random.RandomState(seed), prng=random.Random(seed))
+        (_, img0, b0, l0), (_, img1, b1, l1) = got['0'], got['1']
+        np.testing.assert_array_equal(img0, img1)
+        np.testing.assert_array_equal(b0, b1)
+        assert b1.shape == (1, 5) and l1.dtype == np.int64
+        assert list(l0) == [0, 2]                                    # never filtered: collate pairs the survivor with class 0
+        assert list(l1) == [2]
+        assert collate([got['0']])[3][0, 0] == 0 and collate([got['1']])[3][0, 0] == 2
+    monkeypatch.setenv('Y3_FIX_CROP_LABELS', '1')                    # 'val' mode has no crop: nothing to carry
+    _, _, bv, lv = parse_sample(line, [96, 64], 'val', True)
+    assert bv.shape == (2, 5) and list(lv) == [0, 2]

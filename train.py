@@ -89,6 +89,9 @@ def build_parser():
     p.add_argument('--augment', type=_bool, default=True,
                    help="false: feed the training images through the validation preprocessing (plain resize, no "
                         "augmentation, no mix-up) - not a reference option; used by the memorisation test")
+    p.add_argument('--fix_crop_labels', type=_bool, default=False,
+                   help="true: a box keeps its own class when the random crop drops an earlier box of the image (the "
+                        "reference filters the boxes but not their labels, utils/data_utils.py:150-153; false reproduces it)")
     p.add_argument('--multi_scale_train', type=_bool, default=True)
     p.add_argument('--use_label_smooth', type=_bool, default=True)
     p.add_argument('--use_focal_loss', type=_bool, default=True)
@@ -150,6 +153,7 @@ def validate(model, y3, args, lines):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    os.environ['Y3_FIX_CROP_LABELS'] = '1' if args.fix_crop_labels else '0'      # (read by the feeder's workers too)
     import functools
     import torch
     import torch.distributed as dist

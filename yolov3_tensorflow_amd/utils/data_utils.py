@@ -210,12 +210,21 @@ def _read_rgb(pic_path):
     return np.asarray(img if img.mode == 'RGB' else img.convert('RGB'))      # (convert() copies even RGB -> RGB)
 
 
+def fix_crop_labels():
+    """Opt-in departure from the reference (train.py --fix_crop_labels sets Y3_FIX_CROP_LABELS=1; an environment variable
+    so that the feeder's worker processes see it too): the 'train' chain carries every box's class through the
+    constrained crop, so a box keeps ITS label when an earlier box is dropped.  Off (the default) the reference's pairing is
+    reproduced: boxes are filtered, labels are not (utils/data_utils.py:150-153, 105; see collate())."""
+    import os
+    return os.environ.get('Y3_FIX_CROP_LABELS', '0') == '1'
+
+
 def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False, out=None):
     """The image half of the reference's parse_data (utils/data_utils.py:118-172): read (PIL, RGB), mix-up when `line` is
     a pair, the 'train' augmentation chain (colour distortion, expansion, constrained crop, resize with a random
     interpolation, horizontal flip) or the plain 'val' resize.  Returns (img_idx, float32 RGB image in [0,1] of shape
     [img_size[1], img_size[0], 3], boxes [K,5] with the mix-up weight in column 4, labels [>=K]: the crop may drop boxes
-    and, like the reference, does not drop their labels - see collate()).  Target assignment (process_box) is NOT done here: the feeder runs it on the device for the whole batch (process_box_batch).
+    and, like the reference, does not drop their labels - see collate(); fix_crop_labels() is the opt-in correction).  Target assignment (process_box) is NOT done here: the feeder runs it on the device for the whole batch (process_box_batch).
 
     Two executions of the same recipe, bit-identical (tests/test_feed_native.py): every draw and all box arithmetic come
     from utils.data_aug either way; the pixels go through liby3feed.so in one pass (feed_native.enabled(), the default), or
@@ -239,6 +248,16 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
         img, partner = _read_rgb(pic_path1), _read_rgb(pic_path2)
         lam, boxes = data_aug.mix_up_boxes(boxes1, boxes2, rng=rng)
         labels = np.concatenate((labels1, labels2))
+    carry = train and fix_crop_labels()
+    if carry:                                           # the class rides along as a sixth column (every box function of
+        boxes = np.concatenate((boxes, np.asarray(labels, np.float32)[:, None]), axis=-1)     # data_aug keeps columns 4+)
+
+    def split(bx):                                      # -> (boxes [K,5], labels)
+        bx = np.asarray(bx, np.float32)
+        if not carry:
+            return bx, np.asarray(labels, np.int64)
+        return np.ascontiguousarray(bx[:, :5]), bx[:, 5].astype(np.int64)
+
     if not feed_native.enabled():
         if partner is not None:
             img = data_aug.blend(img, partner, lam)
@@ -249,7 +268,7 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
         if out is not None:
             out[...] = image
             image = out
-        return img_idx, image, np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+        return (img_idx, image) + split(boxes)
 
     # the same recipe, pixels last: the draws and the boxes first (in parse_data's order), then one native pass
     src_h = max(img.shape[0], partner.shape[0]) if partner is not None else img.shape[0]
@@ -272,7 +291,7 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
         resized, pad = (fit_w, fit_h), (pad_x, pad_y)
     image = feed_native.sample(img, partner, lam, colour, offset, window, interp, resized, (width, height), pad, 128, flip,
                                out=out, as_float=not as_uint8)
-    return img_idx, image, np.asarray(boxes, np.float32), np.asarray(labels, np.int64)
+    return (img_idx, image) + split(boxes)
 
 
 def _augment_numpy(img, boxes, width, height, train, letterbox_resize, rng, prng):
