@@ -281,8 +281,9 @@ def box_delta_vs_oracle(model, y3, x, fms, n_check=None, chunk=4):
 
 
 PRECISION_TEXT = {
-    "f32_wino": "fp32 MFMA arithmetic throughout; Winograd kernels for the stride-1 3x3 convs (F(4x4,3x3) for the 128->256 and "
-                "512->1024 convs, F(2x2,3x3) for the others), direct kernel elsewhere",
+    "f32_wino": "fp32 MFMA arithmetic throughout; Winograd kernels for the stride-1 3x3 convs (F(4x4,3x3) where the library's "
+                "y3_conv_wino44_preferred says so: the 31 convs with Cin >= 64 at this size; F(2x2,3x3) for the 32->64 one), direct "
+                "kernels elsewhere",
     "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), direct implicit-GEMM kernels only",
     "f32_bf16x6": "fp32 tensors; each product = 6 bf16 plane products, fp32 accumulate (dropped terms <= 2^-23 relative)",
     "f32_bf16x3": "fp32 tensors; each product = 3 bf16 plane products, fp32 accumulate (dropped terms <= 2^-15 relative)",

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Where the forward's time above its own bound sits, by kernel family (DESIGN.md section 8's table).
 
-    python tools/gap_table.py [profiles/r03_layers_bs32_416_wino.csv] [--batch 32] [--size 416]
+    python tools/gap_table.py [profiles/r04_layers_bs32_416_wino.csv] [--batch 32] [--size 416] [--r03]
 
 Input: the per-layer csv of tools/layer_profile.py (layer, k, stride, cin, cout, ms).  Per layer the bound is
 max(algorithmic bytes / 8 TB/s, ISSUED FLOPs / 157.3 TF/s) - bench.py's `whole_forward_frac` accounting: a Winograd
-F(2x2,3x3) layer issues 16/36 of the direct-convolution FLOPs, an F(4x4,3x3) layer (the 128->256 and 512->1024 convs at
-this batch) 36/144 times the padding of its 4x4 tiles.  No GPU needed.
+F(2x2,3x3) layer issues 16/36 of the direct-convolution FLOPs, an F(4x4,3x3) layer (round 4: the convs with Cin >= 64 at
+this batch, y3_conv_wino44_preferred; --r03: the 128->256 and 512->1024 convs, round 3's rule, for round 3's csv) 36/144
+times the padding of its 4x4 tiles.  No GPU needed.
 """
 import argparse
 import collections
@@ -22,7 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('csv', nargs='?', default=os.path.join(ROOT, 'profiles', 'r03_layers_bs32_416_wino.csv'))
+    ap.add_argument('csv', nargs='?', default=os.path.join(ROOT, 'profiles', 'r04_layers_bs32_416_wino.csv'))
+    ap.add_argument('--r03', action='store_true', help="round 3's F(4x4) layer set")
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=416)
     args = ap.parse_args()
@@ -39,7 +41,7 @@ def main():
     names, factor = [], []
     for (k, s, cin, cout, _), g in zip(table, grids):
         if k == 3 and s == 1 and cin >= 32:
-            if (cin, cout) in ((128, 256), (512, 1024)):          # y3_conv_wino44_candidate; preferred at this batch
+            if ((cin, cout) in ((128, 256), (512, 1024))) if args.r03 else cin >= 64:      # y3_conv_wino44_preferred at this batch
                 t = -(-g // 4) * 4
                 names.append('F(4x4,3x3) %d->%d @%d' % (cin, cout, g))
                 factor.append(0.25 * t * t / float(g * g))
