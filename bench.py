@@ -954,6 +954,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": SIZE,
                    "class_num": CLASS_NUM, "parallelism": "replicas (image-sharded, no collective)",
                    "streams_per_gpu": model.inference_streams,
+                   "streams_calibration_ms": {str(k): round(v, 3) for k, v in
+                                              getattr(model, 'inference_streams_timing', {}).items()} or None,
                    "streams_note": ("the batch runs as %d equal parts on %d HIP streams of the GPU (north star: independent per-GPU "
                                     "streams for inference; one part's kernel tails and partly filled rounds of workgroups are "
                                     "filled by the other's kernels: A/B in one process 10.87 -> 10.33 ms for c2, 4.07 -> 3.77 ms for "

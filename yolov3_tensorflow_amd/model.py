@@ -141,27 +141,34 @@ class yolov3(object):
             self._forward_chunk(x, fms)
         return fms[0], fms[1], fms[2]
 
-    def choose_inference_streams(self, inputs, candidates=(1, 2), iters=3):
-        """Measure the inference forward of `inputs` with each stream count (a few synchronised forwards each) and keep the
-        fastest in self.inference_streams.  Whether two streams overlap depends on how the HIP runtime maps streams to its
-        hardware queues (GPU_MAX_HW_QUEUES, 4 by default): with RCCL initialised in the process the same code measured 12.1 ms
-        on two streams against 10.9 on one, and 10.4 with 2 or 8 hardware queues (profiles/r04_streams_ab.txt) - so a caller
-        that cannot set the variable before HIP starts asks the hardware."""
+    def choose_inference_streams(self, inputs, candidates=(1, 2), iters=3, rounds=4):
+        """Measure the inference forward of `inputs` with each stream count and keep the fastest in self.inference_streams.
+        Whether two streams overlap depends on how the HIP runtime maps streams to its hardware queues (GPU_MAX_HW_QUEUES, 4
+        by default): with RCCL initialised in the process the same code measured 12.1 ms on two streams against 10.9 on one,
+        and 10.4 with 2 or 8 hardware queues (profiles/r04_streams_ab.txt) - so a caller that cannot set the variable before
+        HIP starts asks the hardware.
+        The candidates are timed in alternation (`rounds` times `iters` synchronised forwards each, after one untimed forward
+        per candidate that builds its nets and workspaces) and compared by their BEST round: a single pass of three forwards
+        each, taken while the clocks were still settling, picked one stream in a driver run where two were 4 % faster."""
         import time
         x = fw.as_device_f32(inputs)
-        best, best_t = 1, None
+        candidates = list(dict.fromkeys(int(c) for c in candidates))
         for ns in candidates:
             self.inference_streams = ns
             self.forward(x, False)
-            torch.cuda.synchronize(x.device)
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                self.forward(x, False)
-            torch.cuda.synchronize(x.device)
-            t = time.perf_counter() - t0
-            if best_t is None or t < best_t:
-                best, best_t = ns, t
+        torch.cuda.synchronize(x.device)
+        best_t = {ns: float('inf') for ns in candidates}
+        for _ in range(max(1, int(rounds))):
+            for ns in candidates:
+                self.inference_streams = ns
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self.forward(x, False)
+                torch.cuda.synchronize(x.device)
+                best_t[ns] = min(best_t[ns], time.perf_counter() - t0)
+        best = min(candidates, key=lambda ns: best_t[ns])
         self.inference_streams = best
+        self.inference_streams_timing = {ns: best_t[ns] / iters * 1e3 for ns in candidates}      # ms per forward, best round
         return best
 
     def _forward_chunk(self, x, fms):
