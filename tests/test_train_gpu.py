@@ -193,6 +193,7 @@ def test_winograd_f4x4_data_gradient_matches_autograd(n, h, w, cin, cout):
     (2, 26, 26, 3, 1, 64, 64, 0),       # direct 3x3 stride 1
     (3, 13, 13, 3, 1, 64, 128, 2),      # F(4x4,3x3), odd map: 4x4 tiles hang over the edge (not counted), ragged last block
     (8, 52, 52, 3, 1, 128, 256, 2),     # F(4x4,3x3), several blocks per image
+    (6, 13, 13, 3, 1, 64, 128, 2),      # F(4x4,3x3) on an odd map: the batch tiled as one mosaic (tiles straddle images)
 ])
 def test_conv_epilogue_statistics_equal_the_separate_pass(n, h, w, k, stride, cin, cout, wino):
     """Training forward (ref: model.py:35-41 with is_training=True): the conv writes per-row-block column sums of its

@@ -55,7 +55,9 @@ struct W44Args {
     const float* resid;  // [N,H,W,Cout] or nullptr
     float* y;            // [N,H,W,Cout]
     int N, H, W, Cin, Cout, act;
-    int TH, TW, T;       // 4x4 output tiles per image column / row, and in total
+    int TH, TW, T;       // 4x4 output tiles per image column / row, and in total (mosaic: of the mosaic, T = TH * TW)
+    int mr, mc;          // mosaic tiling (w44_tiling): the N = mr * mc images form ONE picture, mr rows x mc columns of images with a
+                         // zero row / column between neighbours; 0 = every image tiled on its own
     // persistent schedule (workers > 0): whole rounds of blocks first, the remaining < workers blocks cut along K
     float* partial;      // [workers][2 * 256 rows][64] output-space partial sums (pre scale / shift) of the cut blocks' later K-ranges
     unsigned* flags;     // [workers] "partial published" words, zeroed ahead of every launch
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
     const unsigned b_ks_stride = (unsigned)(p.Cout * 2 * KC * 4);
     constexpr int RS = BNC + 4;                                      // staged output row stride in floats
     float* cs = reinterpret_cast<float*>(smem) + wm * (16 * 16 * RS);
-    int* tinfo = reinterpret_cast<int*>(smem + (BT / 16) * 16 * 16 * RS * 4);     // [BT][2]: pixel index of the tile's corner, valid rows | cols << 8
+    int* tinfo = reinterpret_cast<int*>(smem + (BT / 16) * 16 * 16 * RS * 4);     // [BT][8]: pixel-index parts of the tile's 4 output rows, 4 output columns (-1: none)
 
     W44_STAMP(0);
     while (whole_left > 0 || lo < hi) {
@@ -262,16 +264,26 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
         {
             const int t = t0 + ((lane >> 1) & (BT - 1));
             const bool tok = t < p.T;
-            const int n = t / (p.TH * p.TW);
+            const int n = p.mr ? 0 : t / (p.TH * p.TW);
             const int r = t - n * p.TH * p.TW;
             const int ty = r / p.TW, tx = r - ty * p.TW;
 #pragma unroll
             for (int j = 0; j < DPW; ++j) {
                 const int i = (wave + DW * j) * PPI + lane / (2 * BT);
                 const int k = i / 6, l = i - 6 * k;
-                const int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + l;
-                const bool ok = tok && i < 36 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                dvoff[j] = ok ? (unsigned)((((n * p.H + yy) * p.W + xx) * p.Cin) * 4 + (lane & 1) * 16) : OOB;
+                int yy = 4 * ty - 1 + k, xx = 4 * tx - 1 + l, img = n;
+                bool ok = tok && i < 36 && yy >= 0 && xx >= 0;
+                if (p.mr) {
+                    // mosaic row yy = row yy % (H+1) of image row yy / (H+1); row H of every image slot is the zero gap, which
+                    // is at once the bottom padding of the image above and the top padding of the image below
+                    const int ry = yy / (p.H + 1), cx = xx / (p.W + 1);
+                    yy -= ry * (p.H + 1);
+                    xx -= cx * (p.W + 1);
+                    img = ry * p.mc + cx;
+                    ok = ok && ry < p.mr && cx < p.mc;
+                }
+                ok = ok && yy < p.H && xx < p.W;
+                dvoff[j] = ok ? (unsigned)((((img * p.H + yy) * p.W + xx) * p.Cin) * 4 + (lane & 1) * 16) : OOB;
             }
         }
         auto dma_raw = [&](int ks, int buf) {
@@ -408,17 +420,29 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
         //      now) -> either the partial-sum slot (producer) or (+ the other pieces' sums) scale / shift / LeakyReLU /
         //      residual on 16-byte pieces, 256 contiguous bytes per output pixel ------------------------------------------
         if (tid < BT) {
+            // output pixel (q, c) of the tile = pixel index rowpart[q] + colpart[c] of y (separable in the mosaic too: image
+            // ry * mc + cx, row y, column x -> ((ry * mc) * H + y) * W  +  cx * H * W + x); -1 = no such pixel (past the
+            // edge, a gap row / column of the mosaic, or a tile past T)
             const int t = t0 + tid;
-            int pix = 0, vv = 0;
-            if (t < p.T) {
-                const int n = t / (p.TH * p.TW);
-                const int r = t - n * p.TH * p.TW;
-                const int ty = r / p.TW, tx = r - ty * p.TW;
-                pix = (n * p.H + 4 * ty) * p.W + 4 * tx;
-                vv = min(4, p.H - 4 * ty) | (min(4, p.W - 4 * tx) << 8);
+            const int n = p.mr ? 0 : t / (p.TH * p.TW);
+            const int r = t - n * p.TH * p.TW;
+            const int ty = r / p.TW, tx = r - ty * p.TW;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int yy = 4 * ty + q, xx = 4 * tx + q, rpart, cpart;
+                if (p.mr) {
+                    const int ry = yy / (p.H + 1), cx = xx / (p.W + 1);
+                    yy -= ry * (p.H + 1);
+                    xx -= cx * (p.W + 1);
+                    rpart = (ry < p.mr && yy < p.H) ? (ry * p.mc * p.H + yy) * p.W : -1;
+                    cpart = (cx < p.mc && xx < p.W) ? cx * p.H * p.W + xx : -1;
+                } else {
+                    rpart = yy < p.H ? (n * p.H + yy) * p.W : -1;
+                    cpart = xx < p.W ? xx : -1;
+                }
+                tinfo[8 * tid + q] = t < p.T ? rpart : -1;
+                tinfo[8 * tid + 4 + q] = t < p.T ? cpart : -1;
             }
-            tinfo[2 * tid] = pix;
-            tinfo[2 * tid + 1] = vv;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -501,11 +525,10 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
                 for (int it = 0; it < 16; ++it) {
                     const int rowi = it * 16 + (gt >> 4);
                     const int tl = rowi >> 4, px = rowi & 15;
-                    const int pix = tinfo[2 * (wm * 16 + tl)], vv = tinfo[2 * (wm * 16 + tl) + 1];
-                    const int py = px >> 2, pxx = px & 3;
-                    const bool ok = py < (vv & 0xff) && pxx < (vv >> 8) && co < p.Cout;
+                    const int rpart = tinfo[8 * (wm * 16 + tl) + (px >> 2)], cpart = tinfo[8 * (wm * 16 + tl) + 4 + (px & 3)];
+                    const bool ok = (rpart | cpart) >= 0 && co < p.Cout;
                     rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                 rs_res, ok ? (unsigned)(((pix + py * p.W + pxx) * p.Cout + co) * 4) : OOB, 0, 0));
+                                 rs_res, ok ? (unsigned)(((rpart + cpart) * p.Cout + co) * 4) : OOB, 0, 0));
                 }
             } else {
 #pragma unroll
@@ -515,20 +538,19 @@ __global__ void __launch_bounds__(NTH, BT == 16 ? 2 : 1) conv_wino44_f32_kernel(
             for (int it = 0; it < 16; ++it) {
                 const int rowi = it * 16 + (gt >> 4);            // (tile, pixel) row of this half: 256 rows
                 const int tl = rowi >> 4, px = rowi & 15;
-                const int pix = tinfo[2 * (wm * 16 + tl)], vv = tinfo[2 * (wm * 16 + tl) + 1];
-                const int py = px >> 2, pxx = px & 3;
+                const int rpart = tinfo[8 * (wm * 16 + tl) + (px >> 2)], cpart = tinfo[8 * (wm * 16 + tl) + 4 + (px & 3)];
                 f32x4 v = *reinterpret_cast<const f32x4*>(cs + rowi * RS + c4);
                 for (int e = 1; e <= n_extra; ++e)               // the other pieces, in worker order (deterministic)
                     v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                              rs_part, (unsigned)(((wm * 256 + rowi) * BNC + c4) * 4),
                              (unsigned)(blockIdx.x - e) * (unsigned)(SLOT_FLOATS * 4), 17));   // aux 17 = sc0 sc1 (see y3_conv_wino.hip)
-                if (py < (vv & 0xff) && pxx < (vv >> 8) && co < p.Cout) {
+                if ((rpart | cpart) >= 0 && co < p.Cout) {
                     v = v * sc + sh;
                     if (p.act) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
                     }
-                    const size_t o = (size_t)(pix + py * p.W + pxx) * p.Cout + co;
+                    const size_t o = (size_t)(rpart + cpart) * p.Cout + co;
                     v += rv[it];
                     *reinterpret_cast<f32x4*>(p.y + o) = v;
                     if (STATS) { st1 += v; st2 += v * v; }
@@ -646,9 +668,35 @@ int y3_conv_wino44_candidate_impl(const y3_conv_desc* d) {
     return 1;
 }
 
+// How the output is cut into 4x4 tiles.  A map whose side is a multiple of 4 is tiled image by image.  Otherwise (the 13- and
+// 26-grids of a 416-pixel input) every image would pad its last tile row and column with zero work (26: 49 tiles for 42.25
+// tiles' worth of pixels; 13: 16 for 10.6), so the batch is tiled as ONE picture instead: the N = mr x mc images laid out
+// mr rows by mc columns with one zero row / column between neighbours.  The gap is exactly the zero padding both neighbours
+// need, so a tile may straddle two images (its gap outputs are never stored), and only the picture's last tile row / column
+// pads.  bs=32 at 26x26: 4 x 8 images = 107 x 215 pixels = 27 x 54 = 1,458 tiles instead of 1,568 - 736 blocks instead of 784,
+// which is one block per CU less than three rounds of 256 instead of one more (time goes with ceil(blocks / 256),
+// profiles/r04_wino44.txt 5).  mr * mc == N exactly (mr a divisor of N: a prime batch becomes a 1 x N strip).
+struct W44Tiling { int TH, TW, T, mr, mc; };
+static W44Tiling w44_tiling(const y3_conv_desc* d) {
+    W44Tiling t;
+    t.mr = t.mc = 0;
+    t.TH = (d->h + 3) / 4; t.TW = (d->w + 3) / 4; t.T = d->n * t.TH * t.TW;
+    static const bool off = y3_exp_env("Y3_WINO44_MOSAIC") && atoi(y3_exp_env("Y3_WINO44_MOSAIC")) == 0;
+    if ((d->h % 4 == 0 && d->w % 4 == 0) || off) return t;
+    for (int r = 1; r <= d->n; ++r) {
+        if (d->n % r) continue;
+        const int c = d->n / r;
+        const long long th = ((long long)r * (d->h + 1) - 1 + 3) / 4, tw = ((long long)c * (d->w + 1) - 1 + 3) / 4;
+        if (th * tw < t.T) { t.mr = r; t.mc = c; t.TH = (int)th; t.TW = (int)tw; t.T = (int)(th * tw); }
+    }
+    return t;
+}
+
 int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
     if (!y3_conv_wino44_candidate_impl(d)) return 0;
     if (wino44_mode() == 2) return 1;
+    // (thresholds on the image-by-image tile count: the measurements above were taken on it, and the choice of kernel should not
+    // move because the mosaic saves a few blocks)
     const long long tiles = (long long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4);
     const long long blocks = ((tiles + BT - 1) / BT) * (d->cout / BNC);
     return blocks >= 128 * (32 / BT) && (d->cin >= 64 || blocks <= 4096);
@@ -657,7 +705,7 @@ int y3_conv_wino44_preferred_impl(const y3_conv_desc* d) {
 // rows of the `stats` output of the STATS instantiation: one per 16-tile block
 int y3_conv_wino44_stats_blocks_impl(const y3_conv_desc* d) {
     if (!y3_conv_wino44_eligible_impl(d)) return 0;
-    const long long tiles = (long long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4);
+    const long long tiles = w44_tiling(d).T;
     return (int)((tiles + BT - 1) / BT);
 }
 
@@ -689,7 +737,8 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
     W44Args a;
     a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.act = d->act;
-    a.TH = (d->h + 3) / 4; a.TW = (d->w + 3) / 4; a.T = d->n * a.TH * a.TW;
+    const W44Tiling til = w44_tiling(d);
+    a.TH = til.TH; a.TW = til.TW; a.T = til.T; a.mr = til.mr; a.mc = til.mc;
     a.partial = nullptr; a.flags = nullptr; a.err = nullptr; a.spin_limit = 0; a.workers = 0; a.fault = 0;
     a.stats = sk ? sk->stats : nullptr;
     auto kern = a.stats ? conv_wino44_f32_kernel<true> : conv_wino44_f32_kernel<false>;
