@@ -209,7 +209,7 @@ WINO_CASES = [
     (2, 52, 52, 128, 256, True, True),     # true-size 52x52 residual-stage conv
     (7, 26, 26, 64, 1024, True, True),     # 19 x 16 = 304 blocks on 256 workers: stream-K schedule, every block split
     (32, 13, 13, 64, 1024, True, False),   # BASELINE-size 13x13 map: 25 x 16 = 400 blocks, stream-K, ragged last tile block
-    (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear
+    (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear; a 1 x 5 strip mosaic: tiles straddle images
     (1, 2, 2, 96, 32, True, False),        # one tile per image; Cin not a power of two
     (2, 40, 36, 32, 64, True, True),       # the 208x208 stage's shape class: 4 K-steps per block
 ]
@@ -244,17 +244,17 @@ def test_winograd_conv_matches_fp64(n, h, w, cin, cout, act, resid):
 WINO44_CASES = [
     # n, h, w, cin, cout, act, resid
     (3, 20, 28, 64, 128, True, True),      # whole 4x4 tiles, ragged last tile block
-    (2, 13, 13, 512, 1024, True, True),    # odd map: 4x4 tiles of 4x4, the last row / column of tiles 3/4 outside
+    (2, 13, 13, 512, 1024, True, True),    # odd map: tiled as a mosaic of the two images (27 x 13 pixels, a zero gap row between them)
     (1, 26, 26, 256, 512, True, False),    # 7x7 tiles, the last half outside
     (2, 52, 52, 128, 256, True, True),     # true-size 52x52 residual-stage conv
     (5, 3, 5, 64, 64, False, False),       # tiny odd map, linear
     (1, 2, 2, 96, 64, True, False),        # one tile per image, mostly padding; Cin not a power of two
     (2, 40, 36, 32, 64, True, True),       # the 208x208 stage's shape class: 4 K-steps per block
     (1, 9, 130, 32, 192, True, True),      # wide and flat, Cout = 3 column blocks
-    (32, 26, 26, 64, 512, True, True),     # 49 x 8 = 392 blocks on 256 workers: persistent schedule, 136 blocks cut along K
+    (32, 26, 26, 64, 512, True, True),     # mosaic of 4 x 8 images: 1,458 tiles = 92 x 8 = 736 blocks on 512 workers: persistent schedule, 224 blocks cut along K
     (10, 52, 52, 32, 128, True, False),    # 53 x 2 = 106 blocks (one round) ... and with Cout 640 below: 530 blocks, 4 K-steps
     (10, 52, 52, 32, 640, False, True),    # 530 blocks: two whole rounds + 18 cut blocks of 4 K-steps (rem * ksteps < 2 W: data parallel)
-    (24, 26, 26, 128, 512, True, True),    # 37 x 8 = 296 blocks: 40 cut blocks x 16 K-steps, pieces of 2-3 K-steps
+    (24, 26, 26, 128, 512, True, True),    # mosaic of 3 x 8 images: 1,080 tiles = 68 x 8 = 544 blocks (one workgroup per block: 32 x 16 K-steps left over are too few to cut)
 ]
 
 
