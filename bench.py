@@ -656,8 +656,9 @@ def layer_input_grids(table, size):
 def winograd_issue_factors(table, precision, size):
     """Per layer: (is_winograd, MFMA work ISSUED / direct-convolution FLOPs) for the kernel the library runs in `precision`.
     F(2x2,3x3) layers issue 16/36 of the direct count; the layers y3_conv_wino44_preferred names run F(4x4,3x3) in the
-    inference forward: 36/144.  The 4x4 tiles that pad a 13-grid (to 16: x1.51) or a 26-grid (to 28: x1.16) ARE issued by
-    the kernel and are NOT counted (multiplying zeros is not achieved work), so `frac` is the useful fraction.
+    inference forward: 36/144.  The zero pixels of the 4x4 tiles that pad a 13- or a 26-grid (image by image x1.51 / x1.16; with
+    the batch tiled as one mosaic, csrc/y3_conv_wino44.hip w44_tiling, x1.16 / x1.08 at bs=32) ARE issued by the kernel and are
+    NOT counted (multiplying zeros is not achieved work), so `frac` is the useful fraction.
     The factor follows the library's own choice of kernel per layer."""
     from yolov3_tensorflow_amd import engine
     is_w, fac = [], []
