@@ -21,10 +21,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def w44_tiles(n, g, mosaic=True):
+    """4x4 output tiles of a batch of n g x g maps: image by image, or (round 4's last change: csrc/y3_conv_wino44.hip,
+    w44_tiling) the batch as one mosaic of mr x mc images with a zero row / column between neighbours."""
+    best = n * (-(-g // 4)) ** 2
+    if g % 4 and mosaic:
+        for r in range(1, n + 1):
+            if n % r == 0:
+                best = min(best, (-(-(r * (g + 1) - 1) // 4)) * (-(-(n // r * (g + 1) - 1) // 4)))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('csv', nargs='?', default=os.path.join(ROOT, 'profiles', 'r04_layers_bs32_416_wino.csv'))
     ap.add_argument('--r03', action='store_true', help="round 3's F(4x4) layer set")
+    ap.add_argument('--mosaic', action='store_true', help='the csv was taken with the mosaic tiling of the 13- / 26-grids '
+                    '(profiles/r04_layers_bs32_416_wino.csv was not)')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=416)
     args = ap.parse_args()
@@ -42,9 +55,8 @@ def main():
     for (k, s, cin, cout, _), g in zip(table, grids):
         if k == 3 and s == 1 and cin >= 32:
             if ((cin, cout) in ((128, 256), (512, 1024))) if args.r03 else cin >= 64:      # y3_conv_wino44_preferred at this batch
-                t = -(-g // 4) * 4
                 names.append('F(4x4,3x3) %d->%d @%d' % (cin, cout, g))
-                factor.append(0.25 * t * t / float(g * g))
+                factor.append(0.25 * w44_tiles(args.batch, g, args.mosaic) * 16 / float(args.batch * g * g))
             else:
                 names.append('F(2x2,3x3) %d->%d @%d' % (cin, cout, g))
                 factor.append(16.0 / 36.0)
