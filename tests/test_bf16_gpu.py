@@ -45,6 +45,15 @@ def ref_conv(x, w_hwio, scale, shift, k, stride, act, resid=None):
     (4, 76, 76, 3, 1, 128, 256, True, 0, 0), (8, 76, 76, 3, 1, 256, 512, False, 0, 0),
     (2, 38, 50, 3, 2, 32, 64, False, 0, 0), (1, 37, 41, 3, 1, 64, 128, True, 0, 0),
     (3, 20, 28, 1, 1, 128, 64, False, 0, 0), (2, 26, 26, 1, 1, 384, 128, False, 128, 0),
+    # round 5, the 192-row tiles of the pipelined 3x3 kernel (y3_conv_bf16x.hip: 38-grid bs=16 -> 192x256, 19-grid -> 192x128)
+    (16, 38, 38, 3, 1, 256, 512, True, 0, 0), (16, 19, 19, 3, 1, 512, 1024, False, 0, 0), (5, 38, 38, 3, 2, 128, 256, False, 0, 0),
+    # round 5, the persistent ring kernel of the 1x1 convs (y3_conv_bf16r.hip): many tiles per workgroup with one and two
+    # K-steps per tile (the ring runs across tile boundaries), ragged rows, a Cout that is no multiple of 32, a residual,
+    # bf16 output with Cout % 8 != 0 (per-element epilogue), fp32 output with a residual, deep K
+    (4, 152, 152, 1, 1, 64, 32, False, 0, 0), (8, 152, 152, 1, 1, 128, 64, False, 0, 0), (16, 76, 76, 1, 1, 256, 128, False, 0, 0),
+    (3, 21, 27, 1, 1, 192, 136, True, 0, 0), (2, 38, 38, 1, 1, 512, 256, True, 0, 0), (1, 19, 19, 1, 1, 1024, 512, False, 0, 0),
+    (2, 13, 17, 1, 1, 128, 100, False, 0, 0), (2, 13, 17, 1, 1, 128, 255, True, 0, 1), (16, 76, 76, 1, 1, 256, 255, False, 0, 1),
+    (4, 38, 38, 1, 1, 768, 256, False, 256, 0),
 ])
 def test_bf16_conv_matches_fp64_on_rounded_operands(n, h, w, k, stride, cin, cout, resid, c_up, out_f32):
     from yolov3_tensorflow_amd import framework as fw, _lib

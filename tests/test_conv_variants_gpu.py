@@ -3,7 +3,9 @@
 each case runs in its own interpreter): the hybrid stream-K schedule of the F(2x2,3x3) kernel (Y3_WINO_SK_HYBRID=1) and
 the data-parallel schedules forced where the product picks stream-K (Y3_CONV_WINO_STREAMK=0 + Y3_CONV_STREAMK=0), each
 against the fp64 reference through the same cases as the default path (tests/test_conv_gpu.py), plus the statistics
-epilogue and the data / weight gradients of the train step."""
+epilogue and the data / weight gradients of the train step; and every tile shape of the bf16 kernels forced in turn
+(Y3_BF16X_TILE=A..E for the 3x3 convs, Y3_BF16R_TILE=a..g for the 1x1 ring kernel, Y3_BF16R=0 for the register-staged 1x1
+kernel the product no longer dispatches to) through the bf16 conv cases of tests/test_bf16_gpu.py."""
 import os
 import subprocess
 import sys
@@ -28,6 +30,22 @@ def test_switched_winograd_paths(env):
                         os.path.join(HERE, 'test_conv_gpu.py') + '::test_winograd_conv_matches_fp64',
                         os.path.join(HERE, 'test_train_gpu.py'), '-k',
                         'winograd_conv_matches_fp64 or conv_epilogue_statistics or conv_wgrad_and_dgrad'],
+                       env=e, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors='replace')
+    assert r.returncode == 0, out[-3000:]
+    assert ' passed' in out, out[-1000:]
+
+
+@pytest.mark.parametrize('env', [{'Y3_BF16X_TILE': t} for t in 'ABCDE'] + [{'Y3_BF16R_TILE': t} for t in 'abcdefg'] +
+                         [{'Y3_BF16R': '0'}],
+                         ids=['3x3_tile_' + t for t in 'ABCDE'] + ['1x1_tile_' + t for t in 'abcdefg'] + ['1x1_register_staged'])
+def test_forced_bf16_tiles(env):
+    from yolov3_tensorflow_amd import build
+    e = dict(os.environ)
+    e.update(env)
+    e['Y3_LIB_PATH'] = build.build_experiments(verbose=False)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu',
+                        os.path.join(HERE, 'test_bf16_gpu.py') + '::test_bf16_conv_matches_fp64_on_rounded_operands'],
                        env=e, cwd=os.path.dirname(HERE), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode(errors='replace')
     assert r.returncode == 0, out[-3000:]

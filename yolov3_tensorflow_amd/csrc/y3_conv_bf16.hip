@@ -464,6 +464,10 @@ int y3_launch_conv_bf16(hipStream_t stream, const y3_conv_desc* d, const void* x
     Y3_CHECK_ARG(out_f32 || d->cout % 4 == 0, "y3_conv2d_fwd_bf16: bf16 output needs Cout %% 4 == 0");
     if (y3_conv_bf16x_takes(d->k, d->cin))     // the LDS-DMA kernels (y3_conv_bf16x.hip) and their weight packing
         return y3_launch_conv_bf16x(stream, d, x, x_up, w, scale, shift, residual, y, out_f32);
+    if (y3_conv_bf16r_takes(d->k, d->cin)) {   // the 1x1 convs: persistent LDS-DMA ring kernel (y3_conv_bf16r.hip)
+        Y3_CHECK_ARG(d->stride == 1, "y3_conv2d_fwd_bf16: 1x1 conv must have stride 1");
+        return y3_launch_conv_bf16r(stream, d, x, x_up, w, scale, shift, residual, y, out_f32);
+    }
     ConvArgsB a;
     a.x = static_cast<const bf16_t*>(x); a.xu = static_cast<const bf16_t*>(x_up);
     a.w = static_cast<const bf16_t*>(w); a.scale = scale; a.shift = shift;
@@ -487,7 +491,8 @@ extern "C" int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k
     Y3_CHECK_ARG(ctx && w_hwio && w_packed, "y3_pack_conv_weights_bf16: null argument");
     Y3_CHECK_ARG(k > 0 && cin > 0 && cout > 0 && cin % BKB == 0,
                  "y3_pack_conv_weights_bf16: cin must be a positive multiple of %d", BKB);
-    if (y3_conv_bf16x_takes(k, cin)) return y3_launch_pack_bf16x(ctx->stream, w_hwio, k, cin, cout, w_packed);
+    if (y3_conv_bf16x_takes(k, cin) || y3_conv_bf16r_takes(k, cin))      // [tap][Cin/64][Cout][64]
+        return y3_launch_pack_bf16x(ctx->stream, w_hwio, k, cin, cout, w_packed);
     const size_t total = (size_t)k * k * cin * cout;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, w_hwio,

@@ -93,6 +93,10 @@ int y3_conv_bf16x_takes(int k, int cin);
 int y3_launch_pack_bf16x(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, void* w_packed);
 int y3_launch_conv_bf16x(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                          const float* scale, const float* shift, const void* residual, void* y, int out_f32);
+// persistent LDS-DMA ring kernel for the bf16 1x1 convs (y3_conv_bf16r.hip); weights in the bf16x packing with one tap
+int y3_conv_bf16r_takes(int k, int cin);
+int y3_launch_conv_bf16r(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
+                         const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out,
                          int transposed = 0);
 int y3_launch_conv_dgrad_split(hipStream_t stream, const y3_conv_desc* fwd, int planes, const float* dz, int dz_stride,
