@@ -4,8 +4,8 @@ each case runs in its own interpreter): the hybrid stream-K schedule of the F(2x
 the data-parallel schedules forced where the product picks stream-K (Y3_CONV_WINO_STREAMK=0 + Y3_CONV_STREAMK=0), each
 against the fp64 reference through the same cases as the default path (tests/test_conv_gpu.py), plus the statistics
 epilogue and the data / weight gradients of the train step; and every tile shape of the bf16 kernels forced in turn
-(Y3_BF16X_TILE=A..E for the 3x3 convs, Y3_BF16R_TILE=a..g for the 1x1 ring kernel, Y3_BF16R=0 for the register-staged 1x1
-kernel the product no longer dispatches to) through the bf16 conv cases of tests/test_bf16_gpu.py."""
+(Y3_BF16X_TILE=A..E for the 3x3 convs; Y3_BF16R=1 sends every 1x1 conv with Cin % 64 == 0 to the ring kernel - the product
+only those with Cin >= 512 - with Y3_BF16R_TILE=a..g forcing its tile; Y3_BF16R=0 none) through the bf16 conv cases of tests/test_bf16_gpu.py."""
 import os
 import subprocess
 import sys
@@ -36,9 +36,10 @@ def test_switched_winograd_paths(env):
     assert ' passed' in out, out[-1000:]
 
 
-@pytest.mark.parametrize('env', [{'Y3_BF16X_TILE': t} for t in 'ABCDE'] + [{'Y3_BF16R_TILE': t} for t in 'abcdefg'] +
-                         [{'Y3_BF16R': '0'}],
-                         ids=['3x3_tile_' + t for t in 'ABCDE'] + ['1x1_tile_' + t for t in 'abcdefg'] + ['1x1_register_staged'])
+@pytest.mark.parametrize('env', [{'Y3_BF16X_TILE': t} for t in 'ABCDE'] +
+                         [{'Y3_BF16R': '1', 'Y3_BF16R_TILE': t} for t in 'abcdefg'] + [{'Y3_BF16R': '1'}, {'Y3_BF16R': '0'}],
+                         ids=['3x3_tile_' + t for t in 'ABCDE'] + ['1x1_ring_tile_' + t for t in 'abcdefg'] +
+                             ['1x1_ring_every_cin', '1x1_register_staged'])
 def test_forced_bf16_tiles(env):
     from yolov3_tensorflow_amd import build
     e = dict(os.environ)

@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(256, 3) conv_mfma_bf16_kernel(const ConvArgsB 
                         float v = acc[mi][ni][r] * sc + sh;
                         if (p.act) v = v > 0.f ? v : 0.1f * v;
                         const size_t o = (size_t)row * p.Cout + col;
+                        if (p.resid) v += __uint_as_float((unsigned)p.resid[o] << 16);
                         if (p.out_f32) yf[o] = v;
                         else static_cast<bf16_t*>(p.y)[o] = f32_to_bf16(v);
                     }

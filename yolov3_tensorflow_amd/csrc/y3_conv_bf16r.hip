@@ -88,9 +88,13 @@ __global__ void __launch_bounds__(256) conv1x1_bf16r_kernel(const ConvArgsR p) {
     const int kchunks = p.Cin / 64;
     const int ntiles = nbm * nbn;
 
-    // this workgroup's contiguous run of tiles (column-major tile ids: a run stays inside one column block, so its B
-    // tiles are the same few KB over and over)
-    const int G = gridDim.x, g = blockIdx.x;
+    // This workgroup's contiguous run of tiles.  Tile ids are ROW-major (tile = bm * nbn + bn: neighbours share their A rows)
+    // and the runs are handed out XCD by XCD (workgroup b runs on XCD b % 8, observed; placement is a speed matter only): one
+    // XCD's workgroups cover a contiguous range of row blocks for every column block, so an activation row is fetched into
+    // ONE L2 instead of into nbn of them (19-grid 1024->512: 55 -> 20 MB over the fabric) and only the weights - the small
+    // operand of a 1x1 conv - are read by all eight.
+    const int G = gridDim.x;
+    const int g = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int tq = ntiles / G, tr = ntiles - tq * G;
     const int t0 = g * tq + (g < tr ? g : tr);
     const int t1 = t0 + tq + (g < tr ? 1 : 0);
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(256) conv1x1_bf16r_kernel(const ConvArgsR p) {
     unsigned a_off[ACH], a_off_u[UPCAT ? ACH : 1], b_off[BCH];
     int ld_tile = t0, ld_ks = 0;
     auto set_tile = [&](int tile) {
-        const int bn = tile / nbm, bm = tile - bn * nbm;
+        const int bm = tile / nbn, bn = tile - bm * nbn;
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int r = (wave * ACH + j) * 8 + l_row;
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(256) conv1x1_bf16r_kernel(const ConvArgsR p) {
     float* patch = reinterpret_cast<float*>(smem + NSTAGE * STAGE + wave * EPATCH);
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
     auto epilogue = [&](int tile) {
-        const int bn = tile / nbm, bm = tile - bn * nbm;
+        const int bm = tile / nbn, bn = tile - bm * nbn;
         const int mw = bm * BM + wm * WTM, nw = bn * BN + wn * WTN;     // this wave's corner
         const bool wide = !p.out_f32 && (p.Cout & 7) == 0;              // bf16 out, 8-channel (16-byte) pieces
         const bool quad = p.out_f32 && !p.resid;                        // fp32 out (detection convs): 4-channel pieces
@@ -355,7 +359,9 @@ __global__ void __launch_bounds__(256) conv1x1_bf16r_kernel(const ConvArgsR p) {
         // the epilogue's loads and stores sit in the same counter as the DMAs: drain once per tile (the DMAs of the next
         // tile's first items were issued before the epilogue and have had its whole length to land), so that the counted
         // wait above never depends on loads and stores retiring in order relative to each other
+#ifndef R_NODRAIN
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0); the builtin, not inline asm: hipcc's own wait-count pass must see it
+#endif
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -402,62 +408,57 @@ int forced_rtile() {
     return v;
 }
 
-// time model of a tile shape for this conv (us): the workgroups are resident (256 CUs x what the LDS admits) and each walks
-// ceil(tiles / grid) tiles; an item costs its bytes at the rate one CU's DMA ring sustains from the L2 (~60 GB/s, split
-// between the workgroups of the CU), a tile its output at ~34 GB/s plus ~1 us of epilogue latency; 3 us once per workgroup
-// (launch, first fill of the ring).  Fitted to profiles/r05_bf16_tiles.txt.
-float rtile_estimate(const RTile& t, long long M, int cout, int kchunks) {
-    const long long ntiles = ((M + t.bm - 1) / t.bm) * ((cout + t.bn - 1) / t.bn);
-    const int per_cu = 163840 / t.lds < 1 ? 1 : (163840 / t.lds > 4 ? 4 : 163840 / t.lds);
-    const long long grid = ntiles < 256LL * per_cu ? ntiles : 256LL * per_cu;
-    const long long per_wg = (ntiles + grid - 1) / grid;
-    const long long wg_per_cu = (grid + 255) / 256;
-    const float item = (float)((t.bm + t.bn) * 128) / 60e3f * (float)wg_per_cu;
-    const float tail = 1.f + (float)(t.bm * t.bn * 2) / 34e3f * (float)wg_per_cu;
-    return 3.f + (float)per_wg * ((float)kchunks * item + tail);
-}
+#ifndef R_STAGES
+#define R_STAGES 3
+#endif
+constexpr int RS = R_STAGES;       // ring depth of the tiles whose LDS leaves room for more than three stages (probe builds)
 
+// Tile rule, from the per-layer measurements with every tile forced in turn at bs = 16 and bs = 8, 608x608
+// (profiles/r05_bf16_tiles.txt): the largest of 192x128 / 96x128 / 64x64 that still gives ~200 tiles (a tile per CU: the
+// workgroups are resident, one or two per CU by their LDS), Cout <= 64 layers on 128x32 / 128x64.
 template <bool UPCAT>
 int dispatch_r(hipStream_t stream, const ConvArgsR& a) {
-    constexpr RTile T[7] = {rtile<1, 1, 4, 1, 3>(), rtile<2, 1, 2, 2, 3>(), rtile<2, 2, 2, 2, 3>(), rtile<3, 2, 2, 2, 3>(),
-                            rtile<3, 1, 1, 4, 3>(), rtile<1, 1, 2, 2, 3>(), rtile<1, 2, 2, 2, 3>()};
+    constexpr RTile T[7] = {rtile<1, 1, 4, 1, RS>(), rtile<2, 1, 2, 2, RS>(), rtile<2, 2, 2, 2, 3>(), rtile<3, 2, 2, 2, 3>(),
+                            rtile<3, 1, 1, 4, RS>(), rtile<1, 1, 2, 2, RS>(), rtile<1, 2, 2, 2, RS>()};
     int t = forced_rtile();
-    const int kchunks = a.Cin / 64;
     if (t < 0 || (T[t].bn > 32 && a.Cout <= 32) || (T[t].bn > 64 && a.Cout <= 64)) {
-        t = -1;
-        float best = 0.f;
-        for (int c = 0; c < 7; ++c) {
-            if ((T[c].bn > 32 && a.Cout <= 32) || (T[c].bn > 64 && a.Cout <= 64)) continue;   // no tile wider than the layer
-            if (T[c].bn == 32 && a.Cout > 32) continue;
-            const float e = rtile_estimate(T[c], a.M, a.Cout, kchunks);
-            if (t < 0 || e < best) { t = c; best = e; }
-        }
+        auto tiles = [&](int c) { return (long long)((a.M + T[c].bm - 1) / T[c].bm) * ((a.Cout + T[c].bn - 1) / T[c].bn); };
+        if (a.Cout <= 32) t = 0;
+        else if (a.Cout <= 64) t = 1;
+        else if (tiles(3) >= 200) t = 3;
+        else if (tiles(4) >= 200) t = 4;
+        else t = 5;
     }
     switch (t) {
-    case 0: return launch_r<1, 1, 4, 1, 3, UPCAT>(stream, a);
-    case 1: return launch_r<2, 1, 2, 2, 3, UPCAT>(stream, a);
+    case 0: return launch_r<1, 1, 4, 1, RS, UPCAT>(stream, a);
+    case 1: return launch_r<2, 1, 2, 2, RS, UPCAT>(stream, a);
     case 2: return launch_r<2, 2, 2, 2, 3, UPCAT>(stream, a);
     case 3: return launch_r<3, 2, 2, 2, 3, UPCAT>(stream, a);
-    case 4: return launch_r<3, 1, 1, 4, 3, UPCAT>(stream, a);
-    case 5: return launch_r<1, 1, 2, 2, 3, UPCAT>(stream, a);
-    default: return launch_r<1, 2, 2, 2, 3, UPCAT>(stream, a);
+    case 4: return launch_r<3, 1, 1, 4, RS, UPCAT>(stream, a);
+    case 5: return launch_r<1, 1, 2, 2, RS, UPCAT>(stream, a);
+    default: return launch_r<1, 2, 2, 2, RS, UPCAT>(stream, a);
     }
 }
 
 }  // namespace
 
-// 1x1 convs with Cin a multiple of 64 (every 1x1 conv of the network): decided by (k, Cin) alone, because the weight
-// packing is chosen when only the kernel's shape is known.  (experiments build: Y3_BF16R=0 keeps them on y3_conv_bf16.hip)
+// 1x1 convs with Cin >= 512 (a multiple of 64): decided by (k, Cin) alone, because the weight packing is chosen when only
+// the kernel's shape is known.  Measured per layer at configs[4] (profiles/r05_bf16_tiles.txt, us per launch, this kernel |
+// the register-staged kernel of y3_conv_bf16.hip): 38-grid 512->256 19.4 | 23.3, 19-grid 1024->512 17.9 | 21.7, 768->256 with
+// the fused upsample 25.7 | 28.8, detection convs 1024->255 16.1 | 18.7, 512->255 21.5 | 26.9 - deep K, few rows: what the
+// ring is for.  The wide, shallow layers (76-grid 256->128 26.8 | 23.5, 152-grid 128->64 42 | 33) run at the rate the
+// memory system gives a mixed read / write stream either way and stay on the register-staged kernel, whose three
+// co-resident workgroups per CU cover one another's epilogues.  (experiments build: Y3_BF16R=0 / 1 = never / every Cin % 64 == 0)
 int y3_conv_bf16r_takes(int k, int cin) {
     if (k != 1 || cin % 64 != 0) return 0;
-    static int off = -1;
-    if (off < 0) {
+    static int mode = -2;
+    if (mode == -2) {
         const char* e = y3_exp_env("Y3_BF16R");
-        off = (e && e[0] == '0') ? 1 : 0;
+        mode = e ? (e[0] == '0' ? 0 : 1) : -1;
     }
-    return off ? 0 : 1;
+    if (mode >= 0) return mode;
+    return cin >= 512 ? 1 : 0;
 }
-
 int y3_launch_conv_bf16r(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                          const float* scale, const float* shift, const void* residual, void* y, int out_f32) {
     const long long M = (long long)d->n * d->h * d->w;

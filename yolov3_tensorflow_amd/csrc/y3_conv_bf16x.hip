@@ -96,6 +96,7 @@ __device__ __forceinline__ void epilogue_x(const ConvArgsX& p, unsigned char* sm
                         float v = acc[mi][ni][r] * sc + sh;
                         if (p.act) v = v > 0.f ? v : 0.1f * v;
                         const size_t o = (size_t)row * p.Cout + col;
+                        if (p.resid) v += __uint_as_float((unsigned)p.resid[o] << 16);
                         if (p.out_f32) yf[o] = v;
                         else static_cast<bf16_t*>(p.y)[o] = f32_to_bf16(v);
                     }
@@ -701,16 +702,18 @@ int launch_p(hipStream_t stream, const ConvArgsX& a) {
 // Tile choice.  Candidates: A = 256x256, D = 192x256, B = 256x128, E = 192x128 (the pipelined kernel: eight waves, one
 // workgroup per CU), C = 128x128 (two-stage kernel, four waves, two workgroups per CU); narrow Cout: 128x64 / 128x32.
 // At configs[4] (bs = 16, 608x608) a layer is 54 GFLOP - 22 us at the bf16 peak - and what decides is how the tile count
-// quantises over the 256 CUs and what a tile costs besides its K-tiles.  Fitted to the per-layer measurements
-// (profiles/r03_bf16x_tiles.txt, profiles/r05_bf16_tiles.txt):
-//     time = ceil(tiles / slots) * (S * kt + fixed),   S = 9 * Cin / 64 K-tiles per output tile
-//   pipelined kernel: kt = 1.61 us per K-tile of a 256x256 tile, 0.98 for 256x128 (the narrow tile moves more bytes per
-//   FLOP from the L2), 3/4 of that + 4 % for the 192-row forms; fixed = 7 us (launch ramp, first DMA latency, address
-//   set-up, drain) + the output tile at ~34 GB/s per CU (the store tail is issue-bound, 16 bytes per lane);
-//   two-stage kernel (two workgroups share a CU): kt = 0.83, fixed = 11.8.
-// 192-row tiles (round 5): 76-grid 128->256 482 tiles = 1.88 rounds instead of 1,444 128x128 tiles in 2.82 rounds of pairs,
-// 38-grid 256->512 242 tiles (95 % of the CUs) instead of 182 (71 %), 19-grid 512->1024 248 instead of 184.
-// (experiments build: Y3_BF16X_TILE=A|B|C|D|E forces one where it applies, tools/layer_profile.py)
+// quantises over the 256 CUs and what a tile costs besides its K-tiles.  Fitted to the per-layer measurements with every
+// tile forced in turn (profiles/r05_bf16_tiles.txt; S = 9 * Cin / 64 K-tiles per output tile):
+//     time = ceil(tiles / slots) * (S * kt + fixed)
+//   A 256x256: kt 1.58 us, fixed 12.6 | D 192x256: 1.48, 8.9 | B 256x128: 0.965, 7.7  (one workgroup per CU; fixed = launch
+//   ramp, first DMA latency, address set-up, and the output tile leaving through an issue-bound store tail);
+//   E 192x128 (80 KB of LDS, 104 registers: TWO workgroups per CU): a lone tile 1.0 us per K-tile, a pair 1.875 for both,
+//   and one's prologue / epilogue under the other's K-loop: fixed ~1 us;
+//   C 128x128 two-stage kernel (two per CU): 0.876 per pair and K-tile, fixed 10.8.
+// 192-row tiles (round 5): 76-grid 128->256 482 tiles = 1.88 rounds instead of 1,444 128x128 tiles in 2.82 rounds of pairs
+// (83 -> 70 us), 38-grid 256->512 242 tiles (95 % of the CUs) instead of 182 (70 -> 62 us), 19-grid 512->1024 248 instead of
+// 184 (82 -> 72 us), 152-grid 64->128 1,926 pairs-of-E instead of 2,888 128x128 tiles (105 -> 82 us).
+// (experiments build: Y3_BF16X_TILE=A|B|C|D|E forces one where it applies, tools/layer_profile.py, tools/r05_c5.sh)
 int forced_tile() {
     static int v = -2;
     if (v == -2) {
@@ -720,14 +723,14 @@ int forced_tile() {
     return v;
 }
 
-struct TileCand { int bm, bn, slots; float kt, fixed; };
+struct TileCand { int bm, bn, slots; float kt, fixed, kt_lone; };   // kt_lone: per K-tile when at most one tile per CU runs
 // index = tile letter - 'A'
 constexpr TileCand kTiles[5] = {
-    {256, 256, 256, 1.61f, 7.f + 3.9f},
-    {256, 128, 256, 0.98f, 7.f + 1.95f},
-    {128, 128, 512, 0.83f, 11.8f},
-    {192, 256, 256, 1.61f * 0.75f * 1.04f, 7.f + 2.9f},
-    {192, 128, 256, 0.98f * 0.75f * 1.04f, 7.f + 1.5f},
+    {256, 256, 256, 1.58f, 12.6f, 1.58f},
+    {256, 128, 256, 0.965f, 7.7f, 0.965f},
+    {128, 128, 512, 0.876f, 10.8f, 0.6f},
+    {192, 256, 256, 1.48f, 8.9f, 1.48f},
+    {192, 128, 512, 1.875f, 1.0f, 1.0f},
 };
 
 int choose_tile(long long M, int cout, int S) {
@@ -738,8 +741,8 @@ int choose_tile(long long M, int cout, int S) {
         if (c.bn > 128 && cout < 256) continue;         // a 256-column tile needs at least 256 output channels
         const long long tiles = ((M + c.bm - 1) / c.bm) * ((cout + c.bn - 1) / c.bn);
         const long long rounds = (tiles + c.slots - 1) / c.slots;
-        const float est = (float)rounds * ((float)S * c.kt + c.fixed);
-        if (t == 0 || best_t == 0.f || est < best_t) { best = t; best_t = est; }
+        const float est = (float)rounds * ((float)S * (tiles <= 256 ? c.kt_lone : c.kt) + c.fixed);
+        if (best_t == 0.f || est < best_t) { best = t; best_t = est; }
     }
     return best;
 }
