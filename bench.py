@@ -918,10 +918,11 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                                                 'f32_bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
     bound_ms = np.maximum(nbytes / (PEAK_HBM_TBPS * 1e12), issued / (peak * 1e12)) * 1e3      # per layer
     traffic, traffic_src = (None, None) if split else traffic_from_profile(
-        ['r04_pmc_traffic_bf16.json', 'r03_pmc_traffic_bf16.json'] if bf16 else
-        ['r04_pmc_traffic_wino.json', 'r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
-    kernel = ("conv_bf16x_kernel / conv_bf16p_kernel (3x3 implicit-GEMM convs with Cout > 64 on LDS-DMA staged 128x128 / "
-              "256x128 / 256x256 tiles, bf16 storage; see DESIGN.md)" if bf16 else
+        ['r05_pmc_traffic_bf16.json', 'r04_pmc_traffic_bf16.json', 'r03_pmc_traffic_bf16.json'] if bf16 else
+        ['r05_pmc_traffic_wino.json', 'r04_pmc_traffic_wino.json', 'r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
+    kernel = ("conv_bf16p_kernel / conv_bf16x_kernel (3x3 implicit-GEMM convs with Cout > 64, bf16 storage, LDS-DMA staged: "
+              "the pipelined kernel on 192x256 / 192x128 tiles where the library's tile model picks them - the 76-, 38- and "
+              "19-grid layers at this size -, 256-row and 128x128 tiles elsewhere; see DESIGN.md 4.9)" if bf16 else
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else
@@ -959,8 +960,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                                               getattr(model, 'inference_streams_timing', {}).items()} or None,
                    "streams_note": ("the batch runs as %d equal parts on %d HIP streams of the GPU (north star: independent per-GPU "
                                     "streams for inference; one part's kernel tails and partly filled rounds of workgroups are "
-                                    "filled by the other's kernels: A/B in one process 10.87 -> 10.33 ms for c2, 4.07 -> 3.77 ms for "
-                                    "c5, tools/streams_ab.py; kept only because choose_inference_streams() measured it faster "
+                                    "filled by the other's kernels: A/B in one process 10.87 -> 10.33 ms for c2 (round 4, tools/streams_ab.py; "
+                                    "c5's round-5 tiles fill the CUs with the whole batch and usually keep one stream); kept only because choose_inference_streams() measured it faster "
                                     "than one stream in THIS process before the warm-up); the forwards that carry per-layer hipEvents (every 8th step of "
                                     "the timed region: the `roofline` figures) run on ONE stream, so kernel durations are those "
                                     "of undisturbed launches of the whole batch" % (model.inference_streams, model.inference_streams))
