@@ -13,7 +13,7 @@ import sys
 from collections import OrderedDict, defaultdict
 
 CONV = ('conv_wino', 'conv_mfma_f32_kernel', 'conv_stem_kernel', 'conv_mfma_bf16_kernel', 'conv_bf16x_kernel',
-        'conv_bf16p_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel')
+        'conv_bf16p_kernel', 'conv1x1_bf16r_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel')
 
 
 def load(path):
