@@ -174,6 +174,7 @@ def test_configs4_bs16_608_boxes_scores_and_nms_track_the_fp32_oracle(gpu_model,
         return iw * ih / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - iw * ih)
 
     fracs = []
+    gt_dict, val_preds = {}, []        # the fp32 oracle's detections as ground truth, the bf16 path's as predictions
     for i in range(n):
         b, s, l, idx = (t.cpu().numpy() for t in out[i])
         ob, osc, ol, oi = nms_ref.c_per_class('tf', gb[i], gs[i], 80, 100, thr, 0.45)
@@ -182,6 +183,26 @@ def test_configs4_bs16_608_boxes_scores_and_nms_track_the_fp32_oracle(gpu_model,
         eb, es, el, ei = nms_ref.c_per_class('tf', rb[i], rs[i], 80, 100, thr, 0.45)
         hit = sum(1 for k in range(len(el)) if any(l[j] == el[k] and iou(b[j], eb[k]) >= 0.7 for j in range(len(l))))
         fracs.append(hit / float(max(len(el), 1)))
+        gt_dict[i] = [[float(v) for v in eb[k]] + [int(el[k])] for k in range(len(el))]
+        val_preds += [[i] + [float(v) for v in b[j]] + [float(s[j]), int(l[j])] for j in range(len(l))]
     print('bs=16 @608 bf16: oracle detections recovered (same class, IoU >= 0.7): mean %.3f, worst image %.3f'
           % (float(np.mean(fracs)), float(np.min(fracs))))
     assert float(np.mean(fracs)) >= 0.8
+    # The same comparison in the reference's own accuracy metric (eval.py:61-75: VOC AP per class, mean over the classes;
+    # utils/eval_utils.py voc_eval): what storing activations and weights in bf16 costs in mAP when the fp32 path's detections
+    # are taken as the truth (synthetic weights: ~150 detections per image, none of them confident - a hard case for a
+    # rounding error to keep the ranking).  Printed and gated.
+    import contextlib
+    import io
+    from yolov3_tensorflow_amd.utils import eval_utils
+    for thres, floor in ((0.5, 0.82), (0.75, 0.78)):       # measured 0.860 / 0.838 (deterministic)
+        aps = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for c in range(80):
+                npos, nd, rec, prec, ap = eval_utils.voc_eval(gt_dict, val_preds, c, iou_thres=thres)
+                if npos >= 1:
+                    aps.append(float(ap))
+        m = float(np.mean(aps))
+        print('bs=16 @608 bf16: mAP@%.2f of the bf16 detections against the fp32 oracle\'s (VOC AP, %d classes): %.3f'
+              % (thres, len(aps), m))
+        assert m >= floor
