@@ -127,8 +127,10 @@ int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const floa
  * out_f32 != 0 writes fp32 (used for the detection convs so that decode/NMS are unchanged).  The Cin==3 stem
  * takes the fp32 image and the fp32 HWIO kernel and writes bf16.
  * w_packed (k*k*cin*cout bf16) is OPAQUE: y3_pack_conv_weights_bf16 chooses the layout from (k, cin) -
- * [tap][cin/64][cout][64] for the 3x3 convs with cin % 64 == 0, [tap][cin/32][cout][32] otherwise - and
- * y3_conv2d_fwd_bf16 assumes the same rule. */
+ * [tap][cin/64][cout][64] for the 3x3 convs with cin % 64 == 0 and (round 5) for the 1x1 convs with cin >= 512 and
+ * cin % 64 == 0, [tap][cin/32][cout][32] otherwise - and y3_conv2d_fwd_bf16 assumes the same rule.  (Kernels behind it:
+ * csrc/y3_conv_bf16x.hip - LDS-DMA 3x3 convs, tile shape per launch from a fitted cost model -, csrc/y3_conv_bf16r.hip - the
+ * persistent ring kernel of the deep 1x1 convs -, csrc/y3_conv_bf16.hip - the register-staged kernel of the others.) */
 int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, void* w_packed);
 int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);
