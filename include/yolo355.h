@@ -135,6 +135,15 @@ int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, 
 int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 
+/* The first two convs of darknet53_body in one launch (utils/layer_utils.py:34-40: conv2d(inputs, 32, 3) and
+ * conv2d(net, 64, 3, strides=2), each with folded batch norm and LeakyReLU), bf16 storage: x = the fp32 image [n,h,w,3],
+ * w0_hwio = the stem's fp32 HWIO kernel [3][3][3][32], w1_packed = the second conv's kernel from y3_pack_conv_weights_bf16
+ * (k = 3, cin = 32, cout = 64), y = bf16 [n,h/2,w/2,64].  The stem's output exists only in the LDS; both convs accumulate
+ * in fp32 on the bf16 matrix pipe (the image is rounded to bf16 like every other activation of this path).  h and w even.
+ * y3_net_forward (dtype 1) uses it for its layers 0 and 1. */
+int y3_conv2d_fwd_bf16_stem_s2(y3_ctx* ctx, int n, int h, int w, const float* x, const float* w0_hwio, const float* scale0,
+                               const float* shift0, const void* w1_packed, const float* scale1, const float* shift1, void* y);
+
 /* ---- Winograd F(2x2,3x3) form of the stride-1 3x3 conv (exact fp32 arithmetic, 2.25x fewer multiplies) ------------
  * Same tensors and epilogue as y3_conv2d_fwd (utils/layer_utils.py:9-22,25-32) for the convs
  * y3_conv_wino_eligible accepts (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0,

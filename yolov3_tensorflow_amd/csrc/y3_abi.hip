@@ -451,6 +451,17 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
     // every stream-K layer polls its own pre-zeroed flag region: ONE memset per forward instead of one per launch
     unsigned* flag_base = reinterpret_cast<unsigned*>(base + net->arena_bytes + net->scratch_bytes);
     if (net->flags_bytes) Y3_CHECK_HIP(hipMemsetAsync(flag_base, 0, net->flags_bytes, st));
+    // bf16 storage: the stem and the stride-2 conv behind it run as ONE kernel when nothing else reads the stem's output
+    // (y3_conv_bf16s.hip: the 378 MB tensor between them at 608x608, bs=16 never exists)
+    bool fuse01 = false;
+    if (net->dtype == 1 && nl >= 2) {
+        const Layer &l0 = net->layers[0], &l1 = net->layers[1];
+        y3_conv_desc d0 = {n, h, w, l0.cin, l0.c_up, l0.cout, l0.k, l0.stride, l0.act};
+        y3_conv_desc d1 = {n, h / net->tensors[l1.src].sdiv, w / net->tensors[l1.src].sdiv, l1.cin, l1.c_up, l1.cout, l1.k,
+                           l1.stride, l1.act};
+        fuse01 = l0.src == 0 && l1.src == l0.dst && net->tensors[l0.dst].last_use == 1 && net->tensors[l0.dst].ext < 0 &&
+                 l0.resid < 0 && l1.resid < 0 && net->tensors[l1.dst].ext < 0 && y3_conv_bf16_stem_s2_takes(&d0, &d1) == 1;
+    }
     for (size_t i = 0; i < nl; ++i) {
         const Layer& l = net->layers[i];
         const Tensor& in = net->tensors[l.src];
@@ -460,6 +471,17 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         y3_sk_opts o;
         o.err = net->ctx->err_host;
         o.flags = net->flags_bytes ? flag_base + i * y3_net::FLAG_WORDS : nullptr;
+        if (fuse01 && i <= 1) {
+            int rc = Y3_OK;
+            if (i == 1) {
+                const Layer& l0 = net->layers[0];
+                rc = y3_launch_conv_bf16_stem_s2(st, n, h, w, x, l0.w, l0.scale, l0.shift, l0.act, l.w, l.scale, l.shift, l.act,
+                                                 ptr(l.dst));
+            }
+            if (rc != Y3_OK) return rc;
+            if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
+            continue;
+        }
         const int rc = net->dtype == 1
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
