@@ -144,6 +144,14 @@ int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const 
 int y3_conv2d_fwd_bf16_stem_s2(y3_ctx* ctx, int n, int h, int w, const float* x, const float* w0_hwio, const float* scale0,
                                const float* shift0, const void* w1_packed, const float* scale1, const float* shift1, void* y);
 
+/* The first residual block of darknet53_body in one launch (utils/layer_utils.py:25-32 res_block(net, 32) on a 64-channel map:
+ * y = x + conv3x3(conv1x1(x)), both convs with folded batch norm and LeakyReLU), bf16 storage: x, y = bf16 [n,h,w,64];
+ * w2_packed / w3_packed = the kernels of the 1x1 (64 -> 32) and the 3x3 (32 -> 64) conv from y3_pack_conv_weights_bf16.  The
+ * 32-channel tensor between the convs exists only in the LDS and x is read once (it is the input AND the shortcut).
+ * y3_net_forward (dtype 1) uses it for its layers 2 and 3. */
+int y3_resblock64_fwd_bf16(y3_ctx* ctx, int n, int h, int w, const void* x, const void* w2_packed, const float* scale2,
+                           const float* shift2, const void* w3_packed, const float* scale3, const float* shift3, void* y);
+
 /* ---- Winograd F(2x2,3x3) form of the stride-1 3x3 conv (exact fp32 arithmetic, 2.25x fewer multiplies) ------------
  * Same tensors and epilogue as y3_conv2d_fwd (utils/layer_utils.py:9-22,25-32) for the convs
  * y3_conv_wino_eligible accepts (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0,

@@ -119,6 +119,41 @@ def test_bf16_fused_stem_and_stride2_conv(n, h, w):
     print('fused stem + stride-2 conv %dx%dx%d: max |d| %.3e (max |ref| %.2f), mean |d| %.3e' % (n, h, w, err.max(), np.abs(want).max(), err.mean()))
 
 
+@pytest.mark.parametrize('n,h,w', [(2, 32, 48), (1, 35, 19), (3, 16, 16), (1, 304, 304)])
+def test_bf16_fused_first_residual_block(n, h, w):
+    """res_block(net, 32) on a 64-channel map as one kernel (y3_resblock64_fwd_bf16, csrc/y3_conv_bf16b.hip) against fp64
+    convolutions of the same bf16-rounded operands, the 32-channel tensor rounded to bf16 in between as the kernel does
+    (utils/layer_utils.py:25-32).  Maps that are no multiple of the 16 x 16 tile, several images, the bench's own size."""
+    from yolov3_tensorflow_amd import framework as fw, _lib
+    dev = fw.default_device()
+    L, ctx = _lib.lib(), fw.context()
+    rng = np.random.RandomState(h * 5 + w)
+    x = bf16_round(rng.standard_normal((n, h, w, 64)))
+    w2 = bf16_round(rng.standard_normal((1, 1, 64, 32)) * np.sqrt(2.0 / 64))
+    w3 = bf16_round(rng.standard_normal((3, 3, 32, 64)) * np.sqrt(2.0 / 288))
+    sc2, sh2 = rng.uniform(0.5, 1.5, 32).astype(np.float32), rng.normal(0, 0.2, 32).astype(np.float32)
+    sc3, sh3 = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(0, 0.2, 64).astype(np.float32)
+    mid = bf16_round(ref_conv(x, w2, sc2, sh2, 1, 1, True))
+    want = ref_conv(mid, w3, sc3, sh3, 3, 1, True, x)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    w2g, w3g = t(w2), t(w3)
+    w2p = torch.empty(64 * 32, dtype=torch.bfloat16, device=dev)
+    w3p = torch.empty(9 * 64 * 32, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.y3_pack_conv_weights_bf16(ctx, fw.ptr(w2g), 1, 64, 32, fw.ptr(w2p)))
+    _lib.check(L.y3_pack_conv_weights_bf16(ctx, fw.ptr(w3g), 3, 32, 64, fw.ptr(w3p)))
+    xg = t(x).to(torch.bfloat16).contiguous()
+    y = torch.empty((n, h, w, 64), dtype=torch.bfloat16, device=dev)
+    a2, b2, a3, b3 = t(sc2), t(sh2), t(sc3), t(sh3)
+    _lib.check(L.y3_resblock64_fwd_bf16(ctx, n, h, w, fw.ptr(xg), fw.ptr(w2p), fw.ptr(a2), fw.ptr(b2), fw.ptr(w3p),
+                                        fw.ptr(a3), fw.ptr(b3), fw.ptr(y)))
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - want)
+    tol = 2.0 ** -7 * np.abs(want) + 2e-2
+    assert (err <= tol).all(), (float(err.max()), float(np.abs(want).max()))
+    print('fused residual block %dx%dx%d: max |d| %.3e (max |ref| %.2f), mean |d| %.3e' % (n, h, w, err.max(), np.abs(want).max(), err.mean()))
+
+
 @pytest.mark.parametrize('size', [416, 608])
 def test_bf16_forward_tracks_the_fp32_oracle(gpu_model, size):
     """configs[4] (608x608 bf16 storage) and the 416 size: the deviation from the fp32 oracle is GATED, not just

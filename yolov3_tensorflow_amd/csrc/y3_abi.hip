@@ -462,6 +462,18 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         fuse01 = l0.src == 0 && l1.src == l0.dst && net->tensors[l0.dst].last_use == 1 && net->tensors[l0.dst].ext < 0 &&
                  l0.resid < 0 && l1.resid < 0 && net->tensors[l1.dst].ext < 0 && y3_conv_bf16_stem_s2_takes(&d0, &d1) == 1;
     }
+    // ... and the first residual block (layers 2 and 3: 1x1 64 -> 32, 3x3 32 -> 64 + shortcut) likewise (y3_conv_bf16b.hip)
+    bool fuse23 = false;
+    if (net->dtype == 1 && nl >= 4) {
+        const Layer &l2 = net->layers[2], &l3 = net->layers[3];
+        const int sd = net->tensors[l2.src].sdiv;
+        y3_conv_desc d2 = {n, h / sd, w / sd, l2.cin, l2.c_up, l2.cout, l2.k, l2.stride, l2.act};
+        y3_conv_desc d3 = {n, h / net->tensors[l3.src].sdiv, w / net->tensors[l3.src].sdiv, l3.cin, l3.c_up, l3.cout, l3.k,
+                           l3.stride, l3.act};
+        fuse23 = l3.src == l2.dst && l3.resid == l2.src && l2.resid < 0 && l2.src != 0 && net->tensors[l2.dst].last_use == 3 &&
+                 net->tensors[l2.dst].ext < 0 && net->tensors[l3.dst].ext < 0 && net->tensors[l2.src].ext < 0 &&
+                 y3_conv_bf16_resblock64_takes(&d2, &d3) == 1;
+    }
     for (size_t i = 0; i < nl; ++i) {
         const Layer& l = net->layers[i];
         const Tensor& in = net->tensors[l.src];
@@ -471,6 +483,18 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
         y3_sk_opts o;
         o.err = net->ctx->err_host;
         o.flags = net->flags_bytes ? flag_base + i * y3_net::FLAG_WORDS : nullptr;
+        if (fuse23 && (i == 2 || i == 3)) {
+            int rc = Y3_OK;
+            if (i == 3) {
+                const Layer& l2 = net->layers[2];
+                const int sd = net->tensors[l2.src].sdiv;
+                rc = y3_launch_conv_bf16_resblock64(st, n, h / sd, w / sd, ptr(l2.src), l2.w, l2.scale, l2.shift, l2.act, l.w,
+                                                    l.scale, l.shift, l.act, ptr(l.dst));
+            }
+            if (rc != Y3_OK) return rc;
+            if (ev) Y3_CHECK_HIP(hipEventRecord(ev[i + 1], st));
+            continue;
+        }
         if (fuse01 && i <= 1) {
             int rc = Y3_OK;
             if (i == 1) {

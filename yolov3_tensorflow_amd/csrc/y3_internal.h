@@ -98,6 +98,11 @@ int y3_conv_bf16_stem_s2_takes(const y3_conv_desc* d0, const y3_conv_desc* d1);
 int y3_launch_conv_bf16_stem_s2(hipStream_t stream, int n, int h, int w, const float* x, const float* w0, const float* scale0,
                                 const float* shift0, int act0, const void* w1_packed, const float* scale1, const float* shift1,
                                 int act1, void* y);
+// bf16 path: the first residual block (1x1 64 -> 32, 3x3 32 -> 64, + shortcut) in one kernel (y3_conv_bf16b.hip)
+int y3_conv_bf16_resblock64_takes(const y3_conv_desc* d2, const y3_conv_desc* d3);
+int y3_launch_conv_bf16_resblock64(hipStream_t stream, int n, int h, int w, const void* x, const void* w2_packed,
+                                   const float* scale2, const float* shift2, int act2, const void* w3_packed, const float* scale3,
+                                   const float* shift3, int act3, void* y);
 // persistent LDS-DMA ring kernel for the bf16 1x1 convs (y3_conv_bf16r.hip); weights in the bf16x packing with one tap
 int y3_conv_bf16r_takes(int k, int cin);
 int y3_launch_conv_bf16r(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
