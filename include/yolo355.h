@@ -121,6 +121,14 @@ int y3_conv2d_fwd(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const floa
                   const float* w, const float* scale, const float* shift, const float* residual,
                   float* y, void* workspace, size_t workspace_bytes);
 
+/* The first two convs of darknet53_body in one launch (utils/layer_utils.py:34-40: conv2d(inputs, 32, 3) and
+ * conv2d(net, 64, 3, strides=2), each with folded batch norm and LeakyReLU), exact fp32 arithmetic: x = the image [n,h,w,3],
+ * w0_hwio = the stem's HWIO kernel [3][3][3][32], w1_packed = the second conv's kernel from y3_pack_conv_weights (k = 3,
+ * cin = 32, cout = 64), y = [n,h/2,w/2,64].  The stem's output - the largest tensor of the network - exists only in the LDS.
+ * h and w even.  y3_net_forward (dtypes 0 and 4) uses it for its layers 0 and 1. */
+int y3_conv2d_fwd_stem_s2(y3_ctx* ctx, int n, int h, int w, const float* x, const float* w0_hwio, const float* scale0,
+                          const float* shift0, const float* w1_packed, const float* scale1, const float* shift1, float* y);
+
 /* ---- bf16 storage / fp32 accumulate variant (BASELINE configs[4]: 608x608 bf16 inference) -----------------
  * Same contract as y3_conv2d_fwd (utils/layer_utils.py:9-22) with bf16 (round-to-nearest-even) activations, residual
  * and packed weights; scale/shift stay fp32; the accumulator is fp32; ONE rounding to bf16 at the store.

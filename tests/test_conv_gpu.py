@@ -350,3 +350,29 @@ def test_streamk_timeout_is_loud():
             fw.check_context()                         # never leave the session's context poisoned for later tests
         except _lib.Y3Error:
             pass
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 64, 96), (1, 70, 38), (3, 32, 32), (2, 416, 416)])
+def test_fused_stem_and_stride2_conv(n, h, w):
+    """The stem and the stride-2 conv behind it in one kernel (y3_conv2d_fwd_stem_s2, csrc/y3_conv_f32s.hip; what y3_net_forward
+    runs for layers 0 and 1 in the fp32 modes) against the fp64 reference of the two convs (utils/layer_utils.py:34-40), at the
+    tolerance of the separate kernels.  Maps that are no multiple of the 8 x 16 tile, several images, the bench's own size."""
+    from yolov3_tensorflow_amd import framework as fw, _lib
+    dev = fw.default_device()
+    L, ctx = _lib.lib(), fw.context()
+    rng = np.random.RandomState(h * 7 + w)
+    x = rng.uniform(0, 1, (n, h, w, 3)).astype(np.float32)
+    _, w0, sc0, sh0 = make_case(rng, 1, 1, 1, 3, 3, 32)
+    _, w1, sc1, sh1 = make_case(rng, 1, 1, 1, 3, 32, 64)
+    mid = ref_conv(x, w0, sc0, sh0, 3, 1, True)
+    want = ref_conv(mid.astype(np.float64), w1, sc1, sh1, 3, 2, True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    w1g = t(w1)
+    w1p = torch.empty(9 * 64 * 32, device=dev)
+    _lib.check(L.y3_pack_conv_weights(ctx, fw.ptr(w1g), 3, 32, 64, fw.ptr(w1p)))
+    y = torch.empty((n, h // 2, w // 2, 64), device=dev)
+    xg, w0g, a0, b0, a1, b1 = t(x), t(w0), t(sc0), t(sh0), t(sc1), t(sh1)
+    _lib.check(L.y3_conv2d_fwd_stem_s2(ctx, n, h, w, fw.ptr(xg), fw.ptr(w0g), fw.ptr(a0), fw.ptr(b0), fw.ptr(w1p), fw.ptr(a1),
+                                       fw.ptr(b1), fw.ptr(y)))
+    torch.cuda.synchronize()
+    check(y.cpu().numpy(), want, 'fused stem + stride-2 conv %dx%dx%d' % (n, h, w))

@@ -77,6 +77,8 @@ PROTOTYPES = {
                                    c_void_p, c_void_p, c_int]),
     "y3_conv2d_fwd_bf16_stem_s2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
+    "y3_conv2d_fwd_stem_s2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
     "y3_resblock64_fwd_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "y3_net_train_workspace_bytes": (c_size_t, [c_void_p, POINTER(TrainVar), c_int, c_int, c_int]),

@@ -18,6 +18,7 @@ SOURCES = [
     ("y3_abi.hip", []),
     ("y3_net_train.hip", []),
     ("y3_conv.hip", []),
+    ("y3_conv_f32s.hip", []),
     ("y3_conv_bf16.hip", []),
     ("y3_conv_bf16x.hip", []),
     ("y3_conv_bf16r.hip", []),
@@ -96,7 +97,7 @@ def needs_build():
 # into libyolo355_exp.so, the library tools/ A/B runs and tests/test_conv_variants_gpu.py select with Y3_LIB_PATH.
 # The product library reads no environment variable.
 EXP_LIB = os.path.join(CSRC, "libyolo355_exp.so")
-EXP_SOURCES = ("y3_conv.hip", "y3_conv_bf16x.hip", "y3_conv_bf16r.hip", "y3_conv_bf16s.hip", "y3_conv_bf16b.hip", "y3_conv_split.hip", "y3_conv_wino.hip", "y3_conv_wino44.hip",
+EXP_SOURCES = ("y3_conv.hip", "y3_conv_f32s.hip", "y3_conv_bf16x.hip", "y3_conv_bf16r.hip", "y3_conv_bf16s.hip", "y3_conv_bf16b.hip", "y3_conv_split.hip", "y3_conv_wino.hip", "y3_conv_wino44.hip",
                "y3_wgrad.hip")
 
 

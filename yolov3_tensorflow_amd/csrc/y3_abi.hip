@@ -453,14 +453,17 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
     if (net->flags_bytes) Y3_CHECK_HIP(hipMemsetAsync(flag_base, 0, net->flags_bytes, st));
     // bf16 storage: the stem and the stride-2 conv behind it run as ONE kernel when nothing else reads the stem's output
     // (y3_conv_bf16s.hip: the 378 MB tensor between them at 608x608, bs=16 never exists)
+    // (fp32, dtypes 0 and 4 - both run these two layers on the direct kernels -: the same fusion, y3_conv_f32s.hip)
     bool fuse01 = false;
-    if (net->dtype == 1 && nl >= 2) {
+    const bool f32_direct01 = net->dtype == 0 || net->dtype == 4;
+    if ((net->dtype == 1 || f32_direct01) && nl >= 2) {
         const Layer &l0 = net->layers[0], &l1 = net->layers[1];
         y3_conv_desc d0 = {n, h, w, l0.cin, l0.c_up, l0.cout, l0.k, l0.stride, l0.act};
         y3_conv_desc d1 = {n, h / net->tensors[l1.src].sdiv, w / net->tensors[l1.src].sdiv, l1.cin, l1.c_up, l1.cout, l1.k,
                            l1.stride, l1.act};
         fuse01 = l0.src == 0 && l1.src == l0.dst && net->tensors[l0.dst].last_use == 1 && net->tensors[l0.dst].ext < 0 &&
-                 l0.resid < 0 && l1.resid < 0 && net->tensors[l1.dst].ext < 0 && y3_conv_bf16_stem_s2_takes(&d0, &d1) == 1;
+                 l0.resid < 0 && l1.resid < 0 && net->tensors[l1.dst].ext < 0 &&
+                 (net->dtype == 1 ? y3_conv_bf16_stem_s2_takes(&d0, &d1) : y3_conv_f32_stem_s2_takes(&d0, &d1)) == 1;
     }
     // ... and the first residual block (layers 2 and 3: 1x1 64 -> 32, 3x3 32 -> 64 + shortcut) likewise (y3_conv_bf16b.hip)
     bool fuse23 = false;
@@ -499,7 +502,10 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
             int rc = Y3_OK;
             if (i == 1) {
                 const Layer& l0 = net->layers[0];
-                rc = y3_launch_conv_bf16_stem_s2(st, n, h, w, x, l0.w, l0.scale, l0.shift, l0.act, l.w, l.scale, l.shift, l.act,
+                rc = net->dtype == 1
+                    ? y3_launch_conv_bf16_stem_s2(st, n, h, w, x, l0.w, l0.scale, l0.shift, l0.act, l.w, l.scale, l.shift, l.act,
+                                                  ptr(l.dst))
+                    : y3_launch_conv_f32_stem_s2(st, n, h, w, x, l0.w, l0.scale, l0.shift, l0.act, l.w, l.scale, l.shift, l.act,
                                                  ptr(l.dst));
             }
             if (rc != Y3_OK) return rc;

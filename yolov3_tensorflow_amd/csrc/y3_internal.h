@@ -93,6 +93,11 @@ int y3_conv_bf16x_takes(int k, int cin);
 int y3_launch_pack_bf16x(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, void* w_packed);
 int y3_launch_conv_bf16x(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                          const float* scale, const float* shift, const void* residual, void* y, int out_f32);
+// fp32 path: the 3 -> 32 stem and the stride-2 32 -> 64 conv behind it in one kernel (y3_conv_f32s.hip)
+int y3_conv_f32_stem_s2_takes(const y3_conv_desc* d0, const y3_conv_desc* d1);
+int y3_launch_conv_f32_stem_s2(hipStream_t stream, int n, int h, int w, const float* x, const float* w0, const float* scale0,
+                               const float* shift0, int act0, const float* w1_packed, const float* scale1, const float* shift1,
+                               int act1, float* y);
 // bf16 path: the 3 -> 32 stem and the stride-2 32 -> 64 conv behind it in one kernel (y3_conv_bf16s.hip)
 int y3_conv_bf16_stem_s2_takes(const y3_conv_desc* d0, const y3_conv_desc* d1);
 int y3_launch_conv_bf16_stem_s2(hipStream_t stream, int n, int h, int w, const float* x, const float* w0, const float* scale0,
