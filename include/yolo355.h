@@ -140,6 +140,10 @@ int y3_conv2d_fwd_stem_s2(y3_ctx* ctx, int n, int h, int w, const float* x, cons
  * csrc/y3_conv_bf16x.hip - LDS-DMA 3x3 convs, tile shape per launch from a fitted cost model -, csrc/y3_conv_bf16r.hip - the
  * persistent ring kernel of the deep 1x1 convs -, csrc/y3_conv_bf16.hip - the register-staged kernel of the others.) */
 int y3_pack_conv_weights_bf16(y3_ctx* ctx, const float* w_hwio, int k, int cin, int cout, void* w_packed);
+/* Host-only: which tile shape y3_conv2d_fwd_bf16 runs this launch on - 'A' 256x256, 'B' 256x128, 'C' 128x128, 'D' 192x256, 'E'
+ * 192x128 (3x3 convs, csrc/y3_conv_bf16x.hip); 'a'..'g' (the 1x1 ring kernel, csrc/y3_conv_bf16r.hip); 'x' narrow 3x3 forms; 'o'
+ * the register-staged kernel; 's' the stem.  Documentation of the dispatch, not needed to call anything. */
+int y3_conv_bf16_tile(const y3_conv_desc* d);
 int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                        const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 

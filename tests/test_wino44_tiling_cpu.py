@@ -102,3 +102,26 @@ def test_mosaic_is_used_where_it_saves_tiles_and_the_library_agrees():
         assert t <= n * ((h + 3) // 4) * ((w + 3) // 4)
         assert blocks(n, h, w) == (t + 15) // 16, (n, h, w)
     assert blocks(2, 13, 13, cin=48) == 0                                              # not an F(4x4) shape
+
+
+def test_bf16_tile_choice_at_configs4():
+    """The tile the bf16 path picks per layer shape at BASELINE configs[4] (608x608, bs=16, and bs=8 = one of two streams): the
+    per-layer measurements of profiles/r05_bf16_tiles.txt as a table, through the library's own dispatch query (host-only ABI call
+    y3_conv_bf16_tile; csrc/y3_conv_bf16x.hip choose_tile, csrc/y3_conv_bf16r.hip dispatch_r)."""
+    import ctypes
+    from yolov3_tensorflow_amd import _lib
+    L = _lib.lib()
+    tile = lambda n, g, k, s, cin, cout: chr(L.y3_conv_bf16_tile(ctypes.byref(_lib.ConvDesc(n, g, g, cin, 0, cout, k, s, 1))))
+    want16 = {   # (grid of the INPUT, k, stride, cin, cout): tile at bs=16
+        (608, 3, 1, 3, 32): 's', (608, 3, 2, 32, 64): 'x', (304, 1, 1, 64, 32): 'o', (304, 3, 1, 32, 64): 'x',
+        (304, 3, 2, 64, 128): 'E', (152, 1, 1, 128, 64): 'o', (152, 3, 1, 64, 128): 'E', (152, 3, 2, 128, 256): 'E',
+        (76, 1, 1, 256, 128): 'o', (76, 3, 1, 128, 256): 'E', (76, 3, 2, 256, 512): 'D', (38, 1, 1, 512, 256): 'd',
+        (38, 3, 1, 256, 512): 'D', (38, 3, 2, 512, 1024): 'E', (19, 1, 1, 1024, 512): 'e', (19, 3, 1, 512, 1024): 'E',
+        (19, 1, 1, 1024, 255): 'f', (38, 1, 1, 768, 256): 'd', (38, 1, 1, 512, 255): 'd', (76, 1, 1, 384, 128): 'o',
+        (76, 1, 1, 256, 255): 'o',
+    }
+    for (g, k, s, cin, cout), t in want16.items():
+        assert tile(16, g, k, s, cin, cout) == t, (g, k, s, cin, cout, tile(16, g, k, s, cin, cout), t)
+    # half the batch (one of two streams): the deep layers move to the tiles that still give ~a tile per CU
+    assert tile(8, 38, 3, 1, 256, 512) == 'E' and tile(8, 19, 3, 1, 512, 1024) == 'E' and tile(8, 38, 1, 1, 512, 256) == 'e'
+    assert tile(8, 19, 1, 1, 1024, 512) == 'f'

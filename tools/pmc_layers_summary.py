@@ -4,7 +4,7 @@
     python tools/pmc_layers_summary.py <out.json> <counter_collection.csv> [<counter_collection.csv> ...]
 
 Every csv holds the same dispatch sequence (same program), so counters of different passes are joined on the ordinal
-of the dispatch among the conv kernels of the LAST forward (75 conv launches: the 75 layers in order).  The calibration
+of the dispatch among the conv kernels of the LAST forward (its launches in layer order: 75, fewer where layers are fused).  The calibration
 copy (largest-grid non-conv dispatch after the warm-up) gives bytes per counter unit for a 16-B/lane streaming kernel.
 """
 import csv
@@ -13,7 +13,10 @@ import sys
 from collections import OrderedDict, defaultdict
 
 CONV = ('conv_wino', 'conv_mfma_f32_kernel', 'conv_stem_kernel', 'conv_mfma_bf16_kernel', 'conv_bf16x_kernel',
-        'conv_bf16p_kernel', 'conv1x1_bf16r_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel')
+        'conv_bf16p_kernel', 'conv1x1_bf16r_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel', 'conv_stem_s2_f32_kernel',
+        'conv_stem_s2_bf16_kernel', 'conv_resblock64_bf16_kernel')
+# the kernels a forward starts with (round 5: the stem may be fused with the conv behind it)
+FIRST = ('conv_stem_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel', 'conv_stem_s2_f32_kernel', 'conv_stem_s2_bf16_kernel')
 
 
 def load(path):
@@ -34,7 +37,10 @@ def main():
     for p in paths:
         seq = load(p)
         convs = [(n, c) for (n, c) in seq if any(k in n for k in CONV)]
-        last = convs[-75:]
+        # the LAST forward: from the last first-layer kernel to the end (75 launches, fewer where layers are fused: the rows
+        # are then launches, in layer order)
+        starts = [i for i, (n, _) in enumerate(convs) if any(k in n for k in FIRST)]
+        last = convs[starts[-1]:] if starts else convs[-75:]
         if layers is None:
             layers = [dict(kernel=n.replace('(anonymous namespace)::', '').replace('y3conv::', '').split('(')[0].replace('void ', '')) for n, _ in last]
         for row, (n, c) in zip(layers, last):

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "y3_conv2d_dgrad_split": (c_int, [c_void_p, POINTER(ConvDesc), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_size_t]),
     "y3_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "y3_conv_bf16_tile": (c_int, [POINTER(ConvDesc)]),
     "y3_conv2d_fwd_bf16": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int]),
     "y3_conv2d_fwd_bf16_stem_s2": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

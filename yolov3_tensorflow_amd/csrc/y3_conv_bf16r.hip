@@ -459,6 +459,17 @@ int y3_conv_bf16r_takes(int k, int cin) {
     if (mode >= 0) return mode;
     return cin >= 512 ? 1 : 0;
 }
+// the tile letter dispatch_r picks for this conv (host-only, see y3_conv_bf16_tile)
+int y3_conv_bf16r_tile(const y3_conv_desc* d) {
+    const long long M = (long long)d->n * d->h * d->w;
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((d->cout + bn - 1) / bn); };
+    if (d->cout <= 32) return 'a';
+    if (d->cout <= 64) return 'b';
+    if (tiles(192, 128) >= 200) return 'd';
+    if (tiles(96, 128) >= 200) return 'e';
+    return 'f';
+}
+
 int y3_launch_conv_bf16r(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                          const float* scale, const float* shift, const void* residual, void* y, int out_f32) {
     const long long M = (long long)d->n * d->h * d->w;

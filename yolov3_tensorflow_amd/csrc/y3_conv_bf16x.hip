@@ -728,7 +728,7 @@ struct TileCand { int bm, bn, slots; float kt, fixed, kt_lone; };   // kt_lone: 
 constexpr TileCand kTiles[5] = {
     {256, 256, 256, 1.58f, 12.6f, 1.58f},
     {256, 128, 256, 0.965f, 7.7f, 0.965f},
-    {128, 128, 512, 0.876f, 10.8f, 0.6f},
+    {128, 128, 512, 0.876f, 10.8f, 0.95f},
     {192, 256, 256, 1.48f, 8.9f, 1.48f},
     {192, 128, 512, 1.875f, 1.0f, 1.0f},
 };
@@ -783,6 +783,21 @@ int y3_conv_bf16x_takes(int k, int cin) {
         off = (e && e[0] == '0') ? 1 : 0;
     }
     return off ? 0 : 1;
+}
+
+// Which tile the bf16 path runs this conv on (host-only; tests/test_host_logic.py holds the configs[4] table against it):
+// 'A'..'E' = the 3x3 tiles above, 'a'..'g' = the ring kernel's tiles, 'x' = the narrow 3x3 forms (Cin = 32 / Cout <= 64), 'o' = the
+// register-staged kernel of y3_conv_bf16.hip, 's' = the Cin = 3 stem
+extern "C" int y3_conv_bf16_tile(const y3_conv_desc* d) {
+    if (!d) return 0;
+    if (d->cin == 3) return 's';
+    if (y3_conv_bf16x_takes(d->k, d->cin)) {
+        if (d->cin % 64 != 0 || d->cout <= 64) return 'x';
+        const long long M = (long long)d->n * (d->h / d->stride) * (d->w / d->stride);
+        return 'A' + choose_tile(M, d->cout, d->k * d->k * (d->cin / 64));
+    }
+    if (y3_conv_bf16r_takes(d->k, d->cin)) return y3_conv_bf16r_tile(d);
+    return 'o';
 }
 
 int y3_launch_pack_bf16x(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, void* w_packed) {

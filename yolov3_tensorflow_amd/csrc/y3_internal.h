@@ -110,6 +110,7 @@ int y3_launch_conv_bf16_resblock64(hipStream_t stream, int n, int h, int w, cons
                                    const float* shift3, int act3, void* y);
 // persistent LDS-DMA ring kernel for the bf16 1x1 convs (y3_conv_bf16r.hip); weights in the bf16x packing with one tap
 int y3_conv_bf16r_takes(int k, int cin);
+int y3_conv_bf16r_tile(const y3_conv_desc* d);
 int y3_launch_conv_bf16r(hipStream_t stream, const y3_conv_desc* d, const void* x, const void* x_up, const void* w,
                          const float* scale, const float* shift, const void* residual, void* y, int out_f32);
 int y3_launch_pack_split(hipStream_t stream, const float* w_hwio, int k, int cin, int cout, int planes, void* out,
