@@ -65,7 +65,11 @@ def test_train_loop_fed_by_the_feeder_keeps_the_resident_step_time(tmp_path, iso
     from yolov3_tensorflow_amd import training
     from yolov3_tensorflow_amd.feeder import Feeder
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
-    bs, steps = 16, 12
+    # six workers: at bs=16 the step is ~29 ms of which the host's ~1,100 kernel launches are a good part, and the pod's cgroup
+    # grants 16 cores - 10 to 32 busy workers take the launching thread's core away (fed 32-36 ms against 29.5 resident, one
+    # call, same box; 29.7 with six, who still feed a batch in 8-11 ms).  At bs=64 the reference's ten workers cost 1 %
+    # (bench.py: c4.fed).
+    bs, steps, workers = 16, 12, 6
     lines = _write_set(tmp_path, bs * (steps + 8), seed=9)
     y3.reset_default_graph()
     model = y3.yolov3(80, COCO_ANCHORS, batch_norm_decay=0.99)
@@ -73,7 +77,7 @@ def test_train_loop_fed_by_the_feeder_keeps_the_resident_step_time(tmp_path, iso
     with y3.variable_scope('yolov3'):
         model.forward(torch.zeros(1, 32, 32, 3))
         trainer = training.Trainer(model, config_optimizer('momentum', 1e-4))
-        feeder = Feeder(lines, bs, 80, [416, 416], COCO_ANCHORS, mode='train', use_mix_up=True, num_threads=32,
+        feeder = Feeder(lines, bs, 80, [416, 416], COCO_ANCHORS, mode='train', use_mix_up=True, num_threads=workers,
                         prefetch=5, seed=2)
         it = feeder.epoch(0)
         first = next(it)
@@ -119,7 +123,7 @@ def test_train_loop_fed_by_the_feeder_keeps_the_resident_step_time(tmp_path, iso
             done, resident, fed, alone = measure(attempt)
             print('train step bs=%d @416: %.1f ms on resident tensors, %.1f ms fed by the feeder (%d threads, prefetch %d): '
                   '%.0f images/s decoded, augmented, resized and uploaded under the steps; the feeder alone: %.1f ms per batch'
-                  % (bs, resident * 1e3, fed * 1e3, 32, 5, bs / fed, alone * 1e3))
+                  % (bs, resident * 1e3, fed * 1e3, workers, 5, bs / fed, alone * 1e3))
             assert done == steps
             if fed <= 1.15 * max(resident, alone) + 2e-3:
                 break
