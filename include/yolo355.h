@@ -347,7 +347,8 @@ int y3_bias_grad(y3_ctx* ctx, const float* dy, long long rows, int c, float* dbi
  * dgrad: dx [n,h,w,cin] (+)= data gradient.  dz is [n,h/s,w/s] x dz_stride channels (dz_stride >= cout,
  *        multiple of 32: the 3*(5+C) detection convs pad to the next multiple), w_d = the HWIO kernel with
  *        its last axis padded to dz_stride ([k*k][cin][dz_stride]); `ones`/`zeros` are [cin] device vectors.
- * wgrad: dw_hwio [k][k][cin][cout] = weight gradient; scratch: y3_conv_wgrad_scratch_bytes(fwd). */
+ * wgrad: dw_hwio [k][k][cin][cout] = weight gradient; scratch: y3_conv_wgrad_scratch_bytes(fwd), 16-byte aligned
+ *        (dw_hwio itself: any 4-byte boundary). */
 int y3_conv2d_dgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride, const float* w_d,
                     const float* ones, const float* zeros, int accumulate, float* dx, void* workspace,
                     size_t workspace_bytes);
@@ -374,7 +375,7 @@ int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const fl
  *   dw = G^T [ sum over 2x2 output tiles of (B^T d B) .* (A dY A^T) ] G,
  * exact fp32 arithmetic with 16/36 of the multiplies of y3_conv_wgrad; results differ from it by a few fp32 roundings
  * per term; deterministic (the tile range is split over workgroups, partial kernels are added in a fixed order).
- * scratch: y3_conv_wgrad_wino_scratch_bytes(fwd). */
+ * scratch: y3_conv_wgrad_wino_scratch_bytes(fwd), 16-byte aligned. */
 int y3_conv_wgrad_wino_eligible(const y3_conv_desc* fwd);
 size_t y3_conv_wgrad_wino_scratch_bytes(const y3_conv_desc* fwd);
 int y3_conv_wgrad_wino(y3_ctx* ctx, const y3_conv_desc* fwd, const float* x, const float* dz, int dz_stride,

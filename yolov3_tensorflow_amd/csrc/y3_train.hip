@@ -102,6 +102,30 @@ __device__ __forceinline__ double block_sum_fixed(const float* __restrict__ part
     return r;
 }
 
+// The same for TWO columns at once (idx0, idx1): each sum is formed in exactly the order block_sum_fixed uses - one pass over
+// the partial rows and one tree instead of two (the finalize kernels are latency-bound: 72 + 72 launches per train step).
+__device__ __forceinline__ void block_sum2_fixed(const float* __restrict__ partial, int nblocks, size_t stride_b, size_t idx0,
+                                                 size_t idx1, double* sh /*[512]*/, double& r0, double& r1) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        s0 += (double)partial[(size_t)b * stride_b + idx0];
+        s1 += (double)partial[(size_t)b * stride_b + idx1];
+    }
+    sh[threadIdx.x] = s0;
+    sh[256 + threadIdx.x] = s1;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sh[threadIdx.x] += sh[threadIdx.x + off];
+            sh[256 + threadIdx.x] += sh[256 + threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    r0 = sh[0];
+    r1 = sh[256];
+}
+
 // BN forward finalize: batch mean / biased variance, folded scale & shift for the apply pass, and the
 // moving-statistics update  moving <- moving*decay + batch*(1-decay)  with the UNBIASED variance going
 // into moving_variance (TF fused batch norm).
@@ -112,10 +136,10 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const float* __r
                                                                 float* __restrict__ scale, float* __restrict__ shift,
                                                                 float* __restrict__ moving_mean,
                                                                 float* __restrict__ moving_var) {
-    __shared__ double sh[256];
+    __shared__ double sh[512];
     const int c = blockIdx.x;   // one workgroup per channel
-    const double s0 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)c, sh);
-    const double s1 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)C + c, sh);
+    double s0, s1;
+    block_sum2_fixed(partial, nblocks, (size_t)2 * C, (size_t)c, (size_t)C + c, sh, s0, s1);
     if (threadIdx.x != 0) return;
     const double mu = s0 / count;
     double var = s1 / count - mu * mu;
@@ -140,10 +164,10 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ inv_std,
                                                               float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                               float* __restrict__ coef /*[3][C]: a, b, c*/) {
-    __shared__ double sh[256];
+    __shared__ double sh[512];
     const int c = blockIdx.x;
-    const double s0 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)c, sh);
-    const double s1 = block_sum_fixed(partial, nblocks, (size_t)2 * C, (size_t)C + c, sh);
+    double s0, s1;
+    block_sum2_fixed(partial, nblocks, (size_t)2 * C, (size_t)c, (size_t)C + c, sh, s0, s1);
     if (threadIdx.x != 0) return;
     if (dbeta) dbeta[c] = (float)s0;
     if (dgamma) dgamma[c] = (float)s1;

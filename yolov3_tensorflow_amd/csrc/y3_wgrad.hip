@@ -196,28 +196,58 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
-// dw[i] = sum over the splits, in a FIXED order: four lanes per element each add every fourth split (four independent
-// accumulators in flight per lane), then (q0 + q1) + (q2 + q3).  64 elements per workgroup.
+// dw = sum over the splits, in a FIXED order: four lanes per element group each add every fourth split, then
+// (q0 + q1) + (q2 + q3).  A lane holds FOUR consecutive elements (n is a multiple of 4: J = k*k*Cin with Cin % 4 == 0, or the
+// stem's 27 x 32; every split starts 16-byte aligned), 64 such groups per workgroup; element by element the same additions
+// in the same order as one float per lane.  `dw` itself may sit at any 4-byte boundary of the caller's flat gradient buffer
+// (a 255-element bias tensor before it): f32x4_u = one dwordx4 store at dword alignment.
 __global__ void __launch_bounds__(256) wgrad_sum_splits_kernel(const float* __restrict__ scratch, int nsplit,
-                                                               long long n, float* __restrict__ dw) {
-    __shared__ float part[4][64];
+                                                               long long n4, float* __restrict__ dw) {
+    __shared__ f32x4 part[4][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(scratch);
+    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
         const long long i = base + e;
-        float s = 0.f;
-        if (i < n)
-            for (int k = q; k < nsplit; k += 4) s += scratch[(size_t)k * n + i];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4)
+            for (int k = q; k < nsplit; k += 4) s += s4[(size_t)k * n4 + i];
         part[q][e] = s;
         __syncthreads();
-        if (q == 0 && i < n) dw[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        if (q == 0 && i < n4)
+            *reinterpret_cast<f32x4_u*>(dw + 4 * i) = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
         __syncthreads();
     }
+}
+
+// The stem's partial tiles: few elements (27 x 32), many splits (one per workgroup of stem_wgrad_kernel, up to 1,280).  One
+// workgroup per kernel row j (32 output channels): lane (co, g) adds the splits k = g, g + 8, ... in order, the eight group
+// sums are added pairwise in a fixed order.  (The general kernel above gave this case four workgroups and 512 dependent
+// loads per lane: 0.66 ms per bs=64 step, profiles/r05_train_c4_kernel_stats.csv.)
+__global__ void __launch_bounds__(256) stem_sum_splits_kernel(const float* __restrict__ part, int nsplit,
+                                                              float* __restrict__ dw) {
+    __shared__ float red[8][32];
+    const int co = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + co;
+    float s0 = 0.f, s1 = 0.f;
+    int k = g;
+    for (; k + 8 < nsplit; k += 16) {                      // two independent chains (k = g mod 16, g + 8 mod 16)
+        s0 += part[(size_t)k * (27 * 32) + e];
+        s1 += part[(size_t)(k + 8) * (27 * 32) + e];
+    }
+    if (k < nsplit) s0 += part[(size_t)k * (27 * 32) + e];
+    red[g][co] = s0 + s1;
+    __syncthreads();
+    if (g == 0)
+        dw[e] = ((red[0][co] + red[1][co]) + (red[2][co] + red[3][co])) + ((red[4][co] + red[5][co]) + (red[6][co] + red[7][co]));
 }
 
 // Stem conv (Cin = 3): D[27][32] = sum over pixels of patch[m][27] * dz[m][32].  One 32x32 MFMA tile
 // (patch rows padded 27 -> 32 with zeros); a workgroup walks its chunk of pixels 128 at a time: the dz rows
 // and the gathered 3x3x3 patches are staged in LDS, each wave accumulates a quarter of the tile's pixels,
-// the four wave accumulators are summed through LDS at the end.
+// the four wave accumulators are summed through LDS at the end.  The loads of tile t + 1 (4 x 16 bytes of dz, 16
+// gathered patch values per thread) are issued before the MFMAs of tile t and held in registers: with "load, stage,
+// barrier, multiply, barrier" per tile a workgroup paid a memory latency per 128 pixels (1.02 ms per bs=64 step for
+// 1.55 GB of x and dz: 1.5 TB/s; round 5).
 __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                          int N, int H, int W, int M, int chunk,
                                                          float* __restrict__ partial /*[grid][27][32]*/) {
@@ -233,35 +263,45 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int m_begin = blockIdx.x * chunk, m_end = min(m_begin + chunk, M);
-    for (int m0 = m_begin; m0 < m_end; m0 += TP) {
+    f32x4 zr[4];
+    float xr[TP / 8];
+    auto load = [&](int m0) {
         // dz rows: 128 x 32 floats, coalesced float4
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;              // float4 index inside the tile
             const int p = e >> 3, c4 = (e & 7) * 4;
             const int m = m0 + p;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) v = *reinterpret_cast<const f32x4*>(dz + (size_t)m * 32 + c4);
-            *reinterpret_cast<f32x4*>(zs + p * 32 + c4) = v;
+            zr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) zr[i] = *reinterpret_cast<const f32x4*>(dz + (size_t)m * 32 + c4);
         }
         // patches: thread owns column j and rows pr0 + 8*i (coordinates advanced incrementally)
-        {
-            int m = m0 + pr0;
-            int n = m / (H * W);
-            int rem = m - n * H * W;
-            int oy = rem / W, ox = rem - oy * W;
-#pragma unroll 4
-            for (int i = 0; i < TP / 8; ++i) {
-                float v = 0.f;
-                const int iy = oy - 1 + ky, ix = ox - 1 + kx;
-                if (j < 27 && m < m_end && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    v = x[((size_t)(n * H + iy) * W + ix) * 3 + ci];
-                xs[(pr0 + 8 * i) * 32 + j] = v;
-                m += 8; ox += 8;
-                if (ox >= W) { ox -= W; if (++oy == H) { oy = 0; ++n; } }
-            }
+        int m = m0 + pr0;
+        int n = m / (H * W);
+        int rem = m - n * H * W;
+        int oy = rem / W, ox = rem - oy * W;
+#pragma unroll
+        for (int i = 0; i < TP / 8; ++i) {
+            float v = 0.f;
+            const int iy = oy - 1 + ky, ix = ox - 1 + kx;
+            if (j < 27 && m < m_end && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = x[((size_t)(n * H + iy) * W + ix) * 3 + ci];
+            xr[i] = v;
+            m += 8; ox += 8;
+            if (ox >= W) { ox -= W; if (++oy == H) { oy = 0; ++n; } }
         }
+    };
+    if (m_begin < m_end) load(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += TP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(zs + (e >> 3) * 32 + (e & 7) * 4) = zr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < TP / 8; ++i) xs[(pr0 + 8 * i) * 32 + j] = xr[i];
         __syncthreads();
+        if (m0 + TP < m_end) load(m0 + TP);       // in flight under this tile's MFMAs (and the other workgroups of the CU)
         // wave w: pixels [32w, 32w+32) -> 16 MFMAs of k = 2 pixels
         const float* as = xs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
         const float* bs = zs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
@@ -339,6 +379,7 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     Y3_CHECK_ARG(d->c_up == 0, "y3_conv_wgrad: fused upsample+concat inputs are not supported (materialise the concat)");
     Y3_CHECK_ARG(dz_stride >= d->cout && dz_stride % 4 == 0, "y3_conv_wgrad: dz row stride must be >= Cout and a multiple of 4");
     Y3_CHECK_ARG(scratch_bytes >= y3_conv_wgrad_scratch_bytes(d), "y3_conv_wgrad: scratch too small");
+    Y3_CHECK_ARG((reinterpret_cast<size_t>(scratch) & 15) == 0, "y3_conv_wgrad: scratch must be 16-byte aligned");
     const int Ho = d->h / d->stride, Wo = d->w / d->stride;
     const long long M = (long long)d->n * Ho * Wo;
     Y3_CHECK_ARG((long long)d->n * d->h * d->w * d->cin < (1LL << 29) && M * dz_stride < (1LL << 29),
@@ -347,15 +388,16 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && dz_stride == 32,
                      "y3_conv_wgrad: Cin=3 is supported only as the 3x3 3->32 stem conv");
+        // one round of co-resident workgroups (32 KB of LDS each: five per CU)
         int nblk = (int)((M + 4095) / 4096);
-        if (nblk > 2048) nblk = 2048;
+        if (nblk > 1280) nblk = 1280;
         const int chunk = (int)(((M + nblk - 1) / nblk + 127) / 128 * 128);   // multiple of the 128-pixel tile
         nblk = (int)((M + chunk - 1) / chunk);
         float* part = static_cast<float*>(scratch);
         hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dz, d->n, d->h, d->w, (int)M,
                            chunk, part);
         Y3_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3(4), dim3(256), 0, st, part, nblk, (long long)27 * 32, dw_hwio);
+        hipLaunchKernelGGL(stem_sum_splits_kernel, dim3(27), dim3(256), 0, st, part, nblk, dw_hwio);
         Y3_CHECK_HIP(hipGetLastError());
         return Y3_OK;
     }
@@ -386,11 +428,11 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 4, 1>), dim3(tiles, nsplit), dim3(256), lds, st, a);
     Y3_CHECK_HIP(hipGetLastError());
     if (nsplit > 1) {
-        const long long n = (long long)a.J * a.Cout;
-        long long nb = (n + 63) / 64;
+        const long long n4 = (long long)a.J * a.Cout / 4;     // J = k*k*Cin, Cin % 4 == 0
+        long long nb = (n4 + 63) / 64;
         if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(wgrad_sum_splits_kernel, dim3((int)nb), dim3(256), 0, st, static_cast<float*>(scratch),
-                           nsplit, n, dw_hwio);
+                           nsplit, n4, dw_hwio);
         Y3_CHECK_HIP(hipGetLastError());
     }
     return Y3_OK;

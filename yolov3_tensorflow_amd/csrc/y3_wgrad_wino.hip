@@ -327,19 +327,22 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_wino_kernel(const WgWinoArg
     }
 }
 
-// dw[i] = sum over the splits in a fixed order (same scheme as y3_wgrad.hip: four lanes per element)
-__global__ void __launch_bounds__(256) wgw_sum_splits_kernel(const float* __restrict__ scratch, int nsplit, long long n,
+// dw = sum over the splits in a fixed order (same scheme as y3_wgrad.hip: four lanes per group of four consecutive elements -
+// n = 9 * Cin * Cout is a multiple of 4 -, each adds every fourth split, then (q0 + q1) + (q2 + q3); dw at dword alignment)
+__global__ void __launch_bounds__(256) wgw_sum_splits_kernel(const float* __restrict__ scratch, int nsplit, long long n4,
                                                              float* __restrict__ dw) {
-    __shared__ float part[4][64];
+    __shared__ f32x4 part[4][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(scratch);
+    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
         const long long i = base + e;
-        float s = 0.f;
-        if (i < n)
-            for (int k = q; k < nsplit; k += 4) s += scratch[(size_t)k * n + i];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4)
+            for (int k = q; k < nsplit; k += 4) s += s4[(size_t)k * n4 + i];
         part[q][e] = s;
         __syncthreads();
-        if (q == 0 && i < n) dw[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        if (q == 0 && i < n4)
+            *reinterpret_cast<f32x4_u*>(dw + 4 * i) = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
         __syncthreads();
     }
 }
@@ -384,6 +387,7 @@ int y3_launch_conv_wgrad_wino(hipStream_t stream, const y3_conv_desc* d, const f
                  "8 / ceil(w/2) + 1 tile rows (y3_conv_wgrad_wino_eligible)");
     Y3_CHECK_ARG(dz_stride >= d->cout, "y3_conv_wgrad_wino: dz row stride must be >= Cout");
     Y3_CHECK_ARG(scratch_bytes >= y3_conv_wgrad_wino_scratch_bytes_impl(d), "y3_conv_wgrad_wino: scratch too small");
+    Y3_CHECK_ARG((reinterpret_cast<size_t>(scratch) & 15) == 0, "y3_conv_wgrad_wino: scratch must be 16-byte aligned");
     const long long M = (long long)d->n * d->h * d->w;
     Y3_CHECK_ARG(M * d->cin < (1LL << 29) && M * dz_stride < (1LL << 29),
                  "y3_conv_wgrad_wino: tensor exceeds 2^29 elements (32-bit byte offsets)");
@@ -406,11 +410,11 @@ int y3_launch_conv_wgrad_wino(hipStream_t stream, const y3_conv_desc* d, const f
     hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3(wt, a.nsplit), dim3(256), lds, stream, a);
     Y3_CHECK_HIP(hipGetLastError());
     if (a.nsplit > 1) {
-        const long long n = (long long)9 * a.Cin * a.Cout;
-        long long nb = (n + 63) / 64;
+        const long long n4 = (long long)9 * a.Cin * a.Cout / 4;
+        long long nb = (n4 + 63) / 64;
         if (nb > 8192) nb = 8192;
         hipLaunchKernelGGL(wgw_sum_splits_kernel, dim3((int)nb), dim3(256), 0, stream, static_cast<float*>(scratch),
-                           a.nsplit, n, dw_hwio);
+                           a.nsplit, n4, dw_hwio);
         Y3_CHECK_HIP(hipGetLastError());
     }
     return Y3_OK;
