@@ -28,6 +28,8 @@ def _ctx():
 @pytest.mark.parametrize('n,h,w,k,stride,cin,cout', [
     (2, 20, 28, 3, 1, 64, 128), (2, 20, 28, 1, 1, 128, 64), (3, 16, 24, 3, 2, 32, 64),
     (2, 13, 13, 1, 1, 256, 255), (2, 26, 26, 3, 1, 32, 64), (1, 40, 40, 3, 1, 3, 32), (2, 12, 12, 3, 2, 128, 256),
+    # the stem's weight gradient walks 128-pixel pieces of image rows: a last piece of 32 pixels (416), of 2 (130), none (128)
+    (2, 24, 416, 3, 1, 3, 32), (1, 9, 130, 3, 1, 3, 32), (3, 5, 128, 3, 1, 3, 32),
 ])
 def test_conv_wgrad_and_dgrad_match_autograd(n, h, w, k, stride, cin, cout):
     fw, _lib, L, ctx = _ctx()

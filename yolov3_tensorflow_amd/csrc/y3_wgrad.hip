@@ -241,77 +241,84 @@ __global__ void __launch_bounds__(256) stem_sum_splits_kernel(const float* __res
         dw[e] = ((red[0][co] + red[1][co]) + (red[2][co] + red[3][co])) + ((red[4][co] + red[5][co]) + (red[6][co] + red[7][co]));
 }
 
-// Stem conv (Cin = 3): D[27][32] = sum over pixels of patch[m][27] * dz[m][32].  One 32x32 MFMA tile
-// (patch rows padded 27 -> 32 with zeros); a workgroup walks its chunk of pixels 128 at a time: the dz rows
-// and the gathered 3x3x3 patches are staged in LDS, each wave accumulates a quarter of the tile's pixels,
-// the four wave accumulators are summed through LDS at the end.  The loads of tile t + 1 (4 x 16 bytes of dz, 16
-// gathered patch values per thread) are issued before the MFMAs of tile t and held in registers: with "load, stage,
-// barrier, multiply, barrier" per tile a workgroup paid a memory latency per 128 pixels (1.02 ms per bs=64 step for
-// 1.55 GB of x and dz: 1.5 TB/s; round 5).
+// Stem conv (Cin = 3): D[27][32] = sum over pixels of patch[m][27] * dz[m][32].  One 32x32 MFMA tile (kernel rows j = (ky*3 +
+// kx)*3 + ci padded 27 -> 32 with zeros).  A workgroup walks PIECES of 128 consecutive pixels of one image row:
+//   * the patch matrix is never built: the three image rows under the piece are staged as they lie in memory - 130 pixels x 3
+//     channels = 390 consecutive floats per row, coalesced, zeros outside the image - and lane (j, pixel parity) of an MFMA
+//     reads its A value at  ky*XRL + (j % 9) + 3*pixel  (j % 9 = kx*3 + ci: pixel p under tap kx is staged pixel p + kx).
+//     XRL = 394 = 10 mod 32: the 27 lanes of a half-wave hit 27 different banks; j >= 27 reads a zero word with stride 0.
+//     (The first version gathered 16 patch values per thread and 128 pixels with one bounds-checked 4-byte load each:
+//     0.96-1.02 ms per bs=64 step for 1.55 GB of x and dz, 1.6 TB/s; profiles/r05_train_c4_kernel_stats.csv.)
+//   * dz rows: 128 x 32 floats, coalesced float4, zeros past the row end (the last piece of a 416-pixel row has 32 pixels);
+//   * the loads of piece t + 1 are issued before the MFMAs of piece t and held in registers;
+//   * each wave accumulates a quarter of the piece's pixels; the four wave accumulators are summed through LDS at the end.
+constexpr int XRL = 394;                       // floats per staged image row (390 used)
+constexpr int XZERO = 3 * XRL;                 // index of the zero word behind the three rows
 __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
-                                                         int N, int H, int W, int M, int chunk,
+                                                         int N, int H, int W, int pieces_per_row, int pieces, int chunk,
                                                          float* __restrict__ partial /*[grid][27][32]*/) {
     constexpr int TP = 128;
-    __shared__ __attribute__((aligned(16))) float xs[TP * 32];
+    __shared__ __attribute__((aligned(16))) float xs[3 * XRL + 4];
     __shared__ __attribute__((aligned(16))) float zs[TP * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = tid & 31;                   // patch column owned while staging
-    const int tap = j / 3, ci = j - tap * 3;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int pr0 = tid >> 5;                 // staging rows pr0 + 8*i
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int m_begin = blockIdx.x * chunk, m_end = min(m_begin + chunk, M);
+    const int p_begin = blockIdx.x * chunk, p_end = min(p_begin + chunk, pieces);
     f32x4 zr[4];
-    float xr[TP / 8];
-    auto load = [&](int m0) {
-        // dz rows: 128 x 32 floats, coalesced float4
+    float xr[3][2];
+    auto load = [&](int piece) {
+        const int row = piece / pieces_per_row, pc = piece - row * pieces_per_row;
+        const int n = row / H, oy = row - n * H;
+        const int px0 = pc * TP;
+        const size_t m0 = ((size_t)n * H + oy) * W + px0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i;              // float4 index inside the tile
+            const int e = tid + 256 * i;              // float4 index inside the piece
             const int p = e >> 3, c4 = (e & 7) * 4;
-            const int m = m0 + p;
             zr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) zr[i] = *reinterpret_cast<const f32x4*>(dz + (size_t)m * 32 + c4);
+            if (px0 + p < W) zr[i] = *reinterpret_cast<const f32x4*>(dz + (m0 + p) * 32 + c4);
         }
-        // patches: thread owns column j and rows pr0 + 8*i (coordinates advanced incrementally)
-        int m = m0 + pr0;
-        int n = m / (H * W);
-        int rem = m - n * H * W;
-        int oy = rem / W, ox = rem - oy * W;
 #pragma unroll
-        for (int i = 0; i < TP / 8; ++i) {
-            float v = 0.f;
-            const int iy = oy - 1 + ky, ix = ox - 1 + kx;
-            if (j < 27 && m < m_end && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                v = x[((size_t)(n * H + iy) * W + ix) * 3 + ci];
-            xr[i] = v;
-            m += 8; ox += 8;
-            if (ox >= W) { ox -= W; if (++oy == H) { oy = 0; ++n; } }
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy - 1 + r;
+            const bool rok = (unsigned)iy < (unsigned)H;
+            const float* xrow = x + ((size_t)n * H + (rok ? iy : 0)) * W * 3;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = tid + 256 * u;                   // float index inside the staged row
+                const int f = (px0 - 1) * 3 + q;               // float index inside the image row
+                xr[r][u] = (rok && q < 390 && f >= 0 && f < W * 3) ? xrow[f] : 0.f;
+            }
         }
     };
-    if (m_begin < m_end) load(m_begin);
-    for (int m0 = m_begin; m0 < m_end; m0 += TP) {
+    if (tid < 4) xs[XZERO + tid] = 0.f;
+    if (p_begin < p_end) load(p_begin);
+    // A operand: lane (j = lane & 31, h = lane >> 5), MFMA s2 of wave w reads pixel 32 w + 2 s2 + h
+    const int j = lane & 31;
+    const int a_stride = j < 27 ? 3 : 0;
+    const float* as = xs + (j < 27 ? (j / 9) * XRL + (j % 9) : XZERO) + a_stride * (wave * 32 + (lane >> 5));
+    const float* bs = zs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
+    for (int piece = p_begin; piece < p_end; ++piece) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
             *reinterpret_cast<f32x4*>(zs + (e >> 3) * 32 + (e & 7) * 4) = zr[i];
         }
 #pragma unroll
-        for (int i = 0; i < TP / 8; ++i) xs[(pr0 + 8 * i) * 32 + j] = xr[i];
+        for (int r = 0; r < 3; ++r) {
+            xs[r * XRL + tid] = xr[r][0];
+            if (tid < 390 - 256) xs[r * XRL + 256 + tid] = xr[r][1];
+        }
         __syncthreads();
-        if (m0 + TP < m_end) load(m0 + TP);       // in flight under this tile's MFMAs (and the other workgroups of the CU)
-        // wave w: pixels [32w, 32w+32) -> 16 MFMAs of k = 2 pixels
-        const float* as = xs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
-        const float* bs = zs + (wave * 32 + (lane >> 5)) * 32 + (lane & 31);
+        if (piece + 1 < p_end) load(piece + 1);   // in flight under this piece's MFMAs (and the other workgroups of the CU)
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s2 * 64], bs[s2 * 64], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s2 * 2 * a_stride], bs[s2 * 64], acc, 0, 0, 0);
         __syncthreads();
     }
     // sum the four waves: D layout col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (j)
-    float* red = xs;                              // [4][32][32] needs 16 KB: xs (16 KB) is free now
+    float* red = zs;                              // [4][32][32] = 16 KB: zs is free now
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[r];
@@ -388,13 +395,15 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     if (d->cin == 3) {
         Y3_CHECK_ARG(d->k == 3 && d->cout == 32 && d->stride == 1 && dz_stride == 32,
                      "y3_conv_wgrad: Cin=3 is supported only as the 3x3 3->32 stem conv");
-        // one round of co-resident workgroups (32 KB of LDS each: five per CU)
-        int nblk = (int)((M + 4095) / 4096);
-        if (nblk > 1280) nblk = 1280;
-        const int chunk = (int)(((M + nblk - 1) / nblk + 127) / 128 * 128);   // multiple of the 128-pixel tile
-        nblk = (int)((M + chunk - 1) / chunk);
+        // pieces of 128 pixels of one image row; one round of co-resident workgroups (21 KB of LDS each: six per CU)
+        const int ppr = (d->w + 127) / 128;
+        const long long pieces = (long long)d->n * d->h * ppr;
+        Y3_CHECK_ARG(pieces < (1LL << 30), "y3_conv_wgrad: too many pixels");
+        int nblk = (int)(pieces < 1536 ? pieces : 1536);
+        const int chunk = (int)((pieces + nblk - 1) / nblk);
+        nblk = (int)((pieces + chunk - 1) / chunk);
         float* part = static_cast<float*>(scratch);
-        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dz, d->n, d->h, d->w, (int)M,
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dz, d->n, d->h, d->w, ppr, (int)pieces,
                            chunk, part);
         Y3_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(stem_sum_splits_kernel, dim3(27), dim3(256), 0, st, part, nblk, dw_hwio);
