@@ -35,7 +35,7 @@ extern "C" {
 #define Y3_EHIP (-2)     /* a HIP runtime call failed */
 #define Y3_ESTATE (-3)   /* object used before it was fully configured */
 
-#define Y3_ABI_VERSION 2
+#define Y3_ABI_VERSION 3
 
 typedef struct y3_ctx y3_ctx; /* one per (device, stream) */
 typedef struct y3_net y3_net; /* the 75-conv YOLOv3 graph bound to caller-owned parameters */
@@ -178,33 +178,38 @@ size_t y3_conv_wino_workspace_bytes(const y3_conv_desc* d);   /* stream-K scratc
 int y3_conv2d_fwd_wino(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino, const float* scale,
                        const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
 /* The same conv in its Winograd F(4x4,3x3) form (36 multiplies per 4x4 output tile and channel pair: 1.78x less
- * matrix-pipe work again).  A workgroup owns 16 tiles x 64 channels, two workgroups per CU.  With a workspace, block counts
- * that do not fill the last round of the 512 resident workgroups may run a persistent schedule: whole rounds of blocks first, the remaining blocks cut
- * along K and finished inside the kernel (same hand-off protocol and failure reporting as y3_conv2d_fwd_wino).  y3_conv_wino44_eligible accepts
+ * matrix-pipe work again).  A workgroup owns 16 tiles x 64 channels, two workgroups per CU.  y3_conv_wino44_eligible accepts
  * (k = 3, stride 1, no fused upsample input, Cin %% 32 == 0, Cout %% 64 == 0).  w_wino44 = G g G^T with the 6x3 G of the
  * interpolation points 0, +-1, +-2, inf, packed [18 position pairs][cin/8][cout][4 channel pairs][2 positions][2 channels]
  * fp32 (36*cin*cout floats: an opaque layout, what the kernel's 16-byte fragment loads want) by
  * y3_pack_conv_weights_wino44.  Results differ from the direct kernel by fp32 roundings of the transforms (measured on the
- * whole network: boxes 1.0e-5 of the box scale from the fp64 oracle, 6.3e-6 for the direct sum). */
+ * whole network: boxes 1.0e-5 of the box scale from the fp64 oracle, 6.3e-6 for the direct sum).
+ * WORKSPACE (round 6): y3_conv_wino44_workspace_bytes(d) = the bytes of V = B^T d B for this conv (2.25x the input, rounded up
+ * to 16-tile blocks).  With a 16-byte-aligned workspace of at least that size the conv runs as TWO kernels - the input
+ * transform written once, then 36 batched GEMMs + the output transform (csrc/y3_conv_wino44.hip, form 1) -; with
+ * workspace = NULL (or a smaller one) as ONE kernel that transforms inside its K-loop (form 2: rounds 3-5).  Same arithmetic
+ * in the same order either way; the workspace needs no initialisation and carries nothing between calls. */
 int y3_conv_wino44_eligible(const y3_conv_desc* d);
 int y3_conv_wino44_candidate(const y3_conv_desc* d);   /* by shape: the convs worth an alternative packing (y3_net_set_layer_alt) */
 int y3_conv_wino44_preferred(const y3_conv_desc* d);   /* for THIS n, h, w: a candidate with enough blocks to fill the CUs */
 int y3_pack_conv_weights_wino44(y3_ctx* ctx, const float* w_hwio, int cin, int cout, float* w_wino44);
-size_t y3_conv_wino44_workspace_bytes(const y3_conv_desc* d);   /* scratch of the persistent schedule; workspace = NULL is allowed */
+size_t y3_conv_wino44_workspace_bytes(const y3_conv_desc* d);   /* bytes of V (two-kernel form); workspace = NULL is allowed */
 int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44, const float* scale,
                          const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes);
-/* Training uses of the F(4x4,3x3) kernel (train.py:105-115; round 4):
+/* Training uses of the F(4x4,3x3) kernel (train.py:105-115; round 4; the workspace arguments round 6, same rule as above):
  *   y3_conv2d_fwd_wino44_stats: the conv plus the column sums of y and y^2 per 16-tile block - stats
  *     [y3_conv_stats_blocks(d, 2)][2][cout] floats, for y3_bn_train_stats_partials (same contract as
- *     y3_conv2d_fwd_wino_stats: no residual; one workgroup per block, no workspace);
+ *     y3_conv2d_fwd_wino_stats: no residual);
  *   y3_pack_conv_weights_wino44_dgrad + y3_conv2d_dgrad_wino44: the data gradient of a stride-1 3x3 conv as the same kernel
  *     on dz with the flipped, channel-swapped kernel (same arguments as y3_conv2d_dgrad_wino; w_wino44_d = 36 * dz_stride *
- *     cin floats; needs dz_stride %% 32 == 0 and cin %% 64 == 0). */
+ *     cin floats; needs dz_stride %% 32 == 0 and cin %% 64 == 0; its workspace is that of the conv [n,h,w,dz_stride] ->
+ *     [n,h,w,cin]: y3_conv_wino44_workspace_bytes of fwd with cin = dz_stride, cout = fwd->cin). */
 int y3_conv2d_fwd_wino44_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44, const float* scale,
-                               const float* shift, float* y, float* stats);
+                               const float* shift, float* y, float* stats, void* workspace, size_t workspace_bytes);
 int y3_pack_conv_weights_wino44_dgrad(y3_ctx* ctx, const float* w_d, int cin, int dz_stride, float* w_wino44_d);
 int y3_conv2d_dgrad_wino44(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride, const float* w_wino44_d,
-                           const float* ones, const float* zeros, int accumulate, float* dx);
+                           const float* ones, const float* zeros, int accumulate, float* dx, void* workspace,
+                           size_t workspace_bytes);
 
 /* ---- fp32 on the bf16 matrix pipe ----------------------------------------------------------------------------
  * Same contract and tensors as y3_conv2d_fwd (fp32 NHWC in, fp32 out, same epilogue, same workspace rule); every

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_pure_host_entry_points(lib):
-    assert lib.y3_abi_version() == 2
+    assert lib.y3_abi_version() == 3
     # workspace sizing is host-only arithmetic
     assert lib.y3_nms_workspace_bytes(1, 10647, 80, 200) > 80 * 10647 * 4
     assert lib.y3_nms_workspace_bytes(0, 10647, 80, 200) == 0

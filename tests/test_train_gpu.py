@@ -182,6 +182,9 @@ def test_winograd_f4x4_data_gradient_matches_autograd(n, h, w, cin, cout):
     acc = engine.conv2d_dgrad_wino44(torch.tensor(dz, dtype=torch.float32, device=dev),
                                      torch.tensor(wt, dtype=torch.float32, device=dev), cin, accumulate_into=base.clone())
     assert np.abs(acc.cpu().numpy() - (want + base.cpu().numpy())).max() <= 2e-4 * scale + 1e-6
+    one = engine.conv2d_dgrad_wino44(torch.tensor(dz, dtype=torch.float32, device=dev),
+                                     torch.tensor(wt, dtype=torch.float32, device=dev), cin, use_workspace=False)
+    assert np.abs(one.cpu().numpy() - want).max() <= 2e-4 * scale         # the one-kernel form (no workspace)
 
 
 @pytest.mark.parametrize('n,h,w,k,stride,cin,cout,wino', [
@@ -196,6 +199,8 @@ def test_winograd_f4x4_data_gradient_matches_autograd(n, h, w, cin, cout):
     (3, 13, 13, 3, 1, 64, 128, 2),      # F(4x4,3x3), odd map: 4x4 tiles hang over the edge (not counted), ragged last block
     (8, 52, 52, 3, 1, 128, 256, 2),     # F(4x4,3x3), several blocks per image
     (6, 13, 13, 3, 1, 64, 128, 2),      # F(4x4,3x3) on an odd map: the batch tiled as one mosaic (tiles straddle images)
+    (6, 13, 13, 3, 1, 64, 128, 3),      # ... and the one-kernel form of the same (no workspace)
+    (8, 52, 52, 3, 1, 128, 256, 3),
 ])
 def test_conv_epilogue_statistics_equal_the_separate_pass(n, h, w, k, stride, cin, cout, wino):
     """Training forward (ref: model.py:35-41 with is_training=True): the conv writes per-row-block column sums of its
@@ -212,11 +217,11 @@ def test_conv_epilogue_statistics_equal_the_separate_pass(n, h, w, k, stride, ci
     gamma = torch.tensor(rng.uniform(0.5, 1.5, cout).astype(np.float32), device=dev)
     beta = torch.tensor(rng.normal(0, 0.3, cout).astype(np.float32), device=dev)
     d = _lib.ConvDesc(n, h, w, cin, 0, cout, k, stride, 0)
-    nblk = L.y3_conv_stats_blocks(ctypes.byref(d), wino)
+    nblk = L.y3_conv_stats_blocks(ctypes.byref(d), min(wino, 2))
     assert nblk > 0
-    if wino == 2:
+    if wino >= 2:                        # 2: the two-kernel form (workspace), 3: the one-kernel form
         wp = engine.pack_wino44(wt)
-        conv = lambda stats: engine.conv2d_fwd_wino44(x, wp, ones, zeros, cout, False, use_workspace=False, stats=stats)
+        conv = lambda stats: engine.conv2d_fwd_wino44(x, wp, ones, zeros, cout, False, use_workspace=wino == 2, stats=stats)
     elif wino:
         wp = engine.pack_wino(wt)
         conv = lambda stats: engine.conv2d_fwd_wino(x, wp, ones, zeros, cout, False, stats=stats)

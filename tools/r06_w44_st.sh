@@ -1,0 +1,14 @@
+#!/bin/bash
+# Start-stagger probes of conv_wino44v_f32_kernel, all inside ONE gpurun call.  Output: gpurun_out/r06_w44_one.txt
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r06_w44_one.txt
+: > $O
+cd /tmp && export TMPDIR=/tmp
+for v in product one one_kt one_all_kt kt product; do
+  if [ $v = product ]; then unset Y3_LIB_PATH; else export Y3_LIB_PATH=$R/tools/_probe/lib_$v.so; fi
+  echo "== $v" >> $O
+  rm -rf /tmp/prof_$v
+  W44_ONLY2K=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$v -o t -- python $R/tools/wino44_bench.py 32 > /dev/null 2>&1
+  python $R/tools/trace_by_grid.py /tmp/prof_$v/t_kernel_trace.csv "wino44v" >> $O
+done
+cat $O

@@ -61,9 +61,11 @@ PROTOTYPES = {
     "y3_conv_wino44_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "y3_conv2d_fwd_wino44": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_size_t]),
-    "y3_conv2d_fwd_wino44_stats": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "y3_conv2d_fwd_wino44_stats": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_size_t]),
     "y3_pack_conv_weights_wino44_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "y3_conv2d_dgrad_wino44": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "y3_conv2d_dgrad_wino44": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_size_t]),
     "y3_conv2d_fwd_wino": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t]),
     "y3_pack_conv_weights_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -179,7 +181,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.y3_abi_version() != 2:
+        if handle.y3_abi_version() != 3:
             raise Y3Error("libyolo355.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -213,14 +213,15 @@ extern "C" int y3_conv2d_fwd_wino44(y3_ctx* ctx, const y3_conv_desc* d, const fl
 }
 
 extern "C" int y3_conv2d_fwd_wino44_stats(y3_ctx* ctx, const y3_conv_desc* d, const float* x, const float* w_wino44,
-                                          const float* scale, const float* shift, float* y, float* stats) {
+                                          const float* scale, const float* shift, float* y, float* stats, void* workspace,
+                                          size_t workspace_bytes) {
     Y3_CHECK_CTX(ctx, "y3_conv2d_fwd_wino44_stats");
     Y3_CHECK_ARG(stats && d && y3_conv_stats_blocks_impl(d, 2) > 0,
                  "y3_conv2d_fwd_wino44_stats: null stats, or a conv the F(4x4,3x3) kernel does not take");
     y3_sk_opts o;
     o.err = ctx->err_host;
     o.stats = stats;
-    return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, nullptr, y, nullptr, 0, &o);
+    return y3_launch_conv_wino44(ctx->stream, d, x, w_wino44, scale, shift, nullptr, y, workspace, workspace_bytes, &o);
 }
 
 extern "C" int y3_pack_conv_weights_wino44_dgrad(y3_ctx* ctx, const float* w_d, int cin, int dz_stride, float* w_wino44_d) {
@@ -232,7 +233,7 @@ extern "C" int y3_pack_conv_weights_wino44_dgrad(y3_ctx* ctx, const float* w_d, 
 
 extern "C" int y3_conv2d_dgrad_wino44(y3_ctx* ctx, const y3_conv_desc* fwd, const float* dz, int dz_stride,
                                       const float* w_wino44_d, const float* ones, const float* zeros, int accumulate,
-                                      float* dx) {
+                                      float* dx, void* workspace, size_t workspace_bytes) {
     Y3_CHECK_CTX(ctx, "y3_conv2d_dgrad_wino44");
     Y3_CHECK_ARG(fwd && dz && w_wino44_d && ones && zeros && dx, "y3_conv2d_dgrad_wino44: null pointer argument");
     Y3_CHECK_ARG(fwd->k == 3 && fwd->stride == 1 && fwd->c_up == 0 && dz_stride >= fwd->cout,
@@ -243,7 +244,8 @@ extern "C" int y3_conv2d_dgrad_wino44(y3_ctx* ctx, const y3_conv_desc* fwd, cons
     y3_sk_opts o;
     o.err = ctx->err_host;
     // accumulate: dx is read as the residual and written by the same thread for the same element (no cross-thread hazard)
-    return y3_launch_conv_wino44(ctx->stream, &g, dz, w_wino44_d, ones, zeros, accumulate ? dx : nullptr, dx, nullptr, 0, &o);
+    return y3_launch_conv_wino44(ctx->stream, &g, dz, w_wino44_d, ones, zeros, accumulate ? dx : nullptr, dx, workspace,
+                                 workspace_bytes, &o);
 }
 
 // Data gradient of a stride-1 3x3 conv in its Winograd form: dx (+)= conv_same(dz, flipped / channel-swapped kernel) is
@@ -393,6 +395,7 @@ extern "C" int y3_net_set_layer(y3_net* net, int i, const float* w_packed, const
 extern "C" int y3_net_set_layer_alt(y3_net* net, int i, const float* w_wino44) {
     Y3_CHECK_ARG(net && i >= 0 && i < (int)net->layers.size(), "y3_net_set_layer_alt: bad layer index %d", i);
     net->layers[i].w_alt = w_wino44;       // NULL: the layer runs on its y3_net_set_layer packing at every size
+    net->pn = net->ph = net->pw = 0;       // re-plan: the layer's V scratch (two-kernel form) is part of the workspace
     return Y3_OK;
 }
 
@@ -516,7 +519,8 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
             ? y3_launch_conv_bf16(st, &d, ptr(l.src), ptr(l.up), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   net->tensors[l.dst].ext >= 0 ? 1 : 0)
             : (net->dtype == 4 && l.w_alt && y3_conv_wino44_preferred_impl(&d))
-            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w_alt, l.scale, l.shift, ptr(l.resid), ptr(l.dst), nullptr, 0, &o)
+            ? y3_launch_conv_wino44(st, &d, ptr(l.src), l.w_alt, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
+                                    base + net->arena_bytes, net->scratch_bytes, &o)
             : (net->dtype == 4 && y3_conv_wino_eligible_impl(&d))
             ? y3_launch_conv_wino(st, &d, ptr(l.src), l.w, l.scale, l.shift, ptr(l.resid), ptr(l.dst),
                                   base + net->arena_bytes, net->scratch_bytes, &o)

@@ -37,7 +37,8 @@ struct y3_net {
     std::vector<size_t> offsets;  // byte offset of each tensor in the workspace (SIZE_MAX if external)
     size_t plan_bytes = 0;    // arena + conv scratch + flag regions
     size_t arena_bytes = 0;   // activations only; the conv (stream-K) scratch follows at this offset
-    size_t scratch_bytes = 0; // stream-K accumulator slots (shared by all layers: launches on one stream are ordered)
+    size_t scratch_bytes = 0; // stream-K accumulator slots / the V tensor of the two-kernel F(4x4,3x3) form (shared by all
+                              // layers: launches on one stream are ordered)
     size_t flags_bytes = 0;   // one region of FLAG_WORDS "partial published" words per layer, after the scratch:
                               // all regions are zeroed by ONE memset at the start of a forward
     static constexpr size_t FLAG_WORDS = 512;   // >= the largest stream-K grid (512 direct / 256 Winograd workers)
@@ -184,6 +185,9 @@ struct y3_net {
             if (dtype == 1) break;   // the bf16 kernels use no stream-K scratch
             scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
             if (dtype == 4) scratch_bytes = std::max(scratch_bytes, y3_conv_wino_workspace_bytes_impl(&d));
+            // V = B^T d B of the two-kernel F(4x4,3x3) form, for the layers that can run on it at this size
+            if (dtype == 4 && l.w_alt && y3_conv_wino44_preferred_impl(&d))
+                scratch_bytes = std::max(scratch_bytes, y3_conv_wino44_workspace_bytes_impl(&d));
         }
         scratch_bytes = (scratch_bytes + 255) & ~(size_t)255;
         flags_bytes = scratch_bytes ? layers.size() * FLAG_WORDS * sizeof(unsigned) : 0;

@@ -153,6 +153,10 @@ int forward_impl(y3_net* net, const y3_train_var* vars, const float* x, int n, i
         y3_conv_desc g = d;
         g.cin = l.bn ? l.cout : det_pad; g.cout = l.cin;
         if (l.k == 3 && l.stride == 1) sk = std::max(sk, y3_conv_wino_workspace_bytes(&g));
+        // V of the two-kernel F(4x4,3x3) form, forward and data gradient
+        if (net->dtype == 4 && l.bn && y3_conv_wino44_preferred(&d) == 1) sk = std::max(sk, y3_conv_wino44_workspace_bytes(&d));
+        if (net->dtype == 4 && l.k == 3 && l.stride == 1 && l.up < 0 && y3_conv_wino44_preferred(&g) == 1)
+            sk = std::max(sk, y3_conv_wino44_workspace_bytes(&g));
         wg = std::max(wg, y3_conv_wgrad_scratch_bytes(&d));
         if (y3_conv_wgrad_wino_eligible(&d)) wg = std::max(wg, y3_conv_wgrad_wino_scratch_bytes(&d));
     }
@@ -233,7 +237,7 @@ int forward_impl(y3_net* net, const y3_train_var* vars, const float* x, int n, i
             S.z[i] = A.alloc((size_t)rows * cout * 4);
             float* z = A.p(S.z[i]);
             if (wino44)
-                Y3_TRY(y3_conv2d_fwd_wino44_stats(ctx, &d, xin, static_cast<const float*>(wdev), ones, zeros, z, A.p(part)));
+                Y3_TRY(y3_conv2d_fwd_wino44_stats(ctx, &d, xin, static_cast<const float*>(wdev), ones, zeros, z, A.p(part), skp, skb));
             else if (wino)
                 Y3_TRY(y3_conv2d_fwd_wino_stats(ctx, &d, xin, static_cast<const float*>(wdev), ones, zeros, z, A.p(part), skp, skb));
             else if (planes)
@@ -421,7 +425,7 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
             }
             auto dgrad = [&](int accumulate, float* dx) -> int {
                 if (wino44_d)
-                    Y3_TRY(y3_conv2d_dgrad_wino44(ctx, &d, dz, dz_stride, A.p(wk), ones, zeros, accumulate, dx));
+                    Y3_TRY(y3_conv2d_dgrad_wino44(ctx, &d, dz, dz_stride, A.p(wk), ones, zeros, accumulate, dx, skp, skb));
                 else if (wino_d)
                     Y3_TRY(y3_conv2d_dgrad_wino(ctx, &d, dz, dz_stride, A.p(wk), ones, zeros, accumulate, dx, skp, skb));
                 else if (planes)

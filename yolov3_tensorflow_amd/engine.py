@@ -229,27 +229,29 @@ def pack_wino44(w_hwio):
 
 def conv2d_fwd_wino44(x, w_wino44, scale, shift, cout, act, residual=None, use_workspace=True, stats=None):
     """3x3 stride-1 conv in its Winograd F(4x4,3x3) form (y3_conv2d_fwd_wino44); w_wino44 from pack_wino44.
-    use_workspace=False forces the one-workgroup-per-block schedule.  stats: a [y3_conv_stats_blocks(d, 2), 2, cout] tensor
-    -> the training form y3_conv2d_fwd_wino44_stats (column sums of y and y^2 per 16-tile block; no residual)."""
+    use_workspace=True: the two-kernel form (input transform written once into the workspace, then the batched GEMMs);
+    False: the one-kernel form.  stats: a [y3_conv_stats_blocks(d, 2), 2, cout] tensor -> the training form
+    y3_conv2d_fwd_wino44_stats (column sums of y and y^2 per 16-tile block; no residual)."""
     n, h, w, cin = x.shape
     d = _lib.ConvDesc(n, h, w, cin, 0, cout, 3, 1, 1 if act else 0)
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     L = _lib.lib()
-    if stats is not None:
-        assert residual is None
-        _lib.check(L.y3_conv2d_fwd_wino44_stats(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44),
-                                                fw.ptr(scale), fw.ptr(shift), fw.ptr(y), fw.ptr(stats)))
-        return y
     ws, ws_bytes = None, 0
     if use_workspace:
         ws_bytes = L.y3_conv_wino44_workspace_bytes(ctypes.byref(d))
         ws = _conv_scratch(x.device, ws_bytes) if ws_bytes else None
+    if stats is not None:
+        assert residual is None
+        _lib.check(L.y3_conv2d_fwd_wino44_stats(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44),
+                                                fw.ptr(scale), fw.ptr(shift), fw.ptr(y), fw.ptr(stats), fw.ptr(ws),
+                                                ctypes.c_size_t(ws_bytes)))
+        return y
     _lib.check(L.y3_conv2d_fwd_wino44(fw.context(x.device), ctypes.byref(d), fw.ptr(x), fw.ptr(w_wino44), fw.ptr(scale),
                                       fw.ptr(shift), fw.ptr(residual), fw.ptr(y), fw.ptr(ws), ctypes.c_size_t(ws_bytes)))
     return y
 
 
-def conv2d_dgrad_wino44(dz, w_hwio, cin, accumulate_into=None):
+def conv2d_dgrad_wino44(dz, w_hwio, cin, accumulate_into=None, use_workspace=True):
     """Data gradient of a stride-1 3x3 conv in F(4x4,3x3) form (y3_pack_conv_weights_wino44_dgrad + y3_conv2d_dgrad_wino44):
     dz [n,h,w,cout] (cout % 32 == 0), w_hwio the forward kernel [3,3,cin,cout] (cin % 64 == 0) -> dx [n,h,w,cin]."""
     n, h, w, cout = dz.shape
@@ -259,8 +261,14 @@ def conv2d_dgrad_wino44(dz, w_hwio, cin, accumulate_into=None):
     _lib.check(L.y3_pack_conv_weights_wino44_dgrad(ctx, fw.ptr(w_hwio), cin, cout, fw.ptr(wk)))
     ones, zeros = torch.ones(cin, device=dz.device), torch.zeros(cin, device=dz.device)
     dx = accumulate_into if accumulate_into is not None else torch.empty((n, h, w, cin), dtype=torch.float32, device=dz.device)
+    ws, ws_bytes = None, 0
+    if use_workspace:
+        g = _lib.ConvDesc(n, h, w, cout, 0, cin, 3, 1, 0)            # the gradient conv: [n,h,w,cout] -> [n,h,w,cin]
+        ws_bytes = L.y3_conv_wino44_workspace_bytes(ctypes.byref(g))
+        ws = _conv_scratch(dz.device, ws_bytes) if ws_bytes else None
     _lib.check(L.y3_conv2d_dgrad_wino44(ctx, ctypes.byref(d), fw.ptr(dz), cout, fw.ptr(wk), fw.ptr(ones), fw.ptr(zeros),
-                                        1 if accumulate_into is not None else 0, fw.ptr(dx)))
+                                        1 if accumulate_into is not None else 0, fw.ptr(dx), fw.ptr(ws),
+                                        ctypes.c_size_t(ws_bytes)))
     return dx
 
 
