@@ -27,7 +27,10 @@ def main():
     from yolov3_tensorflow_amd import engine
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     print('shape (bs=%d)            F(2x2) us   F(4x4) 1 kernel us   F(4x4) 2 kernels us   ratio 2k/1k   useful TF/s 2k (of 157.3)' % n)
-    for g, cin, cout in ((208, 32, 64), (104, 64, 128), (52, 128, 256), (26, 256, 512), (13, 512, 1024)):
+    shapes = ((208, 32, 64), (104, 64, 128), (52, 128, 256), (26, 256, 512), (13, 512, 1024))
+    if os.environ.get('W44_DGRAD') == '1':          # the data-gradient convs of the same layers (channel axes swapped)
+        shapes = ((104, 128, 64), (52, 256, 128), (26, 512, 256), (13, 1024, 512))
+    for g, cin, cout in shapes:
         x = torch.rand((n, g, g, cin), device='cuda')
         w = torch.randn((3, 3, cin, cout), device='cuda') * 0.05
         r = torch.rand((n, g, g, cout), device='cuda')

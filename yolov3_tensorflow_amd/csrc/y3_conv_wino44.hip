@@ -65,7 +65,7 @@ struct W44Args {
     float* stats;        // STATS instantiation: [tile blocks][2][Cout] column sums of y and y^2 per 16-tile block, the training
                          // forward's batch-norm statistics (y3_bn_train_stats_partials)
     float* v;            // two-kernel form: V = B^T d B, [tile blocks][Cin / 16][VSTAGE bytes] (written by the transform kernel)
-    int xb;              // two-kernel form: channel blocks per XCD rectangle (see conv_wino44v_f32_kernel)
+    int xb;              // channel blocks per XCD rectangle (w44_block_of)
 };
 
 constexpr int BT = 16, BNC = 64, NTH = BT * 16;  // one wave per 16 tiles x 16 channels
@@ -316,6 +316,27 @@ __device__ __forceinline__ void w44_tail(const W44Args& p, const f32x4 (&acc)[36
     }
 }
 
+// Workgroup -> (tile block bt, channel block bn).  Workgroup b runs on XCD b % 8 (observed placement; only speed depends on it).
+// Each XCD gets a contiguous run of the order "for channel-block group: for tile block: for channel block of the group" (groups
+// of p.xb channel blocks): its workgroups then share a rectangle of (tile blocks) x (xb channel blocks), i.e. input patches / V
+// images AND weight slices meet in ONE L2.  A weight slice (36 x Cin x 64) is four times a V image (36 x Cin x 16):
+// y3_launch_conv_wino44 picks xb ~ sqrt(blocks / 32), which minimises (distinct tile blocks) x image + (distinct channel blocks)
+// x slice per XCD.  (One channel block per XCD - what plain dispatch order gives for Cout = 256 / 512 - fetches every input four
+// or eight times: 466 MB of fabric traffic per 52-grid launch against 173 MB algorithmic in round 5; all channel blocks on every
+// XCD fetches the 75 MB of 13-grid weights 25 times.)  The grid is 8 * ceil(blocks / 8) workgroups; false = nothing to do.
+__device__ __forceinline__ bool w44_block_of(const W44Args& p, int nbn, int& bt, int& bn) {
+    const int nbt = (p.T + BT - 1) / BT;
+    const int nblocks = nbt * nbn, per = (nblocks + 7) >> 3;
+    const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (L >= nblocks) return false;
+    const int xb = p.xb, grp = L / (nbt * xb), rem = L - grp * (nbt * xb);
+    // (the last group may hold fewer than xb channel blocks when xb does not divide Cout / 64)
+    const int gb = (grp + 1) * xb <= nbn ? xb : nbn - grp * xb;
+    bt = rem / gb;
+    bn = grp * xb + (rem - bt * gb);
+    return true;
+}
+
 // ---- form (2): one kernel, B^T d B inside the K-loop -------------------------------------------------------------------
 template <bool STATS>
 __global__ void __launch_bounds__(NTH, 2) conv_wino44_f32_kernel(const W44Args p) {
@@ -346,8 +367,8 @@ __global__ void __launch_bounds__(NTH, 2) conv_wino44_f32_kernel(const W44Args p
     const unsigned b_pos_stride = (unsigned)((size_t)ksteps * p.Cout * 2 * KC * 4);         // bytes between position pairs
     const unsigned b_ks_stride = (unsigned)(p.Cout * 2 * KC * 4);
 
-    const int blk = blockIdx.x;
-    const int bt = blk / nbn, bn = blk - bt * nbn;     // the Cout/64 blocks of one tile block are neighbours
+    int bt, bn;
+    if (!w44_block_of(p, nbn, bt, bn)) return;
     const int t0 = bt * BT, n0 = bn * BNC;
     w44_tinfo(p, smem, bt, tid);
 
@@ -371,11 +392,13 @@ __global__ void __launch_bounds__(NTH, 2) conv_wino44_f32_kernel(const W44Args p
             dvoff[j] = ok ? (unsigned)(((rpart + cpart) * p.Cin) * 4 + (lane & 1) * 16) : OOB;
         }
     }
-    auto dma_raw = [&](int ks, int buf) {
+    // (`live` = false: the same instructions with out-of-range offsets - zeros into a buffer nobody reads, nothing fetched: the
+    // DMAs of the K-loop must not sit behind a branch, see dma_piece in conv_wino44v_f32_kernel)
+    auto dma_raw = [&](int ks, int buf, bool live) {
         const unsigned so = (unsigned)(ks * KC) * 4u;
 #pragma unroll
         for (int j = 0; j < DPW; ++j)
-            if (wave + NW * j < NDMA) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + NW * j) * 1024, dvoff[j], so);
+            if (wave + NW * j < NDMA) dma16(rs_x, smem + RAW_OFF + buf * STAGE + (wave + NW * j) * 1024, live ? dvoff[j] : OOB, so);
     };
     auto transform = [&](int bufr, int bufv) {
         const unsigned char* rs = smem + RAW_OFF + bufr * STAGE + st_off;
@@ -400,8 +423,8 @@ __global__ void __launch_bounds__(NTH, 2) conv_wino44_f32_kernel(const W44Args p
     };
 
     // ---- prologue: raw(0), raw(1) by DMA; V(0) = transform(raw(0)); the first weight fragments ---------------------------
-    dma_raw(0, 0);
-    if (1 < ksteps) dma_raw(1, 1);
+    dma_raw(0, 0, true);
+    dma_raw(1, 1, 1 < ksteps);
 #pragma unroll
     for (int s = 0; s < BDEPTH; ++s) issue_b(s, s, 0);      // pairs 0 .. BDEPTH-1
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BDEPTH) : "memory");     // the DMAs are older than the fragment loads
@@ -415,7 +438,7 @@ __global__ void __launch_bounds__(NTH, 2) conv_wino44_f32_kernel(const W44Args p
         const bool more = ks + 1 < ksteps;
         // DMA of raw(ks+2) (raw[cur] held raw(ks): consumed a K-step ago) and V(ks+1) from raw(ks+1) (it landed before the
         // last barrier; on the last K-step it transforms stale data into a buffer nobody reads: keeps the K-step's shape)
-        if (ks + 2 < ksteps) dma_raw(ks + 2, cur);
+        dma_raw(ks + 2, cur, ks + 2 < ksteps);
         transform(cur ^ 1, cur ^ 1);
         const unsigned char* vs = smem + cur * STAGE + a_off;
         constexpr int AD = 4;                             // activation fragments read ahead (two pairs)
@@ -523,23 +546,10 @@ __global__ void __launch_bounds__(NTH, 2) conv_wino44v_f32_kernel(const W44Args 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][2 K-steps][18 pairs][1 KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave;
-    const int nbn = p.Cout / BNC, nbt = (p.T + BT - 1) / BT;
+    const int nbn = p.Cout / BNC;
     const int ksteps = p.Cin / KC, nds = p.Cin / 16;
-    // workgroup b runs on XCD b % 8 (observed placement; only speed depends on it).  Each XCD gets a contiguous run of the
-    // order "for channel-block group: for tile block: for channel block of the group" (groups of p.xb channel blocks): its
-    // workgroups then share a rectangle of (tile blocks) x (xb channel blocks), i.e. V images AND weight slices meet in ONE L2.
-    // A weight slice (36 x Cin x 64) is four times a V image (36 x Cin x 16): y3_launch_conv_wino44 picks xb ~ sqrt(blocks / 32),
-    // which minimises (distinct tile blocks) x image + (distinct channel blocks) x slice per XCD.  (One channel block per XCD -
-    // what plain dispatch order gives for Cout = 256 / 512 - fetches every V image four or eight times: 466 MB of fabric traffic
-    // per 52-grid launch against 173 MB algorithmic in round 5; all channel blocks on every XCD fetches the 75 MB of 13-grid
-    // weights 25 times.)
-    const int nblocks = nbt * nbn, per = (nblocks + 7) >> 3;
-    const int L = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (L >= nblocks) return;
-    const int xb = p.xb, grp = L / (nbt * xb), rem = L - grp * (nbt * xb);
-    // (the last group may hold fewer than xb channel blocks when xb does not divide Cout / 64)
-    const int gb = (grp + 1) * xb <= nbn ? xb : nbn - grp * xb;
-    const int bt = rem / gb, bn = grp * xb + (rem - bt * gb);
+    int bt, bn;
+    if (!w44_block_of(p, nbn, bt, bn)) return;
     const int n0 = bn * BNC;
     const int row16 = lane & 15, quart = lane >> 4;
 #ifdef W44V_PROBE
@@ -795,13 +805,16 @@ size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d) {
     return (size_t)nbt * (d->cin / 16) * VSTAGE;
 }
 
-// Which form a launch WITH a sufficient workspace takes (1 = two kernels).  (experiments build only) Y3_WINO44_V=0 / 1 forces
-// one form on every conv.
+// Which form a launch WITH a sufficient workspace takes (1 = two kernels).  The extra pass costs time in proportion to tiles x
+// Cin, the batched GEMMs save in proportion to tiles x Cin x Cout: measured (profiles/r06_wino44_forms.txt; us per launch at
+// bs=32, one kernel | two kernels) 52-grid 128->256 162 | 176, 26-grid 256->512 157 | 141, 13-grid 512->1024 189 | 163, the data
+// gradients 52-grid 256->128 162 | 219, 26-grid 512->256 190 | 182, 13-grid 1024->512 212 | 172; bs=64 alike): Cout >= 512.
+// (experiments build only) Y3_WINO44_V=0 / 1 forces one form on every conv.
 int y3_conv_wino44_two_pass_impl(const y3_conv_desc* d) {
     if (!y3_conv_wino44_eligible_impl(d) || d->cin % 16) return 0;
     static const int force = y3_exp_env("Y3_WINO44_V") ? atoi(y3_exp_env("Y3_WINO44_V")) : -1;
     if (force >= 0) return force;
-    return 1;
+    return d->cout >= 512;
 }
 
 static int w44_set_lds(const void* kern, int slot) {
@@ -833,6 +846,14 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
     a.stats = sk ? sk->stats : nullptr;
     a.v = nullptr; a.xb = 1;
     const int nbt = (a.T + BT - 1) / BT, nbn = d->cout / BNC;
+    // channel blocks per XCD rectangle (w44_block_of): the power of two nearest sqrt(blocks / 32) in log scale, at most nbn
+    const long long nblocks = (long long)nbt * nbn;
+    int xb = 1;
+    while (xb * 2 <= nbn && (long long)(xb * 2) * (xb * 2) * 32 <= 2 * nblocks) xb *= 2;
+    static const int xb_force = y3_exp_env("Y3_WINO44_XB") ? atoi(y3_exp_env("Y3_WINO44_XB")) : 0;
+    if (xb_force > 0) xb = xb_force < nbn ? xb_force : nbn;
+    a.xb = xb;
+    const unsigned grid = (unsigned)(8 * ((nblocks + 7) / 8));
     const size_t vbytes = y3_conv_wino44_workspace_bytes_impl(d);
     const bool two_pass = workspace != nullptr && workspace_bytes >= vbytes && ((uintptr_t)workspace & 15) == 0 &&
                           y3_conv_wino44_two_pass_impl(d);
@@ -843,23 +864,16 @@ int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float
         Y3_CHECK_HIP(hipGetLastError());
         auto kern = a.stats ? conv_wino44v_f32_kernel<true> : conv_wino44v_f32_kernel<false>;
         if (int rc = w44_set_lds(reinterpret_cast<const void*>(kern), a.stats ? 3 : 2)) return rc;
-        // channel blocks per XCD rectangle: the divisor-free choice nearest sqrt(blocks / 32) (see the kernel), at most nbn
-        const long long nblocks = (long long)nbt * nbn;
-        int xb = 1;
-        while (xb * 2 <= nbn && (long long)(xb * 2) * (xb * 2) * 32 <= 2 * nblocks) xb *= 2;      // (2 xb)^2 <= 2 (blocks / 32): rounds in log scale
-        static const int xb_force = y3_exp_env("Y3_WINO44_XB") ? atoi(y3_exp_env("Y3_WINO44_XB")) : 0;
-        if (xb_force > 0) xb = xb_force < nbn ? xb_force : nbn;
-        a.xb = xb;
 #ifdef W44V_LDS      // probe: a larger request keeps the second workgroup off the CU
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W44V_LDS));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblocks + 7) / 8))), dim3(NTH), W44V_LDS, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), W44V_LDS, stream, a);
 #else
-        hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((nblocks + 7) / 8))), dim3(NTH), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), LDS_BYTES, stream, a);
 #endif
     } else {
         auto kern = a.stats ? conv_wino44_f32_kernel<true> : conv_wino44_f32_kernel<false>;
         if (int rc = w44_set_lds(reinterpret_cast<const void*>(kern), a.stats ? 1 : 0)) return rc;
-        hipLaunchKernelGGL(kern, dim3(nbt * nbn), dim3(NTH), LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), LDS_BYTES, stream, a);
     }
     Y3_CHECK_HIP(hipGetLastError());
     return Y3_OK;

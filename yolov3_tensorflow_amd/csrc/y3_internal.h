@@ -128,7 +128,8 @@ int y3_conv_wino44_candidate_impl(const y3_conv_desc* d);   // by shape (what to
 int y3_conv_wino44_preferred_impl(const y3_conv_desc* d);   // for this launch (candidate + enough blocks to fill the CUs)
 int y3_launch_pack_wino44(hipStream_t stream, const float* w_hwio, int cin, int cout, float* out, int dgrad = 0);
 int y3_conv_wino44_stats_blocks_impl(const y3_conv_desc* d);   // rows of the STATS output (one per 16-tile block)
-size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d);
+size_t y3_conv_wino44_workspace_bytes_impl(const y3_conv_desc* d);   // bytes of V = B^T d B (the two-kernel form's workspace)
+int y3_conv_wino44_two_pass_impl(const y3_conv_desc* d);          // the form a launch with a workspace takes (1 = two kernels)
 int y3_launch_conv_wino44(hipStream_t stream, const y3_conv_desc* d, const float* x, const float* u, const float* scale,
                           const float* shift, const float* residual, float* y, void* workspace, size_t workspace_bytes,
                           const y3_sk_opts* sk);

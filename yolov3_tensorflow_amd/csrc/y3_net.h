@@ -186,7 +186,7 @@ struct y3_net {
             scratch_bytes = std::max(scratch_bytes, y3_conv_workspace_bytes_impl(&d));
             if (dtype == 4) scratch_bytes = std::max(scratch_bytes, y3_conv_wino_workspace_bytes_impl(&d));
             // V = B^T d B of the two-kernel F(4x4,3x3) form, for the layers that can run on it at this size
-            if (dtype == 4 && l.w_alt && y3_conv_wino44_preferred_impl(&d))
+            if (dtype == 4 && l.w_alt && y3_conv_wino44_preferred_impl(&d) && y3_conv_wino44_two_pass_impl(&d))
                 scratch_bytes = std::max(scratch_bytes, y3_conv_wino44_workspace_bytes_impl(&d));
         }
         scratch_bytes = (scratch_bytes + 255) & ~(size_t)255;

@@ -154,8 +154,9 @@ int forward_impl(y3_net* net, const y3_train_var* vars, const float* x, int n, i
         g.cin = l.bn ? l.cout : det_pad; g.cout = l.cin;
         if (l.k == 3 && l.stride == 1) sk = std::max(sk, y3_conv_wino_workspace_bytes(&g));
         // V of the two-kernel F(4x4,3x3) form, forward and data gradient
-        if (net->dtype == 4 && l.bn && y3_conv_wino44_preferred(&d) == 1) sk = std::max(sk, y3_conv_wino44_workspace_bytes(&d));
-        if (net->dtype == 4 && l.k == 3 && l.stride == 1 && l.up < 0 && y3_conv_wino44_preferred(&g) == 1)
+        if (net->dtype == 4 && l.bn && y3_conv_wino44_preferred(&d) == 1 && y3_conv_wino44_two_pass_impl(&d))
+            sk = std::max(sk, y3_conv_wino44_workspace_bytes(&d));
+        if (net->dtype == 4 && l.k == 3 && l.stride == 1 && l.up < 0 && y3_conv_wino44_preferred(&g) == 1 && y3_conv_wino44_two_pass_impl(&g))
             sk = std::max(sk, y3_conv_wino44_workspace_bytes(&g));
         wg = std::max(wg, y3_conv_wgrad_scratch_bytes(&d));
         if (y3_conv_wgrad_wino_eligible(&d)) wg = std::max(wg, y3_conv_wgrad_wino_scratch_bytes(&d));
