@@ -109,7 +109,7 @@ __device__ __forceinline__ void epilogue_x(const ConvArgsX& p, unsigned char* sm
         // bf16 output rows of a multiple of 8 channels (every BN layer of the network): 8 channels = 16 bytes per lane for
         // the residual load and the store.  The tail of a tile is bound by the number of store instructions a CU can issue
         // (~7 B per cycle and CU with 8-byte stores, MI355X guide T21): 16-byte pieces halve it.
-        constexpr int C8 = BN / 8, RPP8 = NT / C8, PASSES8 = 64 / RPP8;
+        constexpr int C8 = BN / 8, RPP8 = NT / C8, PASSES8 = 64 / RPP8, HALVES = BM / 64;
         static_assert(RPP8 >= 1 && PASSES8 >= 1 && RPP8 * C8 == NT, "epilogue pass geometry (8-channel pieces)");
         const int tc = (tid % C8) * 8, tr = tid / C8;
         const int col = n0 + tc;
@@ -121,17 +121,31 @@ __device__ __forceinline__ void epilogue_x(const ConvArgsX& p, unsigned char* sm
             sh0 = *reinterpret_cast<const f32x4*>(p.shift + col);
             sh1 = *reinterpret_cast<const f32x4*>(p.shift + col + 4);
         }
+        // Memory order of the tail (round 6; the same finding as csrc/y3_conv_wino44.hip's tail).  On gfx950 loads and stores share
+        // vmcnt and may complete out of order with each other, so hipcc waits vmcnt(0) for a LOAD whenever a STORE is pending: with
+        // the residual loads of a 64-row pass issued behind the stores of the pass before, every store of the tile waited for the
+        // one before it (six stores, five store round trips and three load latencies in a row per 192 x 128 tile: the 8-13 us per
+        // round of tiles that nothing hid, profiles/r05_bf16_tiles.txt).  Now: buffer accesses relative to the tile's first row
+        // (rows past M and columns past Cout are out-of-range offsets: no branches around memory instructions), the residual
+        // pieces of pass h + 1 are requested BEFORE the stores of pass h, and the one wait per pass sits behind the staging
+        // barrier, where the stores of the pass before have had the whole staging time to complete.
+        const int rows_left = p.M - m0 < BM ? p.M - m0 : BM;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+            static_cast<bf16_t*>(p.y) + (size_t)m0 * p.Cout, 0, (unsigned)((size_t)rows_left * p.Cout * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(p.resid ? p.resid + (size_t)m0 * p.Cout : static_cast<const bf16_t*>(p.y)), 0,
+            p.resid ? (unsigned)((size_t)rows_left * p.Cout * 2) : 0u, 0x00020000);
+        auto piece = [&](int half, int i) -> unsigned {      // byte offset of (row 64 * half + tr + i * RPP8, column col) in the tile's rows
+            return cok ? (unsigned)(((64 * half + tr + i * RPP8) * p.Cout + col) * 2) : 0x80000000u;
+        };
+        u32x4 rv[2][PASSES8];
+        if (p.resid) {
 #pragma unroll
-        for (int half = 0; half < BM / 64; ++half) {
-            u32x4 rv[PASSES8];
-            if (p.resid) {
+            for (int i = 0; i < PASSES8; ++i)
+                rv[0][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, piece(0, i), 0, 0));
+        }
 #pragma unroll
-                for (int i = 0; i < PASSES8; ++i) {
-                    const int row = m0 + 64 * half + tr + i * RPP8;
-                    rv[i] = (cok && row < p.M) ? *reinterpret_cast<const u32x4*>(p.resid + (size_t)row * p.Cout + col)
-                                               : u32x4{0u, 0u, 0u, 0u};
-                }
-            }
+        for (int half = 0; half < HALVES; ++half) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int rbase = wm * WTM + mi * 32;
@@ -145,41 +159,45 @@ __device__ __forceinline__ void epilogue_x(const ConvArgsX& p, unsigned char* sm
                 }
             }
             __syncthreads();
-            if (cok) {
+            if (p.resid) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), visible to hipcc: this pass's residual pieces (and the stores before)
+                if (half + 1 < HALVES) {
 #pragma unroll
-                for (int i = 0; i < PASSES8; ++i) {
-                    const int rr = tr + i * RPP8;
-                    const int row = m0 + 64 * half + rr;
-                    if (row < p.M) {
-                        f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc);
-                        f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc + 4);
-                        v0 = v0 * sc0 + sh0;
-                        v1 = v1 * sc1 + sh1;
-                        if (p.act) {
+                    for (int i = 0; i < PASSES8; ++i)
+                        rv[(half + 1) & 1][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, piece(half + 1, i), 0, 0));
+                }
+            }
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                v0[q] = v0[q] > 0.f ? v0[q] : 0.1f * v0[q];
-                                v1[q] = v1[q] > 0.f ? v1[q] : 0.1f * v1[q];
-                            }
-                        }
-                        if (p.resid) {
-                            v0[0] += __uint_as_float(rv[i][0] << 16);
-                            v0[1] += __uint_as_float(rv[i][0] & 0xFFFF0000u);
-                            v0[2] += __uint_as_float(rv[i][1] << 16);
-                            v0[3] += __uint_as_float(rv[i][1] & 0xFFFF0000u);
-                            v1[0] += __uint_as_float(rv[i][2] << 16);
-                            v1[1] += __uint_as_float(rv[i][2] & 0xFFFF0000u);
-                            v1[2] += __uint_as_float(rv[i][3] << 16);
-                            v1[3] += __uint_as_float(rv[i][3] & 0xFFFF0000u);
-                        }
-                        u32x4 pk;
-                        pk[0] = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
-                        pk[1] = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
-                        pk[2] = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
-                        pk[3] = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
-                        *reinterpret_cast<u32x4*>(static_cast<bf16_t*>(p.y) + (size_t)row * p.Cout + col) = pk;
+            for (int i = 0; i < PASSES8; ++i) {
+                const int rr = tr + i * RPP8;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + rr * LDC + tc + 4);
+                v0 = v0 * sc0 + sh0;
+                v1 = v1 * sc1 + sh1;
+                if (p.act) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v0[q] = v0[q] > 0.f ? v0[q] : 0.1f * v0[q];
+                        v1[q] = v1[q] > 0.f ? v1[q] : 0.1f * v1[q];
                     }
                 }
+                if (p.resid) {
+                    const u32x4 r4 = rv[half & 1][i];
+                    v0[0] += __uint_as_float(r4[0] << 16);
+                    v0[1] += __uint_as_float(r4[0] & 0xFFFF0000u);
+                    v0[2] += __uint_as_float(r4[1] << 16);
+                    v0[3] += __uint_as_float(r4[1] & 0xFFFF0000u);
+                    v1[0] += __uint_as_float(r4[2] << 16);
+                    v1[1] += __uint_as_float(r4[2] & 0xFFFF0000u);
+                    v1[2] += __uint_as_float(r4[3] << 16);
+                    v1[3] += __uint_as_float(r4[3] & 0xFFFF0000u);
+                }
+                u32x4 pk;
+                pk[0] = (unsigned)f32_to_bf16(v0[0]) | ((unsigned)f32_to_bf16(v0[1]) << 16);
+                pk[1] = (unsigned)f32_to_bf16(v0[2]) | ((unsigned)f32_to_bf16(v0[3]) << 16);
+                pk[2] = (unsigned)f32_to_bf16(v1[0]) | ((unsigned)f32_to_bf16(v1[1]) << 16);
+                pk[3] = (unsigned)f32_to_bf16(v1[2]) | ((unsigned)f32_to_bf16(v1[3]) << 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, piece(half, i), 0, 0);
             }
             __syncthreads();
         }
