@@ -138,9 +138,12 @@ def conv_flops(table, n, h, w):
                      for (k, s, cin, cout, bn), d in zip(table, layer_divisors(table))])
 
 
-def conv_bytes(table, n, h, w, esize=4):
+def conv_bytes(table, n, h, w, esize=4, fused=None):
     """Algorithmic HBM bytes per layer: input + packed kernel + output (+ the residual the 3x3 of a
-    res_block adds).  The upsampled/concatenated input of the two head convs is counted at its stored size."""
+    res_block adds).  The upsampled/concatenated input of the two head convs is counted at its stored size.
+    `fused` (model.layer_fused): a layer that runs inside the next layer's launch (1) neither writes its output nor has the
+    next layer read it - the tensor between them never reaches memory -, and a fused residual block reads its input once (it is
+    the 1x1 conv's operand and the shortcut): the bytes of a fused pair are those of ONE kernel, booked on the launching layer."""
     out = []
     resid = set()
     idx = 2
@@ -152,10 +155,15 @@ def conv_bytes(table, n, h, w, esize=4):
     for i, ((k, s, cin, cout, bn), d) in enumerate(zip(table, layer_divisors(table))):
         ho, wo = h // d, w // d
         hi, wi = ho * s, wo * s
-        b = n * hi * wi * cin * esize + k * k * cin * cout * 4 + n * ho * wo * cout * esize
-        if i in resid:
-            b += n * ho * wo * cout * esize
-        out.append(float(b))
+        b_in, b_w, b_out = n * hi * wi * cin * esize, k * k * cin * cout * 4, n * ho * wo * cout * esize
+        if i == 0:
+            b_in = n * hi * wi * cin * 4               # the image is fp32 in every mode
+        b_res = b_out if i in resid else 0
+        if fused is not None and fused[i] == 1:        # runs inside the next launch: its output never reaches memory
+            b_out = 0
+        if fused is not None and fused[i] == 2:        # ... whose input is that tensor; a fused block's shortcut is its first input
+            b_in, b_res = 0, 0
+        out.append(float(b_in + b_w + b_out + b_res))
     return np.array(out)
 
 
@@ -181,6 +189,15 @@ def traffic_from_profile(names):
         except (OSError, KeyError, ValueError):
             continue
     return None, stale
+
+
+def library_stamp():
+    """Which HIP library this process measured (Y3_LIB_PATH lets tools load a probe build): the path ctypes loaded,
+    whether an override was in force, and the hash of the kernel sources in the tree beside this file."""
+    from yolov3_tensorflow_amd import _lib
+    from yolov3_tensorflow_amd.build import csrc_sha16
+    return {"lib_path": os.path.relpath(_lib.LIB_PATH, ROOT) if _lib.LIB_PATH.startswith(ROOT) else _lib.LIB_PATH,
+            "override_env_Y3_LIB_PATH": bool(os.environ.get("Y3_LIB_PATH")), "csrc_sha16": csrc_sha16()}
 
 
 def cpu_quota_cores():
@@ -489,6 +506,8 @@ def main(argv=None):
         watchdog.cancel()
         set_workload(args.workload, args.batch)
     if rank == 0:
+        if isinstance(out, dict):
+            out["library"] = library_stamp()
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
@@ -897,7 +916,8 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH * args.steps / elapsed
     flops = conv_flops(table, BATCH, SIZE, SIZE)
-    nbytes = conv_bytes(table, BATCH, SIZE, SIZE, 2 if bf16 else 4)
+    fused = model.layer_fused(BATCH, SIZE, SIZE)
+    nbytes = conv_bytes(table, BATCH, SIZE, SIZE, 2 if bf16 else 4, fused)
     is3 = np.array([k == 3 and cin != 3 for (k, s, cin, cout, bn) in table])
     is_wino, fac = winograd_issue_factors(table, args.precision if wino else 'f32', SIZE)
     issued = flops * fac                                           # MFMA work the kernels actually issue
@@ -918,16 +938,19 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
                                                 'f32_bf16x3': PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
     bound_ms = np.maximum(nbytes / (PEAK_HBM_TBPS * 1e12), issued / (peak * 1e12)) * 1e3      # per layer
     traffic, traffic_src = (None, None) if split else traffic_from_profile(
-        ['r05_pmc_traffic_bf16.json', 'r04_pmc_traffic_bf16.json', 'r03_pmc_traffic_bf16.json'] if bf16 else
-        ['r05_pmc_traffic_wino.json', 'r04_pmc_traffic_wino.json', 'r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
+        ['r06_pmc_traffic_bf16.json', 'r05_pmc_traffic_bf16.json', 'r04_pmc_traffic_bf16.json', 'r03_pmc_traffic_bf16.json'] if bf16 else
+        ['r06_pmc_traffic_wino.json', 'r05_pmc_traffic_wino.json', 'r04_pmc_traffic_wino.json', 'r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
     kernel = ("conv_bf16p_kernel / conv_bf16x_kernel (3x3 implicit-GEMM convs with Cout > 64, bf16 storage, LDS-DMA staged: "
               "the pipelined kernel on 192x256 / 192x128 tiles where the library's tile model picks them - the 76-, 38- and "
               "19-grid layers at this size -, 256-row and 128x128 tiles elsewhere; see DESIGN.md 4.9)" if bf16 else
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else
-              "the Winograd kernels of the stride-1 3x3 convs: conv_wino8_f32_kernel (F(2x2,3x3), %d launches) and "
-              "conv_wino44_f32_kernel (F(4x4,3x3), %d launches: the convs with Cin >= 64); `achieved` = useful MFMA work "
+              "the Winograd kernels of the stride-1 3x3 convs: conv_wino8_f32_kernel (F(2x2,3x3), %d launches) and the "
+              "F(4x4,3x3) form (%d layers: the convs with Cin >= 64) - one kernel (conv_wino44_f32_kernel, input transform "
+              "inside the K-loop) where Cout < 512, two kernels (wino44_input_transform_kernel writes V = B^T d B once, "
+              "conv_wino44v_f32_kernel runs the 36 batched GEMMs + the output transform) where Cout >= 512; a layer's time is "
+              "the time of ALL its kernels (hipEvents around the layer); `achieved` = useful MFMA work "
               "per second (16/36 resp. 36/144 of the direct-convolution FLOPs, per layer by the kernel the library picked; "
               "zero tiles padding a 13-/26-grid to a multiple of 4 are issued but not counted); `achieved_algorithmic` "
               "counts the direct-convolution FLOPs" % (int(is_wino.sum()) - n_f44, n_f44)

@@ -302,6 +302,10 @@ int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* works
 int y3_net_set_profiling(y3_net* net, int enabled);
 int y3_net_get_layer_ms(y3_net* net, float* ms, int count);
 int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w);
+/* which launches y3_net_forward fuses at this size (dtype as set): 0 = layer i has its own launch; 1 = it runs inside the NEXT
+ * layer's launch (its output tensor never reaches memory; its profiled time is 0); 2 = its launch also runs the layer before it
+ * (stem + stride-2 conv in the fp32 and bf16 paths, the first residual block in the bf16 path: model.py:34-40 of the reference) */
+int y3_net_layer_fused(const y3_net* net, int i, int n, int h, int w);
 
 /* graph topology of y3_net (tensor ids: 0 = network input, 1.. = conv outputs in creation order; -1 = none) */
 int y3_net_layer_graph(const y3_net* net, int i, int* src, int* up, int* resid, int* dst, int* act);

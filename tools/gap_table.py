@@ -34,7 +34,7 @@ def w44_tiles(n, g, mosaic=True):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('csv', nargs='?', default=os.path.join(ROOT, 'profiles', 'r05_layers_bs32_416_wino.csv'))
+    ap.add_argument('csv', nargs='?', default=os.path.join(ROOT, 'profiles', 'r06_layers_bs32_416_wino.csv'))
     ap.add_argument('--r03', action='store_true', help="round 3's F(4x4) layer set")
     ap.add_argument('--mosaic', action='store_true', help='the csv was taken with the mosaic tiling of the 13- / 26-grids '
                     '(profiles/r04_layers_bs32_416_wino.csv was not)')
@@ -68,10 +68,9 @@ def main():
     fused01 = len(ms) > 1 and names[0] == 'stem' and ms[0] < 0.05 * ms[1]
     if fused01:
         names[0] = names[1] = 'stem + 3x3 s2 32->64 (fused)'
-        dropped = 2.0 * args.batch * args.size * args.size * 32 * 4
-        nbytes = np.array(nbytes, dtype=np.float64)
-        nbytes[0] = max(0.0, nbytes[0] + nbytes[1] - dropped)
-        nbytes[1] = 0.0
+        fused = np.zeros(len(ms), int)
+        fused[0], fused[1] = 1, 2                    # (what model.layer_fused / y3_net_layer_fused reports on the GPU box)
+        nbytes = bench.conv_bytes(table, args.batch, args.size, args.size, 4, fused)
     issued = flops * np.array(factor)
     bound = np.maximum(nbytes / (bench.PEAK_HBM_TBPS * 1e12), issued / (bench.PEAK_FP32_MFMA_TFLOPS * 1e12)) * 1e3
     groups = collections.OrderedDict()

@@ -159,6 +159,7 @@ PROTOTYPES = {
     "y3_net_set_profiling": (c_int, [c_void_p, c_int]),
     "y3_net_get_layer_ms": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "y3_net_layer_is_streamk": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "y3_net_layer_fused": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
 }
 
 _lib = None

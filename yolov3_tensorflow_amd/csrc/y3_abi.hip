@@ -412,6 +412,44 @@ extern "C" size_t y3_net_workspace_bytes(const y3_net* net, int n, int h, int w)
     return net->plan_bytes;
 }
 
+// Layers that exist to move bytes run fused with their only reader (round 5):
+//   bf16 storage: the stem and the stride-2 conv behind it are ONE kernel when nothing else reads the stem's output
+//   (y3_conv_bf16s.hip: the 378 MB tensor between them at 608x608, bs=16 never exists); fp32 (dtypes 0 and 4 - both run these
+//   two layers on the direct kernels -): the same fusion, y3_conv_f32s.hip;
+static bool net_fuses_01(const y3_net* net, int n, int h, int w) {
+    const size_t nl = net->layers.size();
+    const bool f32_direct01 = net->dtype == 0 || net->dtype == 4;
+    if (!((net->dtype == 1 || f32_direct01) && nl >= 2)) return false;
+    const Layer &l0 = net->layers[0], &l1 = net->layers[1];
+    y3_conv_desc d0 = {n, h, w, l0.cin, l0.c_up, l0.cout, l0.k, l0.stride, l0.act};
+    y3_conv_desc d1 = {n, h / net->tensors[l1.src].sdiv, w / net->tensors[l1.src].sdiv, l1.cin, l1.c_up, l1.cout, l1.k,
+                       l1.stride, l1.act};
+    return l0.src == 0 && l1.src == l0.dst && net->tensors[l0.dst].last_use == 1 && net->tensors[l0.dst].ext < 0 &&
+           l0.resid < 0 && l1.resid < 0 && net->tensors[l1.dst].ext < 0 &&
+           (net->dtype == 1 ? y3_conv_bf16_stem_s2_takes(&d0, &d1) : y3_conv_f32_stem_s2_takes(&d0, &d1)) == 1;
+}
+//   ... and, bf16 only, the first residual block (layers 2 and 3: 1x1 64 -> 32, 3x3 32 -> 64 + shortcut) likewise (y3_conv_bf16b.hip).
+static bool net_fuses_23(const y3_net* net, int n, int h, int w) {
+    if (!(net->dtype == 1 && net->layers.size() >= 4)) return false;
+    const Layer &l2 = net->layers[2], &l3 = net->layers[3];
+    const int sd = net->tensors[l2.src].sdiv;
+    y3_conv_desc d2 = {n, h / sd, w / sd, l2.cin, l2.c_up, l2.cout, l2.k, l2.stride, l2.act};
+    y3_conv_desc d3 = {n, h / net->tensors[l3.src].sdiv, w / net->tensors[l3.src].sdiv, l3.cin, l3.c_up, l3.cout, l3.k,
+                       l3.stride, l3.act};
+    return l3.src == l2.dst && l3.resid == l2.src && l2.resid < 0 && l2.src != 0 && net->tensors[l2.dst].last_use == 3 &&
+           net->tensors[l2.dst].ext < 0 && net->tensors[l3.dst].ext < 0 && net->tensors[l2.src].ext < 0 &&
+           y3_conv_bf16_resblock64_takes(&d2, &d3) == 1;
+}
+
+// 0: layer i has its own launch; 1: it runs inside the NEXT layer's launch (its output tensor never exists; its profiled time
+// is 0); 2: its launch also runs the layer before it.
+extern "C" int y3_net_layer_fused(const y3_net* net, int i, int n, int h, int w) {
+    if (!net || i < 0 || i >= (int)net->layers.size() || n <= 0 || h <= 0 || w <= 0) return 0;
+    if (i <= 1 && net_fuses_01(net, n, h, w)) return i == 0 ? 1 : 2;
+    if ((i == 2 || i == 3) && net_fuses_23(net, n, h, w)) return i == 2 ? 1 : 2;
+    return 0;
+}
+
 extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, void* workspace,
                               size_t workspace_bytes, float* fm1, float* fm2, float* fm3) {
     Y3_CHECK_ARG(net && x && workspace && fm1 && fm2 && fm3, "y3_net_forward: null argument");
@@ -454,32 +492,7 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
     // every stream-K layer polls its own pre-zeroed flag region: ONE memset per forward instead of one per launch
     unsigned* flag_base = reinterpret_cast<unsigned*>(base + net->arena_bytes + net->scratch_bytes);
     if (net->flags_bytes) Y3_CHECK_HIP(hipMemsetAsync(flag_base, 0, net->flags_bytes, st));
-    // bf16 storage: the stem and the stride-2 conv behind it run as ONE kernel when nothing else reads the stem's output
-    // (y3_conv_bf16s.hip: the 378 MB tensor between them at 608x608, bs=16 never exists)
-    // (fp32, dtypes 0 and 4 - both run these two layers on the direct kernels -: the same fusion, y3_conv_f32s.hip)
-    bool fuse01 = false;
-    const bool f32_direct01 = net->dtype == 0 || net->dtype == 4;
-    if ((net->dtype == 1 || f32_direct01) && nl >= 2) {
-        const Layer &l0 = net->layers[0], &l1 = net->layers[1];
-        y3_conv_desc d0 = {n, h, w, l0.cin, l0.c_up, l0.cout, l0.k, l0.stride, l0.act};
-        y3_conv_desc d1 = {n, h / net->tensors[l1.src].sdiv, w / net->tensors[l1.src].sdiv, l1.cin, l1.c_up, l1.cout, l1.k,
-                           l1.stride, l1.act};
-        fuse01 = l0.src == 0 && l1.src == l0.dst && net->tensors[l0.dst].last_use == 1 && net->tensors[l0.dst].ext < 0 &&
-                 l0.resid < 0 && l1.resid < 0 && net->tensors[l1.dst].ext < 0 &&
-                 (net->dtype == 1 ? y3_conv_bf16_stem_s2_takes(&d0, &d1) : y3_conv_f32_stem_s2_takes(&d0, &d1)) == 1;
-    }
-    // ... and the first residual block (layers 2 and 3: 1x1 64 -> 32, 3x3 32 -> 64 + shortcut) likewise (y3_conv_bf16b.hip)
-    bool fuse23 = false;
-    if (net->dtype == 1 && nl >= 4) {
-        const Layer &l2 = net->layers[2], &l3 = net->layers[3];
-        const int sd = net->tensors[l2.src].sdiv;
-        y3_conv_desc d2 = {n, h / sd, w / sd, l2.cin, l2.c_up, l2.cout, l2.k, l2.stride, l2.act};
-        y3_conv_desc d3 = {n, h / net->tensors[l3.src].sdiv, w / net->tensors[l3.src].sdiv, l3.cin, l3.c_up, l3.cout, l3.k,
-                           l3.stride, l3.act};
-        fuse23 = l3.src == l2.dst && l3.resid == l2.src && l2.resid < 0 && l2.src != 0 && net->tensors[l2.dst].last_use == 3 &&
-                 net->tensors[l2.dst].ext < 0 && net->tensors[l3.dst].ext < 0 && net->tensors[l2.src].ext < 0 &&
-                 y3_conv_bf16_resblock64_takes(&d2, &d3) == 1;
-    }
+    const bool fuse01 = net_fuses_01(net, n, h, w), fuse23 = net_fuses_23(net, n, h, w);
     for (size_t i = 0; i < nl; ++i) {
         const Layer& l = net->layers[i];
         const Tensor& in = net->tensors[l.src];
@@ -537,6 +550,7 @@ extern "C" int y3_net_forward(y3_net* net, const float* x, int n, int h, int w, 
 
 extern "C" int y3_net_layer_is_streamk(const y3_net* net, int i, int n, int h, int w) {
     if (!net || i < 0 || i >= (int)net->layers.size() || n <= 0 || h <= 0 || w <= 0 || net->dtype == 1) return 0;
+    if (y3_net_layer_fused(net, i, n, h, w)) return 0;      // the fused first layers have no stream-K schedule
     const Layer& l = net->layers[i];
     const Tensor& in = net->tensors[l.src];
     y3_conv_desc d;

@@ -78,7 +78,10 @@ constexpr int VSTAGE = 2 * STAGE;              // 36,864 B: the two-kernel form 
 constexpr int LDS_RING = 4 * STAGE;            // 73,728 B of K-loop buffers either way
 constexpr int LDS_BYTES = LDS_RING + 512;      // + the tiles' pixel-index parts: 74,240 B, two workgroups per CU
 constexpr unsigned OOB = 0x80000000u;
-constexpr int BDEPTH = 6;                      // (one-kernel form) weight fragment loads in flight per wave: one load = one lane's 16
+#ifndef W44_BDEPTH
+#define W44_BDEPTH 6
+#endif
+constexpr int BDEPTH = W44_BDEPTH;             // (one-kernel form) weight fragment loads in flight per wave: one load = one lane's 16
                                                // bytes for a PAIR of positions (divides 18: the window runs on across K-steps)
 #ifndef W44V_BDEPTH
 #define W44V_BDEPTH 12

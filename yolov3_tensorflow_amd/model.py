@@ -260,6 +260,13 @@ class yolov3(object):
         L = _lib.lib()
         return np.array([L.y3_net_layer_is_streamk(ent['handle'], i, n, h, w) for i in range(len(ent['table']))], bool)
 
+    def layer_fused(self, n, h, w, device=None):
+        """Per layer (y3_net_layer_fused): 0 = own launch, 1 = runs inside the next layer's launch (its output never reaches
+        memory, its profiled time is 0), 2 = its launch also runs the layer before it."""
+        ent = self._get_net(device if device is not None else fw.default_device())
+        L = _lib.lib()
+        return np.array([L.y3_net_layer_fused(ent['handle'], i, n, h, w) for i in range(len(ent['table']))], int)
+
     def layer_times_ms(self, inputs, iters=5):
         """Per-layer hipEvent timing of the fused plan (for profiles/ and DESIGN.md tables)."""
         x = fw.as_device_f32(inputs)
