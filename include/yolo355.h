@@ -151,7 +151,10 @@ int y3_conv2d_fwd_bf16(y3_ctx* ctx, const y3_conv_desc* d, const void* x, const 
  * conv2d(net, 64, 3, strides=2), each with folded batch norm and LeakyReLU), bf16 storage: x = the fp32 image [n,h,w,3],
  * w0_hwio = the stem's fp32 HWIO kernel [3][3][3][32], w1_packed = the second conv's kernel from y3_pack_conv_weights_bf16
  * (k = 3, cin = 32, cout = 64), y = bf16 [n,h/2,w/2,64].  The stem's output exists only in the LDS; both convs accumulate
- * in fp32 on the bf16 matrix pipe (the image is rounded to bf16 like every other activation of this path).  h and w even.
+ * in fp32 on the bf16 matrix pipe.  The stem does NOT round the image: the fp32 image and the stem's kernel are each split once
+ * into a high and a low bf16 part and the conv runs as three products (hi*hi + hi*lo + lo*hi: fp32-grade; a plainly rounded
+ * image cost 0.05 of the mAP-style gate of tests/test_bf16_gpu.py); its output is rounded to bf16 like every other activation
+ * of this path.  h and w even.
  * y3_net_forward (dtype 1) uses it for its layers 0 and 1. */
 int y3_conv2d_fwd_bf16_stem_s2(y3_ctx* ctx, int n, int h, int w, const float* x, const float* w0_hwio, const float* scale0,
                                const float* shift0, const void* w1_packed, const float* scale1, const float* shift1, void* y);

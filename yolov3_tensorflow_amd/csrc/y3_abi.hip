@@ -18,6 +18,30 @@ void y3_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* y3_last_error(void) { return g_err; }
+
+int y3_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= Y3_MAX_DEVICES) return -1;
+    return dev;
+}
+
+size_t y3_device_max_lds() {
+    static size_t cached[Y3_MAX_DEVICES] = {};       // benign race (idempotent)
+    const int dev = y3_current_device();
+    if (dev >= 0 && cached[dev]) return cached[dev];
+    // (the per-block figure is the 64 KB default of static allocations on some runtimes; what a kernel may ask for with
+    // hipFuncAttributeMaxDynamicSharedMemorySize is bounded by the CU's LDS: take the largest of the three answers)
+    int d = 0, v = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 0;
+    for (hipDeviceAttribute_t a : {hipDeviceAttributeMaxSharedMemoryPerBlock, hipDeviceAttributeSharedMemPerBlockOptin,
+                                   hipDeviceAttributeMaxSharedMemoryPerMultiprocessor}) {
+        int q = 0;
+        if (hipDeviceGetAttribute(&q, a, d) == hipSuccess && q > v) v = q;
+    }
+    if (v <= 0) return 0;
+    if (dev >= 0) cached[dev] = (size_t)v;
+    return (size_t)v;
+}
 extern "C" int y3_abi_version(void) { return Y3_ABI_VERSION; }
 
 extern "C" int y3_ctx_create(int device, void* stream, y3_ctx** out) {

@@ -330,10 +330,11 @@ template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = fal
 int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     using G = Geo<BM, BN, WGM, WGN>;
     auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, TMODE, STATS>;
-    static bool attr_set = false;  // per instantiation; benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};  // per instantiation; benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int nbm = (a.M + BM - 1) / BM;
     const int nbn = (a.Cout + BN - 1) / BN;
@@ -355,10 +356,11 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     using G = Geo<BM, BN, WGM, WGN>;
     auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, false, true, TMODE, STATS>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         if (int rc = set_lds_attr(kern, G::LDS_BYTES)) return rc;
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), G::LDS_BYTES, stream, a);
     Y3_CHECK_HIP(hipGetLastError());

@@ -266,6 +266,10 @@ int y3_conv_bf16_resblock64_takes(const y3_conv_desc* d2, const y3_conv_desc* d3
         off = (e && e[0] == '0') ? 1 : 0;
     }
     if (off) return 0;
+    // (the kernel reads the 1x1 weights in the [cin/32][cout][32] packing; an experiments build that sends the 64 -> 32 conv to
+    // the ring kernel packs them [cin/64][cout][64]: the plan then runs the two layers unfused)
+    if (y3_conv_bf16r_takes(1, 64)) return 0;
+    if (y3_device_max_lds() < (size_t)LDS_BYTES) return 0;      // (the device must offer the kernel's LDS: the plan then runs the layers unfused)
     return d2->k == 1 && d2->stride == 1 && d2->cin == 64 && d2->cout == 32 && d2->c_up == 0 &&
            d3->k == 3 && d3->stride == 1 && d3->cin == 32 && d3->cout == 64 && d3->c_up == 0 &&
            d3->n == d2->n && d3->h == d2->h && d3->w == d2->w;
@@ -284,11 +288,12 @@ int y3_launch_conv_bf16_resblock64(hipStream_t stream, int n, int h, int w, cons
     a.N = n; a.H = h; a.W = w; a.act2 = act2; a.act3 = act3;
     a.tiles_y = (h + TS - 1) / TS; a.tiles_x = (w + TS - 1) / TS;
     a.ntiles = n * a.tiles_y * a.tiles_x;
-    static bool attr_set = false;     // benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};     // benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_resblock64_bf16_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int grid = a.ntiles < 256 ? a.ntiles : 256;
     hipLaunchKernelGGL(conv_resblock64_bf16_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, stream, a);

@@ -384,10 +384,11 @@ template <int MI, int NI, int WM, int WN, int NSTAGE, bool UPCAT>
 int launch_r(hipStream_t stream, const ConvArgsR& a) {
     auto kern = conv1x1_bf16r_kernel<MI, NI, WM, WN, NSTAGE, UPCAT>;
     constexpr RTile t = rtile<MI, NI, WM, WN, NSTAGE>();
-    static bool attr_set = false;     // per instantiation; benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};     // per instantiation; benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, t.lds));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int nbm = (a.M + t.bm - 1) / t.bm, nbn = (a.Cout + t.bn - 1) / t.bn;
     const long long ntiles = (long long)nbm * nbn;

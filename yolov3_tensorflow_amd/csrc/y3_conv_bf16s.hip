@@ -289,6 +289,7 @@ int y3_conv_bf16_stem_s2_takes(const y3_conv_desc* d0, const y3_conv_desc* d1) {
         off = (e && e[0] == '0') ? 1 : 0;
     }
     if (off) return 0;
+    if (y3_device_max_lds() < (size_t)LDS_BYTES) return 0;      // (the device must offer the kernel's LDS: the plan then runs the layers unfused)
     return d0->k == 3 && d0->stride == 1 && d0->cin == 3 && d0->cout == 32 && d0->c_up == 0 &&
            d1->k == 3 && d1->stride == 2 && d1->cin == 32 && d1->cout == 64 && d1->c_up == 0 &&
            d1->n == d0->n && d1->h == d0->h && d1->w == d0->w && d0->h % 2 == 0 && d0->w % 2 == 0;
@@ -306,11 +307,12 @@ int y3_launch_conv_bf16_stem_s2(hipStream_t stream, int n, int h, int w, const f
     a.N = n; a.H = h; a.W = w; a.act0 = act0; a.act1 = act1;
     a.tiles_y = (h / 2 + TS - 1) / TS; a.tiles_x = (w / 2 + TS - 1) / TS;
     a.ntiles = n * a.tiles_y * a.tiles_x;
-    static bool attr_set = false;     // benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};     // benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_s2_bf16_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int grid = a.ntiles < 256 ? a.ntiles : 256;
     hipLaunchKernelGGL(conv_stem_s2_bf16_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, stream, a);

@@ -688,11 +688,12 @@ template <int BM, int BN, int WM, int WN, int BK, int KS, bool UPCAT>
 int launch_x(hipStream_t stream, const ConvArgsX& a) {
     auto kern = conv_bf16x_kernel<BM, BN, WM, WN, BK, KS, UPCAT>;
     constexpr size_t lds = (size_t)2 * (BM + BN) * BK * 2;
-    static bool attr_set = false;     // per instantiation; benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};     // per instantiation; benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(64 * WM * WN), lds, stream, a);
@@ -705,11 +706,12 @@ int launch_p(hipStream_t stream, const ConvArgsX& a) {
     auto kern = conv_bf16p_kernel<MI, NI, WM, WN, KS, UPCAT>;
     constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * 128;
-    static bool attr_set = false;     // per instantiation; benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};     // per instantiation; benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(512), lds, stream, a);
@@ -803,7 +805,7 @@ int y3_conv_bf16x_takes(int k, int cin) {
     return off ? 0 : 1;
 }
 
-// Which tile the bf16 path runs this conv on (host-only; tests/test_host_logic.py holds the configs[4] table against it):
+// Which tile the bf16 path runs this conv on (host-only; tests/test_wino44_tiling_cpu.py holds the configs[4] table against it):
 // 'A'..'E' = the 3x3 tiles above, 'a'..'g' = the ring kernel's tiles, 'x' = the narrow 3x3 forms (Cin = 32 / Cout <= 64), 'o' = the
 // register-staged kernel of y3_conv_bf16.hip, 's' = the Cin = 3 stem
 extern "C" int y3_conv_bf16_tile(const y3_conv_desc* d) {

@@ -300,10 +300,11 @@ template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, int NP>
 int launch_dp(hipStream_t stream, const ConvArgs& a) {
     auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, NP>;
     constexpr size_t lds = split_lds_bytes<BM, BN, NP>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         if (int rc = set_lds_attr(kern, lds)) return rc;
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int nbm = (a.M + BM - 1) / BM;
     const int nbn = (a.Cout + BN - 1) / BN;
@@ -317,10 +318,11 @@ int launch_sk(hipStream_t stream, const ConvArgs& a) {
     constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2;
     auto kern = conv_mfma_split_kernel<BM, BN, WGM, WGN, KS, false, true, NP>;
     constexpr size_t lds = split_lds_bytes<BM, BN, NP>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         if (int rc = set_lds_attr(kern, lds)) return rc;
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.workers), dim3(256), lds, stream, a);
     Y3_CHECK_HIP(hipGetLastError());

@@ -750,14 +750,15 @@ int y3_launch_conv_wino(hipStream_t stream, const y3_conv_desc* d, const float* 
     auto kern = a.stats ? conv_wino8_f32_kernel<false, true> : conv_wino8_f32_kernel<false, false>;
     auto kern_sk = a.stats ? conv_wino8_f32_kernel<true, true> : conv_wino8_f32_kernel<true, false>;
     {
-        static bool attr_set[2] = {false, false};   // per pair of instantiations; benign race (idempotent)
+        static bool attr_set[2][Y3_MAX_DEVICES] = {};   // per pair of instantiations and device; benign race (idempotent)
         const int slot = a.stats ? 1 : 0;
-        if (!attr_set[slot]) {
+        const int dev_ = y3_current_device();
+        if (dev_ < 0 || !attr_set[slot][dev_]) {
             Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set[slot] = true;
+            if (dev_ >= 0) attr_set[slot][dev_] = true;
         }
     }
     const int nbt = (a.T + BT - 1) / BT, nbn = (a.Cout + BNW - 1) / BNW;

@@ -821,13 +821,11 @@ int y3_conv_wino44_two_pass_impl(const y3_conv_desc* d) {
 }
 
 static int w44_set_lds(const void* kern, int slot) {
-    // per device and kernel (idempotent: a race sets it twice)
-    static bool done[4][16] = {};
-    int dev = 0;
-    Y3_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 16 || !done[slot][dev]) {
+    static bool done[4][Y3_MAX_DEVICES] = {};      // per kernel and device (idempotent: a race sets it twice)
+    const int dev = y3_current_device();
+    if (dev < 0 || !done[slot][dev]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        if (dev < 16) done[slot][dev] = true;
+        if (dev >= 0) done[slot][dev] = true;
     }
     return Y3_OK;
 }

@@ -50,6 +50,11 @@ static inline const char* y3_exp_env(const char*) { return nullptr; }
 
 void y3_set_error(const char* fmt, ...);
 
+// The process may drive several devices: "hipFuncSetAttribute done" flags are kept per (kernel instantiation, device).
+constexpr int Y3_MAX_DEVICES = 16;
+int y3_current_device();            // hipGetDevice, or -1 (no device / beyond Y3_MAX_DEVICES: callers then set the attribute every time)
+size_t y3_device_max_lds();         // dynamic LDS one workgroup may ask for on the current device (cached per device); 0: unknown
+
 #define Y3_CHECK_ARG(cond, ...)                \
     do {                                       \
         if (!(cond)) {                         \

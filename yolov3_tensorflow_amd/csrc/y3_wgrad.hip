@@ -421,12 +421,13 @@ extern "C" int y3_conv_wgrad(y3_ctx* ctx, const y3_conv_desc* d, const float* x,
     wgrad_split(d, &nsplit, &a.chunk);
     a.nsplit = nsplit;
     a.out = nsplit == 1 ? dw_hwio : static_cast<float*>(scratch);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<128, 2, 2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(2 * WBK * (WLD + 128) * sizeof(float))));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const size_t lds = (size_t)2 * WBK * (WLD + bnt) * sizeof(float);
     if (bnt == 128)

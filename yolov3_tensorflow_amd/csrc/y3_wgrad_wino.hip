@@ -400,11 +400,12 @@ int y3_launch_conv_wgrad_wino(hipStream_t stream, const y3_conv_desc* d, const f
     wgw_split(d, &a.nsplit, &a.ksteps);
     a.out = a.nsplit == 1 ? dw_hwio : static_cast<float*>(scratch);
     constexpr size_t lds = (size_t)4 * STAGE;
-    static bool attr_set = false;   // benign race (idempotent)
-    if (!attr_set) {
+    static bool attr_set[Y3_MAX_DEVICES] = {};   // benign race (idempotent)
+    const int dev_ = y3_current_device();
+    if (dev_ < 0 || !attr_set[dev_]) {
         Y3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_wino_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev_ >= 0) attr_set[dev_] = true;
     }
     const int wt = (d->cin / 64) * (d->cout / 64);
     hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3(wt, a.nsplit), dim3(256), lds, stream, a);
