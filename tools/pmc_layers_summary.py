@@ -12,7 +12,7 @@ import json
 import sys
 from collections import OrderedDict, defaultdict
 
-CONV = ('conv_wino', 'conv_mfma_f32_kernel', 'conv_stem_kernel', 'conv_mfma_bf16_kernel', 'conv_bf16x_kernel',
+CONV = ('conv_wino', 'wino44_input_transform_kernel', 'conv_mfma_f32_kernel', 'conv_stem_kernel', 'conv_mfma_bf16_kernel', 'conv_bf16x_kernel',
         'conv_bf16p_kernel', 'conv1x1_bf16r_kernel', 'conv_stem_bf16_kernel', 'conv_stem_mfma_kernel', 'conv_stem_s2_f32_kernel',
         'conv_stem_s2_bf16_kernel', 'conv_resblock64_bf16_kernel')
 # the kernels a forward starts with (round 5: the stem may be fused with the conv behind it)
@@ -41,6 +41,19 @@ def main():
         # are then launches, in layer order)
         starts = [i for i, (n, _) in enumerate(convs) if any(k in n for k in FIRST)]
         last = convs[starts[-1]:] if starts else convs[-75:]
+        # round 6: an F(4x4,3x3) layer may be TWO launches (wino44_input_transform_kernel writes V, conv_wino44v_f32_kernel reads
+        # it): one row, the counters of both added up (the kernel name keeps both)
+        merged = []
+        for n, c in last:
+            if merged and 'wino44_input_transform_kernel' in merged[-1][0] and 'conv_wino44v' not in merged[-1][0]:
+                pn, pc = merged.pop()
+                cc = defaultdict(float, pc)
+                for k, v in c.items():
+                    cc[k] += v
+                merged.append((pn.split('(')[0] + ' + ' + n, cc))
+            else:
+                merged.append((n, c))
+        last = merged
         if layers is None:
             layers = [dict(kernel=n.replace('(anonymous namespace)::', '').replace('y3conv::', '').split('(')[0].replace('void ', '')) for n, _ in last]
         for row, (n, c) in zip(layers, last):
