@@ -942,7 +942,7 @@ def run_forward(args, y3, torch, dist, rank, world, distributed, barrier, max_ov
         ['r06_pmc_traffic_wino.json', 'r05_pmc_traffic_wino.json', 'r04_pmc_traffic_wino.json', 'r03_pmc_traffic_wino.json', 'r02_pmc_traffic_wino.json'] if wino else ['r03_pmc_traffic.json', 'r01_pmc_traffic.json'])
     kernel = ("conv_bf16p_kernel / conv_bf16x_kernel (3x3 implicit-GEMM convs with Cout > 64, bf16 storage, LDS-DMA staged: "
               "the pipelined kernel on 192x256 / 192x128 tiles where the library's tile model picks them - the 76-, 38- and "
-              "19-grid layers at this size -, 256-row and 128x128 tiles elsewhere; see DESIGN.md 4.9)" if bf16 else
+              "19-grid layers at this size -, 256-row and 128x128 tiles elsewhere; see DESIGN.md 4.3)" if bf16 else
               "conv_mfma_split_kernel<128,128,2,2,3,false,true,%d,false> (3x3 implicit-GEMM conv on the bf16 matrix pipe, "
               "stream-K schedule; peak = 2500/%d fp32-equivalent)" % ((3, 6) if args.precision == 'f32_bf16x6' else (2, 3))
               if split else

@@ -36,7 +36,7 @@ OPTIONS = (
     ('nms_topk', int, 400, 'most detections kept per class'),
     ('use_voc_07_metric', _flag, False, 'true: the 11-point VOC 2007 AP'),
     ('batch_size', int, 32, 'images per device batch (the reference evaluates one at a time)'),
-    ('compute_dtype', str, 'f32_wino', 'f32_wino (exact fp32, Winograd 3x3 kernels) | f32 | f32_bf16x6 (DESIGN.md 4.3-4.4)'),
+    ('compute_dtype', str, 'f32_wino', 'f32_wino (exact fp32, Winograd 3x3 kernels) | f32 | f32_bf16x6 (docs/history_r01_r05.md 4.3-4.4)'),
 )
 
 

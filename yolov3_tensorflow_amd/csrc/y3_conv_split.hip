@@ -14,7 +14,7 @@
 // x 32 cycles per wave, shorter than the memory latency, so global loads run TWO K-steps ahead in two alternating
 // register sets; a work item of the stream-K partition is a PAIR of K-steps so that the set index is static.
 // The same kernel computes the stride-1 data gradients of training (wrev: flipped kernel, transposed weight
-// packing).  Design notes, measurements and rejected variants: DESIGN.md 4.3.
+// packing).  Design notes, measurements and rejected variants: docs/history_r01_r05.md 4.3.
 #include <type_traits>
 #include "y3_conv_common.h"
 
