@@ -132,9 +132,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         }
     };
 
-    auto set_loader = [&](long long it) {
-        const int tile = (int)(it / S);
-        const int ks = (int)(it - (long long)tile * S);
+    // (tile, ks) as 32-bit values: a 64-bit `item / S` here and at the top of the segment loop was ~150 scalar instructions of
+    // software division per tile, and hipcc put an s_waitcnt vmcnt(0) in front of it (its VALU temporaries) - which waited for
+    // the loads prefetched across the tile boundary: per 64x64 tile of a 1x1 conv (8-32 K-steps) that was the difference
+    // between 0.59 and the matrix-pipe bound (round 6, profiles/r06_conv1x1_ko.txt)
+    auto set_loader = [&](int tile, int ks) {
         const int bn = tile / nbm, bm = tile - bn * nbm;
         ld_tap = ks / kchunks;
         ld_cc = ks - ld_tap * kchunks;
@@ -144,7 +146,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         for (int j = 0; j < AROWS; ++j) {
             const int m = bm * BM + r0 + 32 * j;
             int mk = 0, base = 0, base_u = 0;
-            if (m < p.M) {
+            if (KS == 1 && !TMODE && !UPCAT && p.stride == 1) {
+                // 1x1, stride 1: GEMM row m IS pixel m (no padding, no decomposition into image / row / column)
+                if (m < p.M) { mk = 0x11; base = m * p.Cx; }
+            } else if (m < p.M) {
                 const int n = m / HoWo;
                 const int rem = m - n * HoWo;
                 const int oy = rem / Wrow;
@@ -273,12 +278,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
     // ---- segments: maximal runs of K-steps of one tile inside this workgroup's item range --------
     // Invariant at the top of a segment: ra/rb hold (or are receiving) its first K-step and the loader is
     // prepared for its second one.
-    set_loader(item);
+    int tile = (int)(item / S);                    // (once per workgroup; tiles advance by one below)
+    int ks = (int)(item - (long long)tile * S);
+    set_loader(tile, ks);
     issue_loads();
     advance();
     while (item < item_end) {
-        const int tile = (int)(item / S);
-        const int ks = (int)(item - (long long)tile * S);
         const long long tile_end = (long long)(tile + 1) * S;
         const long long seg_end = tile_end < item_end ? tile_end : item_end;
         const int nsteps = (int)(seg_end - item);
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             __syncthreads();
         }
         if (seg_end < item_end) {
-            set_loader(seg_end);         // prefetch across the tile boundary; stored after the epilogue
+            set_loader(tile + 1, 0);     // (a segment that is not the last ends at its tile's end) prefetch across the tile boundary; stored after the epilogue
             issue_loads();
             advance();
         }
@@ -321,6 +326,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         }
         if (STREAMK || seg_end < item_end) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
+        ++tile;
+        ks = 0;
     }
 }
 

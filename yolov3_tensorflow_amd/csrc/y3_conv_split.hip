@@ -99,9 +99,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
     unsigned b_voff;
     int ld_tap = 0, ld_cc = 0;
 
-    auto set_loader = [&](long long it) {
-        const int tile = (int)(it / S);
-        const int ks = 2 * (int)(it - (long long)tile * S);
+    // (32-bit tile / pair: a 64-bit `item / S` per tile is ~150 scalar instructions of software division, see y3_conv.hip)
+    auto set_loader = [&](int tile, int pair) {
+        const int ks = 2 * pair;
         const int bn = tile / nbm, bm = tile - bn * nbm;
         ld_tap = ks / kchunks;
         ld_cc = ks - ld_tap * kchunks;
@@ -240,12 +240,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
     // the loader is prepared for its third.  K-step 2t uses set/buffer 0, K-step 2t+1 set/buffer 1.
     I0 i0;
     I1 i1;
-    set_loader(item);
+    int tile = (int)(item / S);                    // (once per workgroup; tiles advance by one below)
+    int pair0 = (int)(item - (long long)tile * S);
+    set_loader(tile, pair0);
     issue(i0);
     issue(i1);
     while (item < item_end) {
-        const int tile = (int)(item / S);
-        const int pair0 = (int)(item - (long long)tile * S);
         const long long tile_end = (long long)(tile + 1) * S;
         const long long seg_end = tile_end < item_end ? tile_end : item_end;
         const int npairs = (int)(seg_end - item);
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
             __syncthreads();
         }
         // last pair of the segment: its prefetches belong to the next tile (if this workgroup has one)
-        if (STREAMK && seg_end < item_end) set_loader(seg_end);
+        if (STREAMK && seg_end < item_end) set_loader(tile + 1, 0);
         issue(i0);
         compute(0);
         store(i1);
@@ -293,6 +293,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_split_kernel(const ConvArgs 
         }
         if (STREAMK) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
+        ++tile;
+        pair0 = 0;
     }
 }
 
