@@ -83,6 +83,36 @@ def test_fused_plan_equals_op_by_op_composition(gpu_model):
     assert len(y3.global_variables(scope='yolov3')) == 366
 
 
+def test_fused_launches_are_reported_and_cost_no_layer_time(gpu_model, with_dtype):
+    """y3_net_layer_fused (include/yolo355.h): which launches the plan fuses at a size - the stem with the stride-2 conv behind it
+    (utils/layer_utils.py:34-40) in the fp32 and bf16 paths, the first residual block in the bf16 path - and the profiled time of
+    a layer that runs inside the next layer's launch is the time between two adjacent events: nothing.  bench.py's algorithmic
+    bytes follow this report (a fused pair is ONE kernel's bytes: the tensor between them never reaches memory)."""
+    import yolov3_tensorflow_amd as y3
+    import bench
+    model, _ = gpu_model
+    x = torch.from_numpy(blob_images(2, 2, 416)).cuda()
+    for dtype, want in (('f32_wino', {0: 1, 1: 2}), ('bf16', {0: 1, 1: 2, 2: 1, 3: 2}), ('f32', {0: 1, 1: 2})):
+        with_dtype(dtype)
+        with y3.variable_scope('yolov3'):
+            model.forward(x, False)
+            fused = model.layer_fused(2, 416, 416)
+            assert {i: int(v) for i, v in enumerate(fused) if v} == want, (dtype, fused)
+            ms, table = model.layer_times_ms(x, iters=3)
+        for i, v in enumerate(fused):
+            if v == 1:
+                assert ms[i] < 0.02, (dtype, i, ms[i], ms[i + 1])      # (two adjacent events on the stream: a few us, no kernel)
+        plain = bench.conv_bytes(table, 2, 416, 416, 2 if dtype == 'bf16' else 4)
+        aware = bench.conv_bytes(table, 2, 416, 416, 2 if dtype == 'bf16' else 4, fused)
+        es = 2 if dtype == 'bf16' else 4
+        stem_out = 2 * 416 * 416 * 32 * es
+        assert plain[0] - aware[0] == stem_out and plain[1] - aware[1] == stem_out          # written once, read once: neither happens
+        if dtype == 'bf16':
+            mid = 2 * 208 * 208 * 32 * es
+            assert plain[2] - aware[2] == mid and plain[3] - aware[3] == mid + 2 * 208 * 208 * 64 * es      # ... and the shortcut is the block's input
+        assert (plain[4:] == aware[4:]).all()
+
+
 def test_variables_follow_reference_naming_and_order(gpu_model):
     import yolov3_tensorflow_amd as y3
     from oracle import yolo_ref
