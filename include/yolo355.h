@@ -466,6 +466,18 @@ int y3_process_box(y3_ctx* ctx, const float* boxes, const int32_t* labels, const
                    int class_num, int img_w, int img_h, const float* anchors_host18, float* y_true_13,
                    float* y_true_26, float* y_true_52);
 
+/* ---- row 8(f)#1, the feeder's pixel work on the device (utils/data_utils.py:118-172 parse_data after its draws:
+ * mix_up blend, random_color_distort, the crop window of the expanded canvas, cv2.resize with the drawn interpolation,
+ * letterbox padding, random_flip, / 255) for a BATCH of samples.  The host half - the draws, the box arithmetic, Pillow's
+ * double-precision filter windows and weights - is liby3feed.so's y3f_plan_batch (include/yolo355_feed.h), which writes one
+ * relocatable blob per batch; the caller uploads it and passes its device address here, together with the host copy of
+ * the n y3f_djob records at its start (launch geometry), the y3f_dtables uploaded once per device, and `scratch_bytes` >=
+ * the plan's scratch.  out: [n][out_h][out_w][3] float32, the bytes y3f_sample writes (tests/test_feed_gpu.py).
+ * Asynchronous on the context's stream; blob, tables and scratch must stay untouched until it has run. */
+struct y3f_djob;
+int y3_feed_run(y3_ctx* ctx, const void* blob_dev, const struct y3f_djob* jobs_host, int n, const void* tables_dev,
+                void* scratch_dev, size_t scratch_bytes, float* out, int out_h, int out_w);
+
 /* box_iou (model.py:307-345): pred_boxes [num_pred][4], true_boxes [num_true][4], both (cx,cy,w,h);
  * iou [num_pred][num_true] = inter / (area_p + area_t - inter + 1e-10). */
 int y3_box_iou(y3_ctx* ctx, const float* pred_boxes, long long num_pred, const float* true_boxes, int num_true,

@@ -100,6 +100,61 @@ int y3f_crop_candidates(uint32_t* mt_state, const double* boxes, int n_boxes, in
                         double max_scale, double max_aspect_ratio, const double* bands, int n_bands, int max_trial,
                         int32_t* windows, int32_t* n_windows);
 
+/* ---- the device form of the pixel work ----------------------------------------------------------------------------
+ *
+ * y3f_sample costs 5 of the 5.9 ms one core spends per image (profiles/r03_feeder_rate.txt): a rank of the bs=64 train step
+ * needs four cores for it.  The same pass can run on the GPU beside the train step - its arithmetic is integer and table
+ * look-ups, a few hundred microseconds per batch - once the host has done what must be done in double precision exactly as
+ * Pillow / OpenCV do it: y3f_plan_batch turns n jobs into ONE relocatable blob (the job records, the source pixels the
+ * windows need, the jitter maps, the resampling coefficient tables), the caller uploads the blob, and y3_feed_run
+ * (include/yolo355.h, libyolo355.so) produces the float32 batch on the device.  Same bytes as y3f_sample
+ * (tests/test_feed_gpu.py; tests/test_feed_plan.py runs the device functions on the host against y3f_sample).
+ *
+ * All offsets are bytes from the start of the blob (sources, maps, tables) or of the device scratch (win, tmp). */
+#define Y3F_MODE_NEAREST 0
+#define Y3F_MODE_LINEAR 1
+#define Y3F_MODE_MEAN2X2 2      /* INTER_LINEAR's exact 2x2 reduction */
+#define Y3F_MODE_COPY 3         /* the window has the resize target's size already */
+#define Y3F_MODE_RESAMPLE 4     /* Pillow's two-pass 8-bit filters: CUBIC / AREA / LANCZOS4 */
+
+typedef struct y3f_djob {
+    uint64_t img1_off, img2_off;        /* packed sub-rectangles of the sources, row stride r*_w * 3 */
+    uint64_t jitter_off;                /* 4 x 256 bytes: brightness, hue, saturation, value maps (colour_on) */
+    uint64_t xtab_off, ytab_off;        /* int32 tables.  NEAREST: source index per output index.  LINEAR: [4][n] lo, hi,
+                                           weight of lo, weight of hi.  RESAMPLE: first[n], count[n], coef[n][ksize] */
+    uint64_t win_off, tmp_off;          /* scratch: the live part of the window (blended, jittered); the horizontal pass */
+    int32_t r1_x0, r1_y0, r1_w, r1_h;   /* the part of img1 that was packed, in img1's coordinates */
+    int32_t r2_x0, r2_y0, r2_w, r2_h;   /* (r2_w = 0 without a partner) */
+    float lam1, lam2;
+    int32_t has2, colour_on;
+    int32_t img_dx, img_dy;             /* image coordinate = window coordinate + img_d* */
+    int32_t live_x0, live_y0, live_x1, live_y1;     /* the part of the window that is not black canvas */
+    int32_t win_w, win_h;
+    int32_t mode, horizontal, vertical, ksize_x, ksize_y;
+    int32_t tmp_y0, tmp_rows;           /* the horizontal pass holds window rows [tmp_y0, tmp_y0 + tmp_rows) */
+    int32_t res_w, res_h, out_w, out_h, pad_x, pad_y, pad_value, flip_x;
+    int32_t reserved[3];
+} y3f_djob;                             /* 208 bytes */
+
+/* Plans n jobs for the device.  Always sets *blob_bytes and *scratch_bytes to what the batch needs; when `blob` is not
+ * NULL and `capacity` suffices, also writes the blob (the n y3f_djob records first) on up to `threads` threads (0: the
+ * hardware's).  A caller sizes its pinned buffer with a first call, or simply retries when *blob_bytes > capacity.
+ * Every job must have the same out_w x out_h. */
+int y3f_plan_batch(const y3f_job* jobs, int n, uint8_t* blob, size_t capacity, size_t* blob_bytes, size_t* scratch_bytes,
+                   int threads);
+
+/* The constant tables of the colour conversions and of the final / 255, in the layout the device kernels read
+ * (y3f_dtables below); uploaded once per device.  Returns the byte count (dst may be NULL). */
+typedef struct y3f_dtables {
+    uint8_t hue[3][256][256];   /* [channel that is the maximum][d of the next channel][d of the one after] */
+    uint8_t sat[256][256];      /* [max][min] */
+    uint8_t sector[256];        /* floor(h * 6 / 255) % 6 */
+    float frac[256];            /* h * 6 / 255 - floor(.) */
+    float unit[256];            /* s / 255, float32 of the double quotient */
+    float unit255[256];         /* v / 255.f: the network's input value of byte v */
+} y3f_dtables;
+size_t y3f_device_tables(void* dst, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,9 +34,9 @@ def test_library_exports_what_the_header_declares(fn):
     assert declared == sorted(fn.PROTOTYPES)
     for name in declared:
         assert hasattr(fn.lib(), name), 'liby3feed.so does not export %s' % name
-    assert fn.lib().y3f_abi_version() == 1
+    assert fn.lib().y3f_abi_version() == 2
     # the ctypes mirrors have the header's field order and sizes (all 4-byte fields after the two pointers)
-    assert ctypes.sizeof(fn.Colour) == 24 and ctypes.sizeof(fn.Job) == 128       # (static_assert'ed in y3_feed.cpp)
+    assert ctypes.sizeof(fn.Colour) == 24 and ctypes.sizeof(fn.Job) == 128 and ctypes.sizeof(fn.DJob) == 208      # (static_assert'ed in y3_feed.cpp)
     # errors come back as codes with a message, not as crashes
     out = np.empty((4, 4, 3), np.uint8)
     assert fn.lib().y3f_resize(out.ctypes.data, 4, 4, out.ctypes.data, 4, 4, 9) == -1

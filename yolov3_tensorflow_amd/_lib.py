@@ -149,6 +149,7 @@ PROTOTYPES = {
                               POINTER(c_float), c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t]),
     "y3_process_box": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                POINTER(c_float), c_void_p, c_void_p, c_void_p]),
+    "y3_feed_run": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int]),
     "y3_box_iou": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_void_p]),
     "y3_optimizer_scratch_bytes": (c_size_t, []),
     "y3_clip_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,

@@ -33,6 +33,7 @@ SOURCES = [
     ("y3_train.hip", ["-ffp-contract=off"]),
     ("y3_wgrad.hip", []),
     ("y3_wgrad_wino.hip", []),
+    ("y3_feed_gpu.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -87,6 +88,8 @@ def needs_build():
         os.path.join(CSRC, "y3_internal.h"),
         os.path.join(CSRC, "y3_conv_common.h"),
         os.path.join(CSRC, "y3_net.h"),
+        os.path.join(CSRC, "y3_feed_px.h"),
+        os.path.join(HERE, "..", "include", "yolo355_feed.h"),
         os.path.join(HERE, "..", "include", "yolo355.h"),
         os.path.abspath(__file__),
     ]

@@ -451,7 +451,7 @@ const float* unit_table() {          // v / 255 in float32 for v = 0..255
     return table.t;
 }
 
-int run_job(const y3f_job& j, uint8_t* out_u8, float* out_f32) {
+int check_job(const y3f_job& j) {
     if (!j.img1 || j.h1 < 1 || j.w1 < 1) return fail(Y3F_EINVAL, "sample: img1 is empty");
     if (j.img2 && (j.h2 < 1 || j.w2 < 1)) return fail(Y3F_EINVAL, "sample: img2 is empty");
     if (j.win_w < 1 || j.win_h < 1 || j.res_w < 1 || j.res_h < 1 || j.out_w < 1 || j.out_h < 1)
@@ -464,6 +464,23 @@ int run_job(const y3f_job& j, uint8_t* out_u8, float* out_f32) {
     if (j.win_w > big || j.win_h > big || j.out_w > big || j.out_h > big || j.h1 > big || j.w1 > big || j.h2 > big || j.w2 > big ||
         std::abs(j.win_x) > far || std::abs(j.win_y) > far || std::abs(j.off_x) > far || std::abs(j.off_y) > far)
         return fail(Y3F_EINVAL, "sample: coordinates out of range");
+    return Y3F_OK;
+}
+
+// the part of the window that is not black canvas, as run_job hands it to the resampling filters
+Rect live_rect(const y3f_job& j) {
+    const int mh = j.img2 ? std::max(j.h1, j.h2) : j.h1, mw = j.img2 ? std::max(j.w1, j.w2) : j.w1;
+    const int x_lo = std::max(j.win_x, j.off_x), x_hi = std::min(j.win_x + j.win_w, j.off_x + mw);
+    Rect live = {std::max(0, x_lo - j.win_x), std::max(0, std::max(j.win_y, j.off_y) - j.win_y), std::max(0, x_hi - j.win_x),
+                 std::max(0, std::min(j.win_y + j.win_h, j.off_y + mh) - j.win_y)};
+    live = {std::min(live.x0, j.win_w), std::min(live.y0, j.win_h), std::min(live.x1, j.win_w), std::min(live.y1, j.win_h)};
+    if (live.x1 <= live.x0 || live.y1 <= live.y0) live = {0, 0, 0, 0};
+    return live;
+}
+
+int run_job(const y3f_job& j, uint8_t* out_u8, float* out_f32) {
+    const int bad = check_job(j);
+    if (bad != Y3F_OK) return bad;
     if (!out_u8 && !out_f32) return Y3F_OK;
     try {
         // 1. the window of the canvas: black, except where the (mixed) image lies; those pixels are blended and jittered
@@ -582,7 +599,216 @@ struct PyRandom {
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The device form: the same job, split into what needs the host (double-precision filter windows and weights exactly as
+// Pillow computes them, the jitter maps with numpy's float32 remainder, which source pixels a window can see) and what the
+// GPU does from tables (csrc/y3_feed_px.h).  plan_geometry fixes sizes and offsets, fill_job writes the blob.
+// ---------------------------------------------------------------------------------------------------------------------
+static_assert(sizeof(y3f_djob) == 208 && sizeof(y3f_djob) % 16 == 0, "feed_native.py and the device kernels assume this layout");
+
+inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+struct FilterSpec {
+    double (*fn)(double);
+    double support;
+};
+
+bool filter_of(int interp, FilterSpec* f) {
+    switch (interp) {
+        case Y3F_INTER_CUBIC: *f = {filter_bicubic, 2.0}; return true;
+        case Y3F_INTER_AREA: *f = {filter_box, 0.5}; return true;
+        case Y3F_INTER_LANCZOS4: *f = {filter_lanczos, 3.0}; return true;
+        default: return false;
+    }
+}
+
+// ksize and the source window [lo, hi) of output index o, as Kernel1D computes them
+int kernel_window(int in_size, int out_size, double filter_support, int o, int* lo_out, int* hi_out) {
+    const double scale = (double)((float)in_size - 0.f) / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = filter_support * filterscale;
+    const double center = 0.f + (o + 0.5) * scale;
+    int lo = (int)(center - support + 0.5);
+    if (lo < 0) lo = 0;
+    int hi = (int)(center + support + 0.5);
+    if (hi > in_size) hi = in_size;
+    *lo_out = lo;
+    *hi_out = hi;
+    return (int)std::ceil(support) * 2 + 1;
+}
+
+int plan_geometry(const y3f_job& j, y3f_djob& d, size_t& blob, size_t& scratch) {
+    const int bad = check_job(j);
+    if (bad != Y3F_OK) return bad;
+    memset(&d, 0, sizeof(d));
+    const int sw = j.win_w, sh = j.win_h, dw = j.res_w, dh = j.res_h;
+    const Rect live = live_rect(j);
+    d.live_x0 = live.x0, d.live_y0 = live.y0, d.live_x1 = live.x1, d.live_y1 = live.y1;
+    d.win_w = sw, d.win_h = sh;
+    d.img_dx = j.win_x - j.off_x, d.img_dy = j.win_y - j.off_y;
+    d.lam1 = j.lam1, d.lam2 = j.lam2;
+    d.has2 = j.img2 != nullptr;
+    d.colour_on = j.colour.enabled != 0;
+    d.res_w = dw, d.res_h = dh, d.out_w = j.out_w, d.out_h = j.out_h, d.pad_x = j.pad_x, d.pad_y = j.pad_y;
+    d.pad_value = clamp_u8(j.pad_value), d.flip_x = j.flip_x != 0;
+    // the source pixels the live part of the window can see
+    const int ix0 = live.x0 + d.img_dx, ix1 = live.x1 + d.img_dx, iy0 = live.y0 + d.img_dy, iy1 = live.y1 + d.img_dy;
+    auto cut = [&](int w, int h, int32_t* r) {
+        const int x0 = std::max(ix0, 0), x1 = std::min(ix1, w), y0 = std::max(iy0, 0), y1 = std::min(iy1, h);
+        if (x1 <= x0 || y1 <= y0) { r[0] = r[1] = r[2] = r[3] = 0; return; }
+        r[0] = x0, r[1] = y0, r[2] = x1 - x0, r[3] = y1 - y0;
+    };
+    cut(j.w1, j.h1, &d.r1_x0);
+    if (d.has2) cut(j.w2, j.h2, &d.r2_x0);
+    FilterSpec f;
+    switch (j.interp) {
+        case Y3F_INTER_NEAREST: d.mode = Y3F_MODE_NEAREST; break;
+        case Y3F_INTER_LINEAR:
+            d.mode = (sh == dh && sw == dw) ? Y3F_MODE_COPY : (sw == 2 * dw && sh == 2 * dh) ? Y3F_MODE_MEAN2X2 : Y3F_MODE_LINEAR;
+            break;
+        case Y3F_INTER_CUBIC: case Y3F_INTER_AREA: case Y3F_INTER_LANCZOS4:
+            d.horizontal = dw != sw, d.vertical = dh != sh;
+            d.mode = (d.horizontal || d.vertical) ? Y3F_MODE_RESAMPLE : Y3F_MODE_COPY;
+            break;
+        default: return fail(Y3F_EINVAL, "resize: interpolation code %d is not one of 0..4", j.interp);
+    }
+    size_t xtab = 0, ytab = 0;
+    if (d.mode == Y3F_MODE_NEAREST) {
+        xtab = (size_t)dw * 4, ytab = (size_t)dh * 4;
+    } else if (d.mode == Y3F_MODE_LINEAR) {
+        xtab = (size_t)dw * 16, ytab = (size_t)dh * 16;
+    } else if (d.mode == Y3F_MODE_RESAMPLE) {
+        filter_of(j.interp, &f);
+        int lo, hi, row_first = 0, row_last = sh;
+        if (d.horizontal) {
+            d.ksize_x = kernel_window(sw, dw, f.support, 0, &lo, &hi);
+            xtab = (size_t)dw * (2 + d.ksize_x) * 4;
+        }
+        if (d.vertical) {
+            d.ksize_y = kernel_window(sh, dh, f.support, 0, &row_first, &hi);
+            kernel_window(sh, dh, f.support, dh - 1, &lo, &row_last);
+            ytab = (size_t)dh * (2 + d.ksize_y) * 4;
+        }
+        if (d.horizontal) {
+            d.tmp_y0 = std::max(row_first, live.y0);
+            d.tmp_rows = std::max(0, std::min(row_last, live.y1) - d.tmp_y0);
+        }
+    }
+    d.img1_off = blob, blob += align16((size_t)d.r1_w * d.r1_h * 3);
+    d.img2_off = blob, blob += align16((size_t)d.r2_w * d.r2_h * 3);
+    d.jitter_off = blob, blob += d.colour_on ? 1024 : 0;
+    d.xtab_off = blob, blob += align16(xtab);
+    d.ytab_off = blob, blob += align16(ytab);
+    d.win_off = scratch, scratch += align16((size_t)(live.x1 - live.x0) * (live.y1 - live.y0) * 3);
+    d.tmp_off = scratch, scratch += align16((size_t)d.tmp_rows * dw * 3);
+    return Y3F_OK;
+}
+
+void fill_job(const y3f_job& j, const y3f_djob& d, uint8_t* blob) {
+    auto pack = [&](const uint8_t* img, int w, const int32_t* r, uint64_t off) {
+        for (int y = 0; y < r[3]; ++y)
+            memcpy(blob + off + (size_t)y * r[2] * 3, img + ((size_t)(r[1] + y) * w + r[0]) * 3, (size_t)r[2] * 3);
+    };
+    pack(j.img1, j.w1, &d.r1_x0, d.img1_off);
+    if (d.has2) pack(j.img2, j.w2, &d.r2_x0, d.img2_off);
+    if (d.colour_on) {
+        const Jitter J(j.colour);
+        uint8_t* t = blob + d.jitter_off;
+        memcpy(t, J.bright, 256), memcpy(t + 256, J.h, 256), memcpy(t + 512, J.s, 256), memcpy(t + 768, J.v, 256);
+    }
+    const int sw = j.win_w, sh = j.win_h, dw = j.res_w, dh = j.res_h;
+    int32_t* xt = reinterpret_cast<int32_t*>(blob + d.xtab_off);
+    int32_t* yt = reinterpret_cast<int32_t*>(blob + d.ytab_off);
+    if (d.mode == Y3F_MODE_NEAREST) {
+        const double fx = (double)sw / dw, fy = (double)sh / dh;
+        for (int x = 0; x < dw; ++x) xt[x] = std::min((int)std::floor(x * fx), sw - 1);
+        for (int y = 0; y < dh; ++y) yt[y] = std::min((int)std::floor(y * fy), sh - 1);
+    } else if (d.mode == Y3F_MODE_LINEAR) {
+        auto taps = [](const LinearTaps& t, int n, int32_t* o) {
+            for (int i = 0; i < n; ++i) o[i] = t.lo[i], o[n + i] = t.hi[i], o[2 * n + i] = t.wlo[i], o[3 * n + i] = t.whi[i];
+        };
+        taps(LinearTaps(sw, dw), dw, xt);
+        taps(LinearTaps(sh, dh), dh, yt);
+    } else if (d.mode == Y3F_MODE_RESAMPLE) {
+        FilterSpec f;
+        filter_of(j.interp, &f);
+        auto table = [&](int in, int out, int32_t* o) {
+            const Kernel1D k(in, out, f.fn, f.support);
+            for (int i = 0; i < out; ++i) o[i] = k.first[i], o[out + i] = k.count[i];
+            memcpy(o + 2 * (size_t)out, k.coef.data(), k.coef.size() * 4);
+        };
+        if (d.horizontal) table(sw, dw, xt);
+        if (d.vertical) table(sh, dh, yt);
+    }
+}
+
+// run `work(i)` for i in [0, n) on up to `threads` threads (the caller's included)
+template <typename F>
+void parallel_jobs(int n, int threads, F work) {
+    int workers = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    workers = std::max(1, std::min(workers, n));
+    std::atomic<int> next(0);
+    auto loop = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) work(i);
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < workers; ++t) pool.emplace_back(loop);
+    } catch (...) {      // fewer threads than asked for: the caller's thread takes what is left
+    }
+    loop();
+    for (auto& t : pool) t.join();
+}
+
+}  // namespace
+
 extern "C" {
+
+int y3f_plan_batch(const y3f_job* jobs, int n, uint8_t* blob, size_t capacity, size_t* blob_bytes, size_t* scratch_bytes,
+                   int threads) {
+    if (n < 0 || (n && !jobs) || !blob_bytes || !scratch_bytes) return fail(Y3F_EINVAL, "plan_batch: bad arguments");
+    try {
+        std::vector<y3f_djob> recs((size_t)n);
+        size_t need = align16((size_t)n * sizeof(y3f_djob)), scratch = 0;
+        for (int i = 0; i < n; ++i) {
+            if (jobs[i].out_w != jobs[0].out_w || jobs[i].out_h != jobs[0].out_h)
+                return fail(Y3F_EINVAL, "plan_batch: job %d writes %dx%d, job 0 %dx%d", i, jobs[i].out_w, jobs[i].out_h,
+                            jobs[0].out_w, jobs[0].out_h);
+            const int rc = plan_geometry(jobs[i], recs[i], need, scratch);
+            if (rc != Y3F_OK) {
+                char message[sizeof(g_error)];
+                snprintf(message, sizeof(message), "job %d: %s", i, g_error);
+                snprintf(g_error, sizeof(g_error), "%s", message);
+                return rc;
+            }
+        }
+        *blob_bytes = need;
+        *scratch_bytes = scratch;
+        if (!blob || capacity < need) return Y3F_OK;
+        if (n) memcpy(blob, recs.data(), (size_t)n * sizeof(y3f_djob));
+        parallel_jobs(n, threads, [&](int i) { fill_job(jobs[i], recs[i], blob); });
+        return Y3F_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(Y3F_ENOMEM, "plan_batch: out of memory");
+    }
+}
+
+size_t y3f_device_tables(void* dst, size_t capacity) {
+    static_assert(sizeof(y3f_dtables) == 3 * 65536 + 65536 + 256 + 3 * 1024, "no padding expected");
+    if (dst && capacity >= sizeof(y3f_dtables)) {
+        y3f_dtables* t = static_cast<y3f_dtables*>(dst);
+        const ColourTables& T = colour_tables();
+        memcpy(t->hue, T.hue, sizeof(t->hue));
+        memcpy(t->sat, T.sat, sizeof(t->sat));
+        memcpy(t->sector, T.sector, sizeof(t->sector));
+        memcpy(t->frac, T.frac, sizeof(t->frac));
+        memcpy(t->unit, T.unit, sizeof(t->unit));
+        memcpy(t->unit255, unit_table(), sizeof(t->unit255));
+    }
+    return sizeof(y3f_dtables);
+}
 
 int y3f_crop_candidates(uint32_t* mt_state, const double* boxes, int n_boxes, int width, int height, double min_scale,
                         double max_scale, double max_aspect_ratio, const double* bands, int n_bands, int max_trial,
@@ -631,7 +857,7 @@ int y3f_crop_candidates(uint32_t* mt_state, const double* boxes, int n_boxes, in
 
 const char* y3f_last_error(void) { return g_error; }
 
-int y3f_abi_version(void) { return 1; }
+int y3f_abi_version(void) { return 2; }
 
 int y3f_resize(const uint8_t* src, int src_h, int src_w, uint8_t* dst, int dst_h, int dst_w, int interp) {
     return resize_any(src, src_h, src_w, dst, dst_h, dst_w, interp);
