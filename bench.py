@@ -537,11 +537,11 @@ def run_feeder(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
         for _ in range(args.warmup):
             next(it)
         barrier()
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         for _ in range(args.steps):
             next(it)
         barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
+        elapsed, cpu = max_over_ranks(time.perf_counter() - t0), time.process_time() - c0
         it.close()
         feeder.close()
     if rank != 0:
@@ -554,8 +554,12 @@ def run_feeder(args, y3, torch, dist, rank, world, distributed, barrier, max_ove
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic 640x480 JPEGs, 1-7 boxes each",
         "config": {"workload": "the host side of configs[3]: per GPU one feeder, %d worker threads, prefetch %d, bs=%d, "
-                               "pixel work in liby3feed.so" % (workers, prefetch, BATCH),
-                   "batch_per_gpu": BATCH, "image_size": SIZE, "backend": feeder.backend, "workers": workers},
+                               "pixel work %s" % (workers, prefetch, BATCH,
+                                                  "on the device (y3_feed_run; planned by liby3feed.so)"
+                                                  if feeder.pixels == 'gpu' else "in liby3feed.so"),
+                   "batch_per_gpu": BATCH, "image_size": SIZE, "backend": feeder.backend, "workers": workers,
+                   "pixels": feeder.pixels},
+        "host_cpu_ms_per_image": round(1e3 * cpu / (BATCH * args.steps), 3),      # rank 0's process, all threads
     }
 
 
@@ -564,7 +568,7 @@ def slim(res):
     if res is None or 'error' in res:
         return res
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'dtype', 'precision', 'scaling',
-            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data', 'fed')
+            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data', 'fed', 'host_cpu_ms_per_image')
     return {k: res[k] for k in keep if k in res}
 
 
@@ -829,7 +833,7 @@ def fed_train_steps(args, trainer, torch, rank, barrier, max_over_ranks):
         feeder.close()
     assert np.isfinite(float(loss[0])), "non-finite loss on fed batches"
     return {"ms_per_step": round(elapsed / args.steps * 1e3, 3), "steps": args.steps, "workers": workers,
-            "prefetch": prefetch, "backend": feeder.backend,
+            "prefetch": prefetch, "backend": feeder.backend, "pixels": feeder.pixels,
             "data": "synthetic 640x480 JPEGs through the reference's 'train' augmentation chain with mix-up"}
 
 

@@ -247,4 +247,4 @@ def test_a_c_host_links_the_library_and_gets_the_same_bytes(fn, tmp_path):
     want = fn.sample(img, colour=(9, -7, 1.25, 0.9), offset=(105, 75), window=(52, 37, 210, 150), interp=4,
                      out_size=(416, 416), flip_x=True)
     np.testing.assert_array_equal(got, want)
-    assert text.startswith('abi 1;') and ('%.6f' % (want[415, 0, 0] / np.float32(255.))) in text
+    assert text.startswith('abi 2;') and ('%.6f' % (want[415, 0, 0] / np.float32(255.))) in text

@@ -48,7 +48,7 @@ def _one_feeder(rank, nfeed, lines, args, backend, workers, barrier, out):
     from yolov3_tensorflow_amd.feeder import Feeder
     try:
         f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True, num_threads=workers,
-                   prefetch=5, seed=1 + rank, backend=backend)
+                   prefetch=5, seed=1 + rank, backend=backend, pixels=args.pixels.split(',')[0])
         if args.host_only:
             # the host half alone (decode, augmentation chain, resize into a float32 batch buffer, collate): no device call at
             # all, so eight of these on a one-GPU box measure the HOST of an eight-GPU node (with uploads, eight processes
@@ -90,12 +90,12 @@ def _one_feeder(rank, nfeed, lines, args, backend, workers, barrier, out):
             next(it)
         torch.cuda.synchronize()
         barrier.wait(timeout=180)
-        t0 = time.time()
+        t0, c0 = time.time(), time.process_time()
         for _ in range(args.batches):
             next(it)
         torch.cuda.synchronize()
-        t1 = time.time()
-        out.put((rank, t0, t1, None))
+        t1, c1 = time.time(), time.process_time()
+        out.put((rank, t0, t1, None, c1 - c0))
         it.close()
         f.close()
     except BaseException as e:      # noqa: BLE001 - reported by the parent; never leave the others at the barrier
@@ -131,9 +131,12 @@ def concurrent_feeders(args, lines):
             span = max(r[2] for r in res) - min(r[1] for r in res)
             per = [args.batches * args.batch_size / (r[2] - r[1]) for r in res]
             total = n * args.batches * args.batch_size / span
-            print('%d feeders at once%s, backend=%s, %d workers each: aggregate %.0f images/s (per feeder min %.0f / mean %.0f / '
-                  'max %.0f) against %d x 697 = %d images/s consumed by %d train steps: %.2fx'
-                  % (n, ' (host half only)' if args.host_only else '', backend, workers, total, min(per), sum(per) / n, max(per), n, n * 697, n, total / (n * 697.0)), flush=True)
+            cpu = [r[4] for r in res if len(r) > 4]
+            print('%d feeders at once%s, pixels=%s, backend=%s, %d workers each: aggregate %.0f images/s (per feeder min %.0f / mean %.0f / '
+                  'max %.0f) against %d x 697 = %d images/s consumed by %d train steps: %.2fx%s'
+                  % (n, ' (host half only)' if args.host_only else '', args.pixels.split(',')[0], backend, workers, total, min(per),
+                     sum(per) / n, max(per), n, n * 697, n, total / (n * 697.0),
+                     '; %.2f ms of CPU per image' % (1e3 * sum(cpu) / (n * args.batches * args.batch_size)) if cpu else ''), flush=True)
 
 
 def main():
@@ -143,6 +146,8 @@ def main():
     ap.add_argument('--workers', default='8,16,32')
     ap.add_argument('--backends', default='thread,process')
     ap.add_argument('--native', default='1,0')
+    ap.add_argument('--pixels', default='host', help="host,gpu: where the pixel work runs (Feeder(pixels=...); thread backend, "
+                                                     "native=1 for gpu); with --feeders the first entry is used")
     ap.add_argument('--batches', type=int, default=12)
     ap.add_argument('--batch_size', type=int, default=64)
     ap.add_argument('--check', action='store_true', help="first compare the first batch of a process-backed feeder with a "
@@ -173,21 +178,26 @@ def main():
         os.environ['Y3_FEED_NATIVE'] = native
         for backend in args.backends.split(','):
             for workers in [int(v) for v in args.workers.split(',')]:
-                f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True,
-                           num_threads=workers, prefetch=5, seed=1, backend=backend)
-                it = f.epoch(0)
-                for _ in range(3):              # pool start-up, pinned buffers
-                    next(it)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.batches):
-                    next(it)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                it.close()
-                f.close()
-                print('native=%s backend=%-7s workers=%3d: %7.0f images/s' % (native, backend, workers,
-                                                                                args.batches * args.batch_size / dt), flush=True)
+                for pixels in args.pixels.split(','):
+                    if pixels == 'gpu' and (backend != 'thread' or native != '1'):
+                        continue
+                    f = Feeder(lines, args.batch_size, 80, [416, 416], ANCHORS, mode='train', use_mix_up=True,
+                               num_threads=workers, prefetch=5, seed=1, backend=backend, pixels=pixels)
+                    it = f.epoch(0)
+                    for _ in range(3):              # pool start-up, pinned buffers
+                        next(it)
+                    torch.cuda.synchronize()
+                    t0, c0 = time.perf_counter(), time.process_time()
+                    for _ in range(args.batches):
+                        next(it)
+                    torch.cuda.synchronize()
+                    dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+                    it.close()
+                    f.close()
+                    images = args.batches * args.batch_size
+                    print('native=%s backend=%-7s workers=%3d pixels=%-4s: %7.0f images/s%s' % (
+                        native, backend, workers, pixels, images / dt,
+                        ', %.2f ms of this process\'s CPU per image' % (1e3 * cpu / images) if backend == 'thread' else ''), flush=True)
 
 
 if __name__ == '__main__':

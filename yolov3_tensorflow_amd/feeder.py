@@ -26,6 +26,10 @@ rebuilt for one process per GPU with the device-resident target assignment of th
     SIDE stream; a bounded queue of `prefetch` batches (reference: prefetech_buffer = 5) decouples it from the train step,
     so decode / resize / H2D of batch i+1.. overlap the step on batch i.  The pinned buffers are recycled once their copy
     has completed (pinning 130 MB per batch afresh costs more than filling it);
+  * pixels='gpu': the workers only decode and draw (parse_sample(defer=True)); the coordinator plans the batch's pixel
+    work (liby3feed.so: y3f_plan_batch, native threads), uploads ONE blob of 8-bit sources and tables and runs y3_feed_run
+    on the side stream (feed_device.DevicePixels) - the same bytes as the host path, 5 of the 5.9 ms a core spends per
+    image moved to three launches of a few hundred microseconds per batch;
   * the consumer makes its compute stream wait for the copy's event (no host synchronisation) and runs `y3_process_box`
     for the whole batch on the device (utils.data_utils.process_box_batch: bit-exact against the reference's
     process_box), so the three y_true tensors (3.6 MB per 416x416 image - more than the image itself) never cross PCIe;
@@ -45,13 +49,14 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 
-def _worker_sample(job, out=None):
+def _worker_sample(job, out=None, defer=False):
     """One sample in a worker: job = (line or mix-up pair, [w, h], mode, letterbox, rng key).  A thread is handed `out`, its
-    float32 slot of the batch buffer; a process returns the 8-bit image (a quarter of the bytes to pickle)."""
+    float32 slot of the batch buffer; a process returns the 8-bit image (a quarter of the bytes to pickle); `defer`: the
+    decoded sources and the pixel JOB come back, the pixels are left to the device."""
     from .utils.data_utils import parse_sample
     line, size, mode, letterbox, key = job
     return parse_sample(line, size, mode, letterbox, rng=np.random.RandomState(key % (2 ** 31)), prng=random.Random(key),
-                        as_uint8=out is None, out=out)
+                        as_uint8=out is None and not defer, out=out, defer=defer)
 
 
 _ATTACHED = {}        # (in a worker process) path of a shared batch buffer -> its mapping
@@ -234,7 +239,7 @@ class Batch(object):
 class Feeder(object):
     def __init__(self, lines, batch_size, class_num, img_size, anchors, mode='train', multi_scale=False, use_mix_up=False,
                  letterbox_resize=True, num_threads=10, prefetch=5, shuffle=None, seed=0, rank=0, world=1, interval=10,
-                 device=None, drop_remainder=False, backend=None):
+                 device=None, drop_remainder=False, backend=None, pixels=None):
         self.lines = [l for l in lines if (l.strip() if isinstance(l, str) else l)]
         self.batch_size, self.class_num = int(batch_size), int(class_num)
         self.img_size, self.anchors = list(img_size), np.asarray(anchors, np.float32).reshape(9, 2)
@@ -254,6 +259,17 @@ class Feeder(object):
         if backend not in ('process', 'thread'):
             raise ValueError("backend must be 'process' or 'thread'")
         self.backend = backend
+        if pixels is None:      # on the device wherever the workers can hand decoded sources over (same bytes either way)
+            from . import feed_native
+            pixels = 'gpu' if backend == 'thread' and feed_native.enabled() else 'host'
+        if pixels not in ('host', 'gpu'):
+            raise ValueError("pixels must be 'host' or 'gpu'")
+        if pixels == 'gpu':
+            from . import feed_native
+            if backend != 'thread' or not feed_native.enabled():
+                raise ValueError("pixels='gpu' runs with the thread backend and the native job builder (Y3_FEED_NATIVE=1): "
+                                 "the workers hand decoded sources to the coordinator")
+        self.pixels = pixels
         self._pool = None
 
     def _executor(self):
@@ -319,6 +335,11 @@ class Feeder(object):
 
         pool = self._executor()
 
+        on_device = self.pixels == 'gpu'
+        device_pixels = None
+        if on_device:
+            from .feed_device import DevicePixels
+            device_pixels = DevicePixels(dev)
         in_place = self.backend == 'thread'
         buffers = _PinnedBuffers()
         shared = None if in_place else _SharedBuffers()
@@ -349,7 +370,10 @@ class Feeder(object):
                         shape = (len(lines), size[1], size[0], 3)
                         jobs = [self._job(epoch, b, j, line, size) for j, line in enumerate(lines)]
                         entry = shared.take(shape) if shared is not None else None
-                        if entry is not None:       # worker processes fill the shared, page-locked batch buffer
+                        if on_device:               # worker threads decode and draw; the pixels are left to the device
+                            pinned, owner = None, None
+                            futs = [pool.submit(_worker_sample, job, None, True) for job in jobs]
+                        elif entry is not None:     # worker processes fill the shared, page-locked batch buffer
                             pinned, owner = entry['tensor'], (shared, entry)
                             futs = [pool.submit(_worker_sample_shared, job, entry['path'], shape, j)
                                     for j, job in enumerate(jobs)]
@@ -365,18 +389,25 @@ class Feeder(object):
                     if not pending:
                         break
                     b, size, futs, pinned, owner = pending.pop(0)
-                    slots = pinned.numpy()
                     samples = [f.result() for f in futs]
-                    samples = [(s[0], slots[j] if s[1] is None else s[1], s[2], s[3]) for j, s in enumerate(samples)]
-                    ids, _, boxes, labels, counts = collate(samples, out_images=slots)
+                    if on_device:
+                        ids, _, boxes, labels, counts = collate(samples, with_images=False)
+                    else:
+                        slots = pinned.numpy()
+                        samples = [(s[0], slots[j] if s[1] is None else s[1], s[2], s[3]) for j, s in enumerate(samples)]
+                        ids, _, boxes, labels, counts = collate(samples, out_images=slots)
                     with torch.cuda.stream(copy_stream):
-                        images = pinned.to(dev, non_blocking=True)
+                        if on_device:
+                            images = device_pixels.run([s[1] for s in samples], threads=min(self.num_threads, 8))
+                        else:
+                            images = pinned.to(dev, non_blocking=True)
                         bx = torch.from_numpy(boxes).pin_memory().to(dev, non_blocking=True)
                         lb = torch.from_numpy(labels.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
                         ct = torch.from_numpy(counts.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(copy_stream)
-                    owner[0].give(ev, owner[1])
+                    if owner is not None:
+                        owner[0].give(ev, owner[1])
                     item = (ids, size, images, bx, lb, ct, ev)
                     put(item)
                 put(None)

@@ -219,7 +219,7 @@ def fix_crop_labels():
     return os.environ.get('Y3_FIX_CROP_LABELS', '0') == '1'
 
 
-def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False, out=None):
+def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as_uint8=False, out=None, defer=False):
     """The image half of the reference's parse_data (utils/data_utils.py:118-172): read (PIL, RGB), mix-up when `line` is
     a pair, the 'train' augmentation chain (colour distortion, expansion, constrained crop, resize with a random
     interpolation, horizontal flip) or the plain 'val' resize.  Returns (img_idx, float32 RGB image in [0,1] of shape
@@ -229,7 +229,9 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
     Two executions of the same recipe, bit-identical (tests/test_feed_native.py): every draw and all box arithmetic come
     from utils.data_aug either way; the pixels go through liby3feed.so in one pass (feed_native.enabled(), the default), or
     through data_aug's numpy / Pillow functions one augmentation at a time (Y3_FEED_NATIVE=0).  `out`: a [h, w, 3] array
-    (uint8 with as_uint8, else float32) to write the image into - the native path fills it directly."""
+    (uint8 with as_uint8, else float32) to write the image into - the native path fills it directly.  `defer`: return the
+    pixel JOB (feed_native.PixelJob) in place of the image - the feeder then runs a whole batch of them on the device
+    (feed_device.DevicePixels: the same bytes)."""
     from . import data_aug
     from .. import feed_native
     rng = rng if rng is not None else np.random
@@ -258,6 +260,8 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
             return bx, np.asarray(labels, np.int64)
         return np.ascontiguousarray(bx[:, :5]), bx[:, 5].astype(np.int64)
 
+    if defer and not feed_native.enabled():
+        raise ValueError("parse_sample(defer=True) needs the native pixel path (Y3_FEED_NATIVE=0 is set)")
     if not feed_native.enabled():
         if partner is not None:
             img = data_aug.blend(img, partner, lam)
@@ -289,8 +293,11 @@ def parse_sample(line, img_size, mode, letterbox_resize, rng=None, prng=None, as
     if letterbox_resize:
         _, fit_w, fit_h, pad_x, pad_y = data_aug.letterbox_geometry(window[2], window[3], width, height)
         resized, pad = (fit_w, fit_h), (pad_x, pad_y)
-    image = feed_native.sample(img, partner, lam, colour, offset, window, interp, resized, (width, height), pad, 128, flip,
-                               out=out, as_float=not as_uint8)
+    if defer:
+        image = feed_native.make_job(img, partner, lam, colour, offset, window, interp, resized, (width, height), pad, 128, flip)
+    else:
+        image = feed_native.sample(img, partner, lam, colour, offset, window, interp, resized, (width, height), pad, 128, flip,
+                                   out=out, as_float=not as_uint8)
     return (img_idx, image) + split(boxes)
 
 
@@ -406,19 +413,24 @@ def _map_samples(lines, img_size, mode, letterbox_resize):
     return [j.result() for j in jobs]
 
 
-def collate(samples, out_images=None):
+def collate(samples, out_images=None, with_images=True):
     """[(img_idx, image, boxes [K,5], labels [K]), ...] -> (ids, images [n,h,w,3], boxes [n,Kmax,5], labels [n,Kmax],
-    counts [n]) padded to the largest box count (the layout y3_process_box takes)."""
+    counts [n]) padded to the largest box count (the layout y3_process_box takes).  with_images=False: the images are
+    pixel jobs still to be run (parse_sample(defer=True)); `images` comes back as None."""
     n = len(samples)
     kmax = max(1, max(len(s[2]) for s in samples))
     h, w = samples[0][1].shape[:2]
-    images = out_images if out_images is not None else np.empty((n, h, w, 3), np.float32)
+    images = None
+    if with_images:
+        images = out_images if out_images is not None else np.empty((n, h, w, 3), np.float32)
     boxes = np.zeros((n, kmax, 5), np.float32)
     labels = np.zeros((n, kmax), np.int64)
     counts = np.zeros((n,), np.int64)
     ids = []
     for i, (idx, img, b, l) in enumerate(samples):
-        if img.dtype == np.uint8:        # img.astype(float32) / 255. of parse_data, written in place (no temporaries)
+        if not with_images:
+            pass
+        elif img.dtype == np.uint8:      # img.astype(float32) / 255. of parse_data, written in place (no temporaries)
             np.true_divide(img, np.float32(255.), out=images[i], dtype=np.float32)
         elif img.ctypes.data != images[i].ctypes.data:      # (a feeder thread has written its slot of out_images already)
             images[i] = img
