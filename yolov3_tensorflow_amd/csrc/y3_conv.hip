@@ -283,6 +283,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
     set_loader(tile, ks);
     issue_loads();
     advance();
+    // (the first K-step's operands are needed at once; waiting HERE, visibly to hipcc, keeps the wait out of the loop header,
+    // where the back edge would turn it into a wait for the previous tile's output stores: loads and stores share vmcnt)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     while (item < item_end) {
         const long long tile_end = (long long)(tile + 1) * S;
         const long long seg_end = tile_end < item_end ? tile_end : item_end;
@@ -314,6 +317,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
         }
         compute_tile((nsteps - 1) & 1);
         __syncthreads();
+        // the next tile's first operands (requested above, a K-step ago) are in: said HERE so that no path through the epilogue
+        // leaves them "pending" for hipcc - at the loop header that would become a wait for this tile's output stores
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 
         if (STREAMK && ks > 0) {
             // later K-steps of a cut tile (this worker's first segment): publish the raw accumulators

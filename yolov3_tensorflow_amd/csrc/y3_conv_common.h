@@ -107,6 +107,93 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
         const int tc = (tid % C4) * 4, tr = tid / C4;
         const int col = n0 + tc;
         const bool cok = col < p.Cout;
+        if (PASSES <= 8 && (p.Cout & 3) == 0) {
+            // Every layer but the detection heads, on the 64x64 / 128x32 / 128x64 tiles (measured on the 128x128 tiles, whose
+            // kernels sit at the register limit: 3 % slower, tools/r06_epi_ab.sh - they keep the pass-by-pass path below).  Loads and stores share vmcnt on gfx950 and may complete out of order with
+            // each other, so hipcc waits vmcnt(0) for a load whenever a store is pending: with the residual / scale / shift
+            // loads consumed pass by pass (the odd-Cout path below) every pass waited for the previous pass's STORE to
+            // complete - four store round trips in a row per 64x64 tile, sixteen per 128x128 tile - and so did the first LDS
+            // write of the next tile (its operands, prefetched under this epilogue, are loads too).  Here every load goes out
+            // ahead of the staging, ONE compiler-visible wait sits behind the staging barrier, and the stores leave back to
+            // back; invalid rows / columns are out-of-range buffer offsets (no branches).  Same pattern as w44_tail.  A tile
+            // of eight passes WITH a residual takes its residual four passes at a time: one round trip more.
+            constexpr int CH = PASSES < 4 ? PASSES : 4;
+            const size_t out_rows = TMODE ? (size_t)p.N * 4 * p.H * p.W : (size_t)p.M;
+            const unsigned ybytes = (unsigned)(out_rows * p.Cout * 4);
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.resid ? p.resid : p.y), 0, p.resid ? ybytes : 0u, 0x00020000);    // (no residual: every offset is out of range = zeros)
+            auto off_of = [&](int i) -> unsigned {
+                const int row = m0 + tr + i * RPP;
+                return (cok && row < p.M) ? (unsigned)((out_pixel(row) * p.Cout + col) * 4) : OOB;
+            };
+            f32x4 res[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off_of(i), 0, 0));
+            const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, (unsigned)p.Cout * 4u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, (unsigned)p.Cout * 4u, 0x00020000);
+            const f32x4 sc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, cok ? (unsigned)col * 4u : OOB, 0, 0));
+            const f32x4 sh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sh, cok ? (unsigned)col * 4u : OOB, 0, 0));
+            float* cs = smem;
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        cs[(wm * G::WTM + mi * 32 + row_l + (r & 3) + 8 * (r >> 2)) * G::LDC + wn * G::WTN +
+                           ni * 32 + col_l] = acc[mi][ni][r];
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), visible to hipcc's wait-count pass: every load above has landed
+            __syncthreads();
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < PASSES / CH; ++c) {
+                if (c > 0 && p.resid) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off_of(c * CH + i), 0, 0));
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cs + (tr + (c * CH + i) * RPP) * G::LDC + tc);
+                    v = v * sc + sh;
+                    if (p.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
+                    }
+                    v += res[i];
+                    const unsigned off = off_of(c * CH + i);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, off, 0, 0);
+                    if (STATS) {
+                        if (off != OOB) { s1 += v; s2 += v * v; }
+                    }
+                }
+            }
+            if (STATS) {
+                __syncthreads();                           // every thread is done reading the staged tile
+                float* red = smem;                         // [RPP][2][BN]
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BN + tc) = s1;
+                *reinterpret_cast<f32x4*>(red + (tr * 2 + 1) * BN + tc) = s2;
+                __syncthreads();
+                if (tid < C4 && cok) {                     // (tid < C4  <=>  tr == 0: tc = 4 * tid)
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < RPP; ++k) {
+                        a += *reinterpret_cast<const f32x4*>(red + (k * 2 + 0) * BN + tc);
+                        b += *reinterpret_cast<const f32x4*>(red + (k * 2 + 1) * BN + tc);
+                    }
+                    float* st = p.stats + (size_t)(m0 / BM) * 2 * p.Cout;
+                    *reinterpret_cast<f32x4*>(st + col) = a;
+                    *reinterpret_cast<f32x4*>(st + p.Cout + col) = b;
+                }
+                __syncthreads();                           // (the LDS goes back to the caller)
+            }
+            return;
+        }
+        // ---- the 128x128 tiles, and Cout % 4 != 0 (the detection heads, Cout = 3 * (5 + C): 4-byte-aligned accesses, a
+        // per-element tail for the quad that crosses Cout) ----
         const bool full = col + 3 < p.Cout;      // (cok && !full: the quad that crosses Cout, odd Cout only)
         // residual tile first: its HBM/L2 latency overlaps the LDS staging below
         f32x4 res[PASSES];
@@ -150,6 +237,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                         sh[q] = p.shift[col + q];
                     }
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // (no load of this path stays "pending" for hipcc past the epilogue: see above)
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const int rr = tr + i * RPP;
