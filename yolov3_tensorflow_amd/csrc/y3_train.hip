@@ -191,12 +191,18 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float* __restri
     f32x4* y4 = reinterpret_cast<f32x4*>(y);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C4);
-        f32x4 v = z4[i] * sc4[c] + sh4[c];
+        // (z is not read again before the backward pass: a streaming load leaves the caches to y, which the next conv reads;
+        // measured on the bs=64 step together with the two loads of bn_apply_bwd: 81.63 -> 81.22 ms, profiles/r06_bn_nt_ab.txt)
+        f32x4 v = __builtin_nontemporal_load(z4 + i) * sc4[c] + sh4[c];
         if (act) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
         }
+#ifdef Y3_BN_NT2
+        if (resid) v += __builtin_nontemporal_load(r4 + i);
+#else
         if (resid) v += r4[i];
+#endif
         y4[i] = v;
     }
 }
@@ -215,8 +221,8 @@ __global__ void __launch_bounds__(256) bn_apply_bwd_kernel(const float* __restri
     const int C = C4 * 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
-        const f32x4 v = z4[i];
-        f32x4 g = g4[i];
+        const f32x4 v = __builtin_nontemporal_load(z4 + i);      // (the last reader of z and of dy)
+        f32x4 g = __builtin_nontemporal_load(g4 + i);
         f32x4 out;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -271,6 +271,7 @@ class Feeder(object):
                                  "the workers hand decoded sources to the coordinator")
         self.pixels = pixels
         self._pool = None
+        self._side = None           # (device, side stream, DevicePixels or None)
 
     def _executor(self):
         """The worker pool: one per process and worker count, created on first use and shared by every Feeder (see the
@@ -331,15 +332,21 @@ class Feeder(object):
         plan = self._plan(epoch)
         q = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
-        copy_stream = torch.cuda.Stream(device=dev)
+        # one side stream (and, with pixels='gpu', one set of device tables + pinned blob buffers) per feeder and device, kept
+        # over the epochs: framework.context() caches a y3_ctx per (device, stream)
+        if self._side is None or self._side[0] != dev:
+            self._side = (dev, torch.cuda.Stream(device=dev), None)
+        copy_stream = self._side[1]
 
         pool = self._executor()
 
         on_device = self.pixels == 'gpu'
         device_pixels = None
         if on_device:
-            from .feed_device import DevicePixels
-            device_pixels = DevicePixels(dev)
+            if self._side[2] is None:
+                from .feed_device import DevicePixels
+                self._side = (dev, copy_stream, DevicePixels(dev))
+            device_pixels = self._side[2]
         in_place = self.backend == 'thread'
         buffers = _PinnedBuffers()
         shared = None if in_place else _SharedBuffers()
