@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict
                     s0 += v;
                     s1 += v * v;
                 } else {
+                    // (plain loads: bn_apply_bwd reads both tensors again right behind this kernel, and what the caches keep of
+                    // them counts - streaming loads here cost 0.15-0.35 ms per bs=64 step, profiles/r06_bn_nt_ab.txt)
                     const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * C + 4 * c4);
                     f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + 4 * c4);
 #pragma unroll
@@ -198,11 +200,7 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const float* __restri
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.1f * v[q];
         }
-#ifdef Y3_BN_NT2
         if (resid) v += __builtin_nontemporal_load(r4 + i);
-#else
-        if (resid) v += r4[i];
-#endif
         y4[i] = v;
     }
 }
