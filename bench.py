@@ -402,6 +402,8 @@ def parse_args(argv):
                          "f32_bf16x3: fp32 tensors, every product rebuilt from 6 / 3 bf16 plane products with fp32 "
                          "accumulation")
     ap.add_argument('--batch', type=int, default=None, help="per-GPU batch (default: the workload's BASELINE value)")
+    ap.add_argument('--wgrad-stream', type=int, choices=[0, 1], default=None,
+                    help="c4: backward's weight gradients on a second stream (1) or on the main one (0); default: the package's")
     ap.add_argument('--no-fed', action='store_true', help="c4: skip the repetition of the steps on batches from the feeder")
     ap.add_argument('--head-only', action='store_true', help="c4: update only yolov3/yolov3_head (the reference's "
                                                              "default update_part) instead of the whole model")
@@ -713,6 +715,8 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
     model = y3.yolov3(CLASS_NUM, ANCHORS, batch_norm_decay=0.99, weight_decay=5e-4)
     model.compute_dtype = args.precision
+    if getattr(args, 'wgrad_stream', None) is not None:
+        model.wgrad_stream = bool(args.wgrad_stream)
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda', generator=torch.Generator(device='cuda').manual_seed(100 + rank))
     yt = synthetic_y_true(BATCH, SIZE, CLASS_NUM, ANCHORS, rank, 'cuda')
     with y3.variable_scope('yolov3'):

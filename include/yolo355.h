@@ -454,6 +454,14 @@ int y3_net_train_backward(y3_net* net, const y3_train_var* vars, float* flat_gra
 int y3_net_train_step(y3_net* net, const y3_train_var* vars, const float* x, int n, int h, int w, const float* y_true_1,
                       const float* y_true_2, const float* y_true_3, const y3_train_opts* opts, float* flat_grad,
                       void* workspace, size_t workspace_bytes, float* loss5, y3_grad_ready_fn ready, void* user);
+/* Optional second stream for backward: a layer's weight gradient is off the critical path of the pass (only the optimizer
+ * reads it), its data gradient and the BN backward below it are on it.  With a stream set here (a hipStream_t of the net's
+ * device, not the context's; NULL switches it off) the weight gradients run there, ordered against the context's stream by
+ * events, and overlap the HBM-bound BN passes of the next layer.  Everything the caller sees keeps its stream order: `ready`
+ * for a layer is called once the context's stream has been made to wait for that layer's weight gradient, and backward
+ * returns with the context's stream waiting for all of them.  The workspace is a little larger (one layer's dz lives one
+ * layer longer): size it after this call. */
+int y3_net_train_set_wgrad_stream(y3_net* net, void* stream);
 /* test hook: byte offsets inside the last forward's workspace of layer i's raw conv output z and of its [4][cout]
  * mean / inv_std / folded scale / folded shift (the tensors that fix the LeakyReLU branches); SIZE_MAX for non-BN layers */
 int y3_net_train_saved(const y3_net* net, int layer, size_t* z_offset, size_t* stats_offset);

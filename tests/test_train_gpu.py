@@ -513,6 +513,39 @@ def test_train_step_is_deterministic_and_loss_decreases(isolated_graph):
     assert runs[0][0][-1] < runs[0][0][0]
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f32_wino'])
+def test_weight_gradients_on_the_second_stream_change_no_bit(dtype, isolated_graph):
+    """y3_net_train_set_wgrad_stream (the default of training.Trainer): the same kernels on the same inputs, only on another
+    stream - every loss, every gradient and the order of the `ready` calls must be those of the one-stream pass; the
+    workspace holds one layer's dz one layer longer."""
+    import yolov3_tensorflow_amd as y3
+    from yolov3_tensorflow_amd import training
+    from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
+    from oracle import yolo_ref, train_ref
+    params = yolo_ref.synthetic_params(80, seed=4)
+    x = blob_images(7, 3, 128)
+    yts = train_ref.synthetic_targets(8, 3, [128, 128], 80, COCO_ANCHORS, max_boxes=4)
+    runs = []
+    for side in (False, True, True):
+        model = _fresh_model(params, batch_norm_decay=0.99)
+        model.compute_dtype = dtype
+        model.wgrad_stream = side
+        trainer = training.Trainer(model, config_optimizer('momentum', 1e-3))
+        edges = []
+        with y3.variable_scope('yolov3'):
+            losses = [float(trainer.step(x, yts)[0]) for _ in range(3)]
+            ready = trainer.exchange.ready
+            trainer.exchange.ready = lambda edge: (edges.append(int(edge)), ready(edge))[1]
+            losses.append(float(trainer.step(x, yts)[0]))
+        torch.cuda.synchronize()
+        runs.append((losses, trainer.flat.clone(), edges, model._train['ws'].numel()))
+    for other in runs[1:]:
+        assert other[0] == runs[0][0]
+        assert torch.equal(other[1], runs[0][1])
+        assert other[2] == runs[0][2] and len(other[2]) > 10
+    assert runs[1][3] >= runs[0][3]
+
+
 def test_train_workspace_follows_the_dtype_and_a_small_one_is_refused_before_launch(isolated_graph):
     """(a) the step's workspace is sized per (shape, device, compute_dtype) - the allocation sequence differs
     between 'f32', 'f32_wino' and 'f32_bf16x6' - so switching the mode on a live model must re-size it, and the steps

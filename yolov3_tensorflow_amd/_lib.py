@@ -91,6 +91,7 @@ PROTOTYPES = {
     "y3_net_train_backward": (c_int, [c_void_p, POINTER(TrainVar), c_void_p, GradReadyFn, c_void_p]),
     "y3_net_train_step": (c_int, [c_void_p, POINTER(TrainVar), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                   POINTER(TrainOpts), c_void_p, c_void_p, c_size_t, c_void_p, GradReadyFn, c_void_p]),
+    "y3_net_train_set_wgrad_stream": (c_int, [c_void_p, c_void_p]),
     "y3_net_train_saved": (c_int, [c_void_p, c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "y3_net_set_dtype": (c_int, [c_void_p, c_int]),
     "y3_upsample_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

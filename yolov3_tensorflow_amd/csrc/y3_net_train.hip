@@ -97,9 +97,23 @@ struct y3_train_state {
     std::vector<Buf> z, stats;               // per BN layer: raw conv output, [4][cout] mean / inv_std / scale / shift
     Buf fm_grad[3];                          // d loss / d feature_map_i, [n,g,g,det_pad]
     int fm_tensor[3] = {-1, -1, -1};         // tensor ids of feature maps 1..3 (13-, 26-, 52-grid)
+    // the second stream of backward (y3_net_train_set_wgrad_stream): its context and the events that order it against the
+    // context's stream - "dz of this layer is ready" (main -> side), "this layer's weight gradient is done" (side -> main)
+    y3_ctx* side_ctx = nullptr;
+    void* side_stream = nullptr;
+    static constexpr int NEV = 8;
+    hipEvent_t ev_dz[NEV] = {}, ev_done[NEV] = {};
 };
 
-void y3_train_state_free(y3_train_state* s) { delete s; }
+void y3_train_state_free(y3_train_state* s) {
+    if (!s) return;
+    for (int i = 0; i < y3_train_state::NEV; ++i) {
+        if (s->ev_dz[i]) (void)hipEventDestroy(s->ev_dz[i]);
+        if (s->ev_done[i]) (void)hipEventDestroy(s->ev_done[i]);
+    }
+    if (s->side_ctx) (void)y3_ctx_destroy(s->side_ctx);
+    delete s;
+}
 
 namespace {
 
@@ -336,6 +350,47 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
     const float* ones = A.p(S.ones);
     const float* zeros = A.p(S.zeros);
 
+    // Two streams (y3_net_train_set_wgrad_stream).  A layer's weight gradient is off the critical path - nothing of this pass
+    // reads it - while its data gradient and the BN backward of the layer below are on it: the weight gradient goes to the
+    // side stream behind "dz ready", and the context's stream waits for it only one layer later, just before the buffers it
+    // read go back to the arena (their release, and the layer's `ready` call, are deferred by that one layer; the dry run
+    // defers alike, so the workspace is sized for it).  What overlaps: a matrix-pipe-bound weight gradient with the HBM-bound
+    // BN passes of the next layer.
+    const bool two = net->wgrad_stream != nullptr;
+    y3_ctx* sctx = ctx;
+    if (two && !dry) {
+        if (S.side_ctx && S.side_stream != net->wgrad_stream) { (void)y3_ctx_destroy(S.side_ctx); S.side_ctx = nullptr; }
+        if (!S.side_ctx) {
+            if (int rc = y3_ctx_create(ctx->device, net->wgrad_stream, &S.side_ctx)) return rc;
+            S.side_stream = net->wgrad_stream;
+        }
+        for (int e = 0; e < y3_train_state::NEV; ++e) {
+            if (!S.ev_dz[e]) Y3_CHECK_HIP(hipEventCreateWithFlags(&S.ev_dz[e], hipEventDisableTiming));
+            if (!S.ev_done[e]) Y3_CHECK_HIP(hipEventCreateWithFlags(&S.ev_done[e], hipEventDisableTiming));
+        }
+        sctx = S.side_ctx;
+    }
+#ifndef Y3_WGRAD_DEPTH
+#define Y3_WGRAD_DEPTH 1            // layers a weight gradient may lag behind the main stream (measured: profiles/r06_wgrad_stream_ab.txt)
+#endif
+    static_assert(Y3_WGRAD_DEPTH >= 1 && Y3_WGRAD_DEPTH < y3_train_state::NEV, "one event pair per weight gradient in flight");
+    struct Deferred {
+        Buf a, b;                       // buffers the weight gradient read: released once the main stream waits for it
+        hipEvent_t done = nullptr;
+        long long g_end = -1;
+    };
+    std::vector<Deferred> pend;         // oldest first
+    int flip = 0;
+    auto flush_oldest = [&]() -> int {
+        Deferred q = pend.front();
+        pend.erase(pend.begin());
+        if (!dry && q.done) Y3_CHECK_HIP(hipStreamWaitEvent(ctx->stream, q.done, 0));
+        if (q.a.ok()) A.release(q.a);
+        if (q.b.ok()) A.release(q.b);
+        if (ready && q.g_end >= 0 && !dry) ready(user, q.g_end);
+        return Y3_OK;
+    };
+
     // grads[t] (+)= src[:, offset : offset + c]
     auto accumulate_into = [&](int t, const float* src, int src_channels, int offset, long long rows, int c) -> int {
         if (!have[t]) { grads[t] = A.alloc(tbytes(t)); own[t] = 1; }
@@ -398,13 +453,21 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
             w_d = A.p(w_d_buf);
         }
         const float* dz = A.p(dz_buf);
+        const bool on_side = two && trainable(v.g_weights);
         if (trainable(v.g_weights)) {
+            if (on_side && !dry) {
+                Y3_CHECK_HIP(hipEventRecord(S.ev_dz[flip], ctx->stream));
+                Y3_CHECK_HIP(hipStreamWaitEvent(sctx->stream, S.ev_dz[flip], 0));
+            }
+            y3_ctx* wctx = on_side ? sctx : ctx;
             if (net->dtype == 4 && y3_conv_wgrad_wino_eligible(&d) == 1)
-                Y3_TRY(y3_conv_wgrad_wino(ctx, &d, xin, dz, dz_stride, gptr(v.g_weights), A.p(S.wgrad_sc), S.wgrad_sc.bytes));
+                Y3_TRY(y3_conv_wgrad_wino(wctx, &d, xin, dz, dz_stride, gptr(v.g_weights), A.p(S.wgrad_sc), S.wgrad_sc.bytes));
             else
-                Y3_TRY(y3_conv_wgrad(ctx, &d, xin, dz, dz_stride, gptr(v.g_weights), A.p(S.wgrad_sc), S.wgrad_sc.bytes));
+                Y3_TRY(y3_conv_wgrad(wctx, &d, xin, dz, dz_stride, gptr(v.g_weights), A.p(S.wgrad_sc), S.wgrad_sc.bytes));
+            if (on_side && !dry) Y3_CHECK_HIP(hipEventRecord(S.ev_done[flip], sctx->stream));
         }
-        if (ready && v.g_end >= 0 && !dry) ready(user, v.g_end);      // this layer's gradients are complete (enqueued)
+        // this layer's gradients are complete (enqueued) - with two streams: once the main stream waits for the side one (flush)
+        if (!on_side && ready && v.g_end >= 0 && !dry) ready(user, v.g_end);
         const int src = l.src, up = l.up;
         const bool need_src = needs(src), need_up = up >= 0 && needs(up);
         if (need_src || need_up) {
@@ -456,11 +519,28 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
             A.release(wk);
         }
         A.release(w_d_buf);
-        // the consumed gradient goes back to the free list (the loss gradients are not this pass's to free)
-        if (dz_buf.off != dy.off) A.release(dz_buf);
-        if (!dy_given_away && own[dst]) A.release(grads[dst]);
+        // the consumed gradient goes back to the free list (the loss gradients are not this pass's to free) - at once, or, when
+        // the side stream may still be reading it, behind the wait of the NEXT layer's end
+        while ((int)pend.size() >= Y3_WGRAD_DEPTH)
+            if (int rc = flush_oldest()) return rc;
+        Buf rel_a = (dz_buf.off != dy.off) ? dz_buf : Buf();
+        Buf rel_b = (!dy_given_away && own[dst]) ? grads[dst] : Buf();
+        if (on_side) {
+            Deferred q;
+            q.a = rel_a;
+            q.b = rel_b;
+            q.done = dry ? nullptr : S.ev_done[flip];
+            q.g_end = v.g_end;
+            pend.push_back(q);
+            flip = (flip + 1) % y3_train_state::NEV;
+        } else {
+            if (rel_a.ok()) A.release(rel_a);
+            if (rel_b.ok()) A.release(rel_b);
+        }
         grads[dst] = Buf();
     }
+    while (!pend.empty())
+        if (int rc = flush_oldest()) return rc;
     if (!dry && A.overflow) { y3_set_error("y3_net_train_backward: workspace too small"); return Y3_EINVAL; }
     return Y3_OK;
 }
@@ -486,6 +566,12 @@ int check_vars(const char* who, const y3_net* net, const y3_train_var* vars) {
 }
 
 }  // namespace
+
+extern "C" int y3_net_train_set_wgrad_stream(y3_net* net, void* stream) {
+    Y3_CHECK_ARG(net, "y3_net_train_set_wgrad_stream: null net");
+    net->wgrad_stream = stream;
+    return Y3_OK;
+}
 
 extern "C" size_t y3_net_train_workspace_bytes(y3_net* net, const y3_train_var* vars, int n, int h, int w) {
     if (check_common("y3_net_train_workspace_bytes", net, n, h, w) != Y3_OK || !vars) return 0;

@@ -100,7 +100,7 @@ def _train_state(model):
 _TRAIN_DTYPES = {'f32': 0, 'f32_bf16x6': 2, 'f32_bf16x3': 3, 'f32_wino': 4}
 
 
-def _train_net(model, ctx):
+def _train_net(model, ctx, dev=None):
     """The y3_net handle the train step runs on (one per model; its dtype follows model.compute_dtype at every call: the
     dtype only selects kernels, the state a forward leaves is the same in every mode)."""
     st = _train_state(model)
@@ -115,6 +115,14 @@ def _train_net(model, ctx):
     if st.get('net_dtype') != mode:
         _lib.check(L.y3_net_set_dtype(st['net'], _TRAIN_DTYPES[mode]))
         st['net_dtype'] = mode
+    # backward's second stream (include/yolo355.h: y3_net_train_set_wgrad_stream): on unless model.wgrad_stream is False
+    want = bool(getattr(model, 'wgrad_stream', True))
+    if st.get('wgrad_on') != want or st.get('wgrad_net') != st['net'].value:
+        if want and st.get('side_stream') is None:
+            st['side_stream'] = torch.cuda.Stream(device=dev)
+        _lib.check(L.y3_net_train_set_wgrad_stream(st['net'], ctypes.c_void_p(st['side_stream'].cuda_stream) if want else None))
+        st['wgrad_on'], st['wgrad_net'] = want, st['net'].value
+        st['ws_shape'] = None            # (the allocation sequence of backward changes with it)
     return st['net']
 
 
@@ -154,7 +162,7 @@ def _prepare(model, x):
     topo = st['topo']
     L = _lib.lib()
     dev = x.device
-    net = _train_net(model, fw.context(dev))
+    net = _train_net(model, fw.context(dev), dev)
     scope = fw.current_scope_name()
     layer_vars = model._ensure_variables(scope, [(l['k'], l['stride'], l['cin'], l['cout'], l['bn'])
                                                  for l in topo.layers])
@@ -397,7 +405,7 @@ class Trainer(object):
         if not st.get('have_loss') or st.get('fms') is None:
             raise RuntimeError('backward needs forward(is_training=True) and compute_loss first')
         dev = st['fms'][0].device
-        net = _train_net(self.model, fw.context(dev))         # (the mode may have changed since the forward)
+        net = _train_net(self.model, fw.context(dev), dev)         # (the mode may have changed since the forward)
         arr = self._vars(st['layer_vars'], dev)
         self.exchange.begin()
         _lib.check(_lib.lib().y3_net_train_backward(net, arr, fw.ptr(self.flat), self._ready_cb(), None))
