@@ -570,7 +570,7 @@ def slim(res):
     if res is None or 'error' in res:
         return res
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'dtype', 'precision', 'scaling',
-            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data', 'fed', 'host_cpu_ms_per_image')
+            'config', 'roofline', 'loss', 'peak_mem_gb', 'regimes', 'data', 'fed', 'host_cpu_ms_per_image', 'wgrad_stream')
     return {k: res[k] for k in keep if k in res}
 
 
@@ -715,8 +715,6 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
     from yolov3_tensorflow_amd.utils.misc_utils import config_optimizer
     model = y3.yolov3(CLASS_NUM, ANCHORS, batch_norm_decay=0.99, weight_decay=5e-4)
     model.compute_dtype = args.precision
-    if getattr(args, 'wgrad_stream', None) is not None:
-        model.wgrad_stream = bool(args.wgrad_stream)
     x = torch.rand((BATCH, SIZE, SIZE, 3), device='cuda', generator=torch.Generator(device='cuda').manual_seed(100 + rank))
     yt = synthetic_y_true(BATCH, SIZE, CLASS_NUM, ANCHORS, rank, 'cuda')
     with y3.variable_scope('yolov3'):
@@ -725,10 +723,16 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
         upd = None
         if args.head_only:
             upd = [v for v in y3.global_variables(scope='yolov3') if v.op_name.startswith('yolov3/yolov3_head')]
+        ws_arg = getattr(args, 'wgrad_stream', None)
         trainer = training.Trainer(model, config_optimizer('sgd', 1e-4), update_vars=upd,
-                                   process_group=dist.group.WORLD if distributed and world > 1 else None)
-        for _ in range(args.warmup):
+                                   process_group=dist.group.WORLD if distributed and world > 1 else None,
+                                   wgrad_stream='auto' if ws_arg is None else bool(ws_arg))
+        # warm-up: the W asked for, and (default) the seven steps in which the Trainer measures its second stream against one
+        # stream and settles on the faster (training.Trainer: wgrad_stream='auto'; the choice is reported below)
+        done = 0
+        while done < args.warmup or trainer.wgrad_choice is None:
             loss = trainer.step(x, yt)
+            done += 1
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -800,6 +804,8 @@ def run_train(args, y3, torch, dist, rank, world, distributed, barrier, max_over
                                "count) over the step time, BN / loss / update kernels included in the time; "
                                "achieved_algorithmic counts direct-convolution FLOPs"},
         "loss": round(loss0, 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+        "wgrad_stream": {"on": bool(trainer.wgrad_choice), "how": "measured by the Trainer in its first steps" if ws_arg is None else "forced",
+                         "calibration_ms": getattr(trainer, 'wgrad_calibration', None)},
         "fed": fed if fed is None or "error" in fed
         else dict(fed, images_per_s=round(world * BATCH / (fed["ms_per_step"] * 1e-3), 2)),
     }

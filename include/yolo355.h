@@ -460,7 +460,12 @@ int y3_net_train_step(y3_net* net, const y3_train_var* vars, const float* x, int
  * events, and overlap the HBM-bound BN passes of the next layer.  Everything the caller sees keeps its stream order: `ready`
  * for a layer is called once the context's stream has been made to wait for that layer's weight gradient, and backward
  * returns with the context's stream waiting for all of them.  The workspace is a little larger (one layer's dz lives one
- * layer longer): size it after this call. */
+ * layer longer): size it after this call.  Y3_OWN_STREAM: the library creates (once per net, destroyed with it) a stream of
+ * the device's LOWEST priority for it - the recommended form: the weight gradient is the work that can wait, and a stream
+ * of another priority cannot share the hardware queue of the context's stream (an ordinary stream of the caller's can,
+ * once enough streams are alive in the process; the event waits then serialise inside one queue and the step gets slower
+ * than on one stream). */
+#define Y3_OWN_STREAM ((void*)(size_t)1)
 int y3_net_train_set_wgrad_stream(y3_net* net, void* stream);
 /* test hook: byte offsets inside the last forward's workspace of layer i's raw conv output z and of its [4][cout]
  * mean / inv_std / folded scale / folded shift (the tensors that fix the LeakyReLU branches); SIZE_MAX for non-BN layers */

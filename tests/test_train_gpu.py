@@ -526,11 +526,10 @@ def test_weight_gradients_on_the_second_stream_change_no_bit(dtype, isolated_gra
     x = blob_images(7, 3, 128)
     yts = train_ref.synthetic_targets(8, 3, [128, 128], 80, COCO_ANCHORS, max_boxes=4)
     runs = []
-    for side in (False, True, True):
+    for side in (False, True, torch.cuda.Stream()):          # off / the library's low-priority stream / a stream of the caller's
         model = _fresh_model(params, batch_norm_decay=0.99)
         model.compute_dtype = dtype
-        model.wgrad_stream = side
-        trainer = training.Trainer(model, config_optimizer('momentum', 1e-3))
+        trainer = training.Trainer(model, config_optimizer('momentum', 1e-3), wgrad_stream=side)
         edges = []
         with y3.variable_scope('yolov3'):
             losses = [float(trainer.step(x, yts)[0]) for _ in range(3)]
@@ -539,6 +538,14 @@ def test_weight_gradients_on_the_second_stream_change_no_bit(dtype, isolated_gra
             losses.append(float(trainer.step(x, yts)[0]))
         torch.cuda.synchronize()
         runs.append((losses, trainer.flat.clone(), edges, model._train['ws'].numel()))
+    # ... and 'auto' (the default) measures both in its first seven steps and settles on one of them
+    model = _fresh_model(params, batch_norm_decay=0.99)
+    model.compute_dtype = dtype
+    trainer = training.Trainer(model, config_optimizer('momentum', 1e-3))
+    with y3.variable_scope('yolov3'):
+        losses = [float(trainer.step(x, yts)[0]) for _ in range(8)]
+    assert trainer.wgrad_choice in (True, False) and set(trainer.wgrad_calibration) == {'ms_with', 'ms_without'}
+    assert losses[:4] == runs[0][0]
     for other in runs[1:]:
         assert other[0] == runs[0][0]
         assert torch.equal(other[1], runs[0][1])

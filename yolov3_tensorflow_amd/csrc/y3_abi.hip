@@ -367,6 +367,7 @@ extern "C" int y3_net_destroy(y3_net* net) {
         for (auto& set : net->event_sets)
             for (hipEvent_t e : set) (void)hipEventDestroy(e);
         if (net->train) y3_train_state_free(net->train);
+        if (net->own_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(net->own_stream));
         delete net;
     }
     return Y3_OK;

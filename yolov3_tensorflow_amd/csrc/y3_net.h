@@ -28,6 +28,7 @@ struct y3_net {
     int class_num;
     y3_train_state* train = nullptr;
     void* wgrad_stream = nullptr;   // y3_net_train_set_wgrad_stream: the weight gradients of backward run on this stream (nullptr: on the context's)
+    void* own_stream = nullptr;     // the low-priority stream y3_net_train_set_wgrad_stream(net, Y3_OWN_STREAM) created (destroyed with the net)
     int dtype = 0;            // 0: fp32 (exact fp32 MFMA), 1: bf16 storage with fp32 accumulation,
                               // 2 / 3: fp32 tensors, products rebuilt from 3 / 2 bf16 planes (y3_conv_split.hip)
                               // 4: fp32, Winograd F(2x2,3x3) kernel for the layers y3_conv_wino_eligible accepts

@@ -569,6 +569,28 @@ int check_vars(const char* who, const y3_net* net, const y3_train_var* vars) {
 
 extern "C" int y3_net_train_set_wgrad_stream(y3_net* net, void* stream) {
     Y3_CHECK_ARG(net, "y3_net_train_set_wgrad_stream: null net");
+    if (stream == Y3_OWN_STREAM) {
+        // A stream of the LOWEST priority, created here: (1) the weight gradient is the work that can wait - where the two
+        // streams compete, the critical path should win; (2) a stream of another priority gets a hardware queue of its own.
+        // Measured why (2) matters: a caller's ordinary stream can land on the hardware queue of the context's stream once
+        // enough streams are alive in the process (bench.py's default line: c2, detect and c5 each leave two behind) - the
+        // event waits between the two then serialise INSIDE one queue: 96 ms per step instead of 79.6
+        // (profiles/r06_wgrad_stream_ab.txt).
+        if (!net->own_stream) {
+            if (!net->ctx) { y3_set_error("y3_net_train_set_wgrad_stream: the net was created without a context"); return Y3_ESTATE; }
+            int prev = -1;
+            Y3_CHECK_HIP(hipGetDevice(&prev));
+            Y3_CHECK_HIP(hipSetDevice(net->ctx->device));
+            int least = 0, greatest = 0;
+            hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            hipStream_t s = nullptr;
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+            (void)hipSetDevice(prev);
+            if (e != hipSuccess) { y3_set_error("y3_net_train_set_wgrad_stream: %s", hipGetErrorString(e)); return Y3_EHIP; }
+            net->own_stream = s;
+        }
+        stream = net->own_stream;
+    }
     net->wgrad_stream = stream;
     return Y3_OK;
 }

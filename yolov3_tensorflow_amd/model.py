@@ -23,6 +23,8 @@ N_BODY_CONVS = 52  # utils/layer_utils.py:24-68
 NET_DTYPES = {'f32': 0, 'bf16': 1, 'f32_bf16x6': 2, 'f32_bf16x3': 3, 'f32_wino': 4}
 
 
+_SIDE_STREAMS = {}      # (device index, parts) -> the side streams of yolov3._forward_on_streams, shared by every model
+
 class yolov3(object):
 
     def __init__(self, class_num, anchors, use_label_smooth=False, use_focal_loss=False,
@@ -36,7 +38,6 @@ class yolov3(object):
         self.weight_decay = weight_decay
         self.use_static_shape = use_static_shape
         self._nets = {}   # (ctx key, scope, dtype) -> dict(handle, version, keepalive, workspace)
-        self._side_streams = {}   # (device index, parts) -> side streams of _forward_on_streams
         self.inference_streams = 1    # > 1: inference forwards split the batch over that many HIP streams (opt-in)
         self.img_size = None
         # 'f32' (the reference's precision), 'f32_bf16x6' / 'f32_bf16x3' (fp32 tensors, products on the bf16
@@ -195,7 +196,13 @@ class yolov3(object):
         stream, so per-layer event times are those of undisturbed kernels."""
         dev = x.device
         main = torch.cuda.current_stream(dev)
-        pool = self._side_streams.setdefault((dev.index, ns), [torch.cuda.Stream(device=dev) for _ in range(ns - 1)])
+        # one set of side streams per (device, parts) for the whole PROCESS, not per model: streams beyond the hardware queues
+        # share them (GPU_MAX_HW_QUEUES), and a process that had built five models with a side stream each ran its train step's
+        # second stream on an occupied queue (bench.py's default line: 96 ms per step instead of 79.6, profiles/r06_wgrad_stream_ab.txt)
+        key = (dev.index, ns)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(ns - 1)]
+        pool = _SIDE_STREAMS[key]
         c = x.shape[0] // ns
         self._get_net(dev)                  # (parameters are prepared / packed on the caller's stream, once for all parts)
         for side in pool:

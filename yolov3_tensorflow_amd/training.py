@@ -116,12 +116,15 @@ def _train_net(model, ctx, dev=None):
         _lib.check(L.y3_net_set_dtype(st['net'], _TRAIN_DTYPES[mode]))
         st['net_dtype'] = mode
     # backward's second stream (include/yolo355.h: y3_net_train_set_wgrad_stream): on unless model.wgrad_stream is False
-    want = bool(getattr(model, 'wgrad_stream', True))
-    if st.get('wgrad_on') != want or st.get('wgrad_net') != st['net'].value:
-        if want and st.get('side_stream') is None:
-            st['side_stream'] = torch.cuda.Stream(device=dev)
-        _lib.check(L.y3_net_train_set_wgrad_stream(st['net'], ctypes.c_void_p(st['side_stream'].cuda_stream) if want else None))
-        st['wgrad_on'], st['wgrad_net'] = want, st['net'].value
+    # True: on a low-priority stream the library creates; False: off; a torch.cuda.Stream: on that stream
+    want = getattr(model, 'wgrad_stream', False)
+    handle = (want.cuda_stream if isinstance(want, torch.cuda.Stream) else 1) if want else None       # 1 = Y3_OWN_STREAM
+    key = (handle, st['net'].value)
+    if st.get('wgrad_key') != key:
+        if isinstance(want, torch.cuda.Stream):
+            st['side_stream'] = want        # (kept alive)
+        _lib.check(L.y3_net_train_set_wgrad_stream(st['net'], ctypes.c_void_p(handle) if handle else None))
+        st['wgrad_key'] = key
         st['ws_shape'] = None            # (the allocation sequence of backward changes with it)
     return st['net']
 
@@ -338,8 +341,17 @@ class Trainer(object):
     factor is folded into the clip/update kernel) before clipping."""
 
     def __init__(self, model, optimizer, update_vars=None, clip_norm=CLIP_NORM, process_group=None,
-                 global_step=0.0, bucket_bytes=distributed.DEFAULT_BUCKET_BYTES):
+                 global_step=0.0, bucket_bytes=distributed.DEFAULT_BUCKET_BYTES, wgrad_stream='auto'):
         self.model, self.opt = model, optimizer
+        # backward's weight gradients on a second stream (include/yolo355.h: y3_net_train_set_wgrad_stream): True / False /
+        # a torch.cuda.Stream / 'auto'.  Every result is bit-identical either way; only the step time differs - and by how
+        # much depends on which hardware queue the second stream lands on (with many streams alive in the process it can
+        # share the main stream's: 96 ms per bs=64 step instead of 79.6 against 81 on one stream,
+        # profiles/r06_wgrad_stream_ab.txt).  'auto' therefore MEASURES: steps 3-4 with it, steps 6-7 without (hipEvents
+        # around the step, one host synchronisation each), and keeps the faster; `wgrad_choice` tells which.
+        self.wgrad_stream = wgrad_stream
+        self.wgrad_choice = None if wgrad_stream == 'auto' else wgrad_stream
+        self._calib = dict(step=0, on=[], off=[]) if wgrad_stream == 'auto' else None
         self.update_names = None if update_vars is None else set(v.op_name for v in update_vars)
         self.clip_norm = float(clip_norm)
         self.pg = process_group
@@ -476,6 +488,15 @@ class Trainer(object):
         all-reduce join, L2, clip and update (y3_clip_update_multi)."""
         x = fw.as_device_f32(images)
         self.model.img_size = [int(x.shape[1]), int(x.shape[2])]
+        timing = None
+        if self._calib is not None:
+            k = self._calib['step']
+            self.model.wgrad_stream = k < 4                   # steps 0-3 with the second stream, 4-6 without
+            if k in (2, 3, 5, 6):
+                timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                timing[0].record(torch.cuda.current_stream(x.device))
+        else:
+            self.model.wgrad_stream = self.wgrad_choice
         st, net, layer_vars = _prepare(self.model, x)
         n, h, w, _ = x.shape
         yt = [fw.as_device_f32(y) for y in y_true]
@@ -497,4 +518,15 @@ class Trainer(object):
         if self.capture is not None:
             self._fill_capture(st)
         self.apply_gradients()
+        if self._calib is not None:
+            c = self._calib
+            if timing is not None:
+                timing[1].record(torch.cuda.current_stream(x.device))
+                timing[1].synchronize()
+                (c['on'] if c['step'] < 4 else c['off']).append(timing[0].elapsed_time(timing[1]))
+            c['step'] += 1
+            if c['step'] == 7:
+                self.wgrad_choice = min(c['on']) < 0.995 * min(c['off'])
+                self.wgrad_calibration = dict(ms_with=min(c['on']), ms_without=min(c['off']))
+                self._calib = None
         return [loss5[0], loss5[1], loss5[2], loss5[3], loss5[4]]
