@@ -153,7 +153,8 @@ def test_forward_on_two_streams_equals_one_stream(gpu_model, with_dtype, dtype):
             model.inference_streams = 2
             runs = [[t.clone() for t in model.forward(x, False)] for _ in range(3)]
             torch.cuda.synchronize()
-            assert len(model._side_streams) == 1
+            from yolov3_tensorflow_amd import model as model_module
+            assert len(model_module._SIDE_STREAMS[(x.device.index, 2)]) == 1        # one set per process, shared by every model
             model.set_layer_profiling(True)
             prof = [t.clone() for t in model.forward(x, False)]
             model.set_layer_profiling(False)
