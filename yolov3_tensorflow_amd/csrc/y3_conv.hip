@@ -33,7 +33,7 @@ using namespace y3conv;
 
 // TMODE (compile time, so that the forward instantiations carry none of its state): data gradient of a stride-2
 // conv, one output parity class per launch (see ConvArgs::tmode)
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, bool TMODE, bool STATS = false>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool STREAMK, bool TMODE, bool STATS = false, bool BSTATS = false>
 __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p) {
     using G = Geo<BM, BN, WGM, WGN>;
     constexpr int MI = G::MI, NI = G::NI, WTM = G::WTM, WTN = G::WTN;
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
             // whole tile, or K-steps [0, k) of a cut tile (this worker's last segment): add what the next workers
             // of the group published for it, then the common epilogue
             if (STREAMK && seg_end < tile_end) sk_consume<BM, BN, WGM, WGN>(p, skw, ntiles, S, tile_end, acc);
-            epilogue<BM, BN, WGM, WGN, TMODE, STATS>(p, smem, acc, m0, n0);
+            epilogue<BM, BN, WGM, WGN, TMODE, STATS, BSTATS>(p, smem, acc, m0, n0);
         }
         if (STREAMK || seg_end < item_end) __syncthreads();  // the staging LDS is reused by the next segment
         item = seg_end;
@@ -339,10 +339,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32_kernel(const ConvArgs p)
 
 constexpr int RESIDENT_64 = 1024;      // 64x64-tile workgroups resident at once: four per CU (37 KB of LDS, 72 VGPRs)
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = false, bool STATS = false>
+template <int BM, int BN, int WGM, int WGN, int KS, bool UPCAT, bool TMODE = false, bool STATS = false, bool BSTATS = false>
 int launch_data_parallel(hipStream_t stream, const ConvArgs& a) {
     using G = Geo<BM, BN, WGM, WGN>;
-    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, TMODE, STATS>;
+    auto kern = conv_mfma_f32_kernel<BM, BN, WGM, WGN, KS, UPCAT, false, TMODE, STATS, BSTATS>;
     static bool attr_set[Y3_MAX_DEVICES] = {};  // per instantiation; benign race (idempotent)
     const int dev_ = y3_current_device();
     if (dev_ < 0 || !attr_set[dev_]) {
@@ -380,15 +380,16 @@ int launch_streamk(hipStream_t stream, const ConvArgs& a) {
     return Y3_OK;
 }
 
-template <int KS, bool UPCAT, bool TMODE = false, bool STATS = false>
+template <int KS, bool UPCAT, bool TMODE = false, bool STATS = false, bool BSTATS = false>
 int dispatch_bn(hipStream_t stream, const ConvArgs& a) {
-    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT, TMODE, STATS>(stream, a);
-    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT, TMODE, STATS>(stream, a);
+    if (a.Cout <= 32) return launch_data_parallel<128, 32, 4, 1, KS, UPCAT, TMODE, STATS, BSTATS>(stream, a);
+    if (a.Cout <= 64) return launch_data_parallel<128, 64, 4, 1, KS, UPCAT, TMODE, STATS, BSTATS>(stream, a);
     // 1x1 layers have 8-32 K-steps per tile: 64x64 tiles (37 KB of LDS, 72 VGPRs -> 4 workgroups per CU) hide one
     // tile's prologue/epilogue under its neighbours' MFMAs and quantise the 172-1352-tile grids of the network 4x
     // finer (measured, batch 32: 52x52 -10 %, 26x26 -19 %, 13x13 -21 % against the 128x128 tile)
-    if (KS == 1 && !TMODE) return launch_data_parallel<64, 64, 2, 2, KS, UPCAT, TMODE, STATS>(stream, a);
-    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT, TMODE, STATS>(stream, a);
+    if (KS == 1 && !TMODE) return launch_data_parallel<64, 64, 2, 2, KS, UPCAT, TMODE, STATS, BSTATS>(stream, a);
+    static_assert(!BSTATS || KS == 1, "the fused BN backward reduction exists on the small tiles of the 1x1 data gradient only");
+    return launch_data_parallel<128, 128, 2, 2, KS, UPCAT, TMODE, STATS, BSTATS>(stream, a);
 }
 
 }  // namespace
@@ -433,7 +434,7 @@ int y3_launch_conv(hipStream_t stream, const y3_conv_desc* d, const float* x, co
     ConvArgs a;
     a.x = x; a.xu = x_up; a.w = w; a.scale = scale; a.shift = shift; a.resid = residual; a.y = y;
     a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
-    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr; a.bz = nullptr; a.bvec = nullptr;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;
@@ -489,6 +490,13 @@ int y3_conv_stats_blocks_impl(const y3_conv_desc* d, int wino) {
     return (int)((M + bm - 1) / bm);
 }
 
+int y3_conv_dgrad_stats_blocks_impl(const y3_conv_desc* fwd) {
+    if (!fwd || fwd->k != 1 || fwd->stride != 1 || fwd->c_up != 0 || fwd->cin % 4 != 0) return 0;
+    const long long M = (long long)fwd->n * fwd->h * fwd->w;
+    const int bm = fwd->cin > 64 ? 64 : 128;        // dispatch_bn's tile for Cout' = fwd->cin
+    return (int)((M + bm - 1) / bm);
+}
+
 // Data gradient of a conv layer as a forward conv over dz:
 //   stride 1: dx = conv_same(dz, flip(W)^T)  -> same kernel, weights = the HWIO variable read with reversed taps
 //             ([tap][ci][co] is already "[tap][Cout'=ci][Cin'=co]"), no re-packing;
@@ -509,7 +517,7 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     ConvArgs a;
     a.x = dz; a.xu = nullptr; a.w = w_d; a.scale = ones; a.shift = zeros;
     a.resid = accumulate ? dx : nullptr; a.y = dx; a.partial = nullptr; a.flags = nullptr; a.workers = 0;
-    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr; a.bz = nullptr; a.bvec = nullptr;
     a.wrev = 1; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
     a.N = fwd->n; a.H = Ho; a.W = Wo; a.Cin = dz_stride; a.Cu = 0; a.Cx = dz_stride;
     a.Cout = fwd->cin; a.stride = 1; a.pad = fwd->k / 2; a.act = 0;
@@ -518,7 +526,15 @@ int y3_launch_conv_dgrad(hipStream_t stream, const y3_conv_desc* fwd, const floa
     Y3_CHECK_ARG(M * fwd->cin < (1LL << 29) && (long long)fwd->n * Ho * Wo * dz_stride < (1LL << 29),
                  "y3_conv2d_dgrad: tensor exceeds 2^29 elements (32-bit byte offsets)");
     a.M = (int)M;
-    if (fwd->k == 1) return dispatch_bn<1, false>(stream, a);
+    if (fwd->k == 1) {
+        if (sk && sk->bwd_z) {
+            // this gradient is the dy of a BN layer: its backward reduction rides in the epilogue (y3_sk_opts::bwd_*)
+            Y3_CHECK_ARG(sk->bwd_vec && sk->stats, "y3_conv2d_dgrad: the fused BN reduction needs z, the layer's vectors and the partial rows");
+            a.bz = sk->bwd_z; a.bvec = sk->bwd_vec; a.stats = sk->stats;
+            return dispatch_bn<1, false, false, false, true>(stream, a);
+        }
+        return dispatch_bn<1, false>(stream, a);
+    }
     const bool has_ws = workspace != nullptr && workspace_bytes >= SK_WORKSPACE_BYTES &&
                         ((uintptr_t)workspace & 15) == 0;
     if (fwd->stride == 2) {

@@ -22,6 +22,9 @@ struct ConvArgs {
     int fault;           // stream-K test hook: producers skip raising their flag
     float* stats;        // nullptr, or [ceil(M/BM)][2][Cout]: per row block of the output, the column sums of y and y^2
                          // (batch-norm statistics of the training forward, taken where the tile is already in registers)
+    const float* bz;     // BSTATS instantiations (a data gradient whose output IS the dy of a BN layer): that layer's raw conv
+    const float* bvec;   // output z [M,Cout] and its [4][Cout] mean / inv_std / folded scale / folded shift; `stats` then gets
+                         // the column sums of g' = y * leaky'(z*scale+shift) and g' * (z-mean)*inv_std (the BN backward reduction)
     int N, H, W, Cin, Cu, Cx;
     int Ho, Wo, Cout;
     int stride, pad, act;
@@ -80,7 +83,7 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[NP]) {
 // D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // STATS (training forward only; a template parameter so that the inference instantiations carry none of it): the column
 // sums of y and y^2 over the tile's rows go to p.stats (ConvArgs).
-template <int BM, int BN, int WGM, int WGN, bool TMODE, bool STATS = false>
+template <int BM, int BN, int WGM, int WGN, bool TMODE, bool STATS = false, bool BSTATS = false>
 __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                                          f32x16 (&acc)[Geo<BM, BN, WGM, WGN>::MI][Geo<BM, BN, WGM, WGN>::NI],
                                          int m0, int n0) {
@@ -131,6 +134,22 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off_of(i), 0, 0));
+            // BSTATS: the BN layer's z at the same places, and its per-channel vectors
+            const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(BSTATS ? p.bz : p.y), 0, BSTATS ? ybytes : 0u, 0x00020000);
+            f32x4 zr[BSTATS ? CH : 1];
+            f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = bmu, bsc = bmu, bsh = bmu;
+            if (BSTATS) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    zr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, off_of(i), 0, 0));
+                const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bvec), 0, (unsigned)p.Cout * 16u, 0x00020000);
+                const unsigned vo = cok ? (unsigned)col * 4u : OOB;
+                bmu = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, 0, 0));
+                bis = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, (unsigned)p.Cout * 4u, 0));
+                bsc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, (unsigned)p.Cout * 8u, 0));
+                bsh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, vo, (unsigned)p.Cout * 12u, 0));
+            }
             const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, (unsigned)p.Cout * 4u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, (unsigned)p.Cout * 4u, 0x00020000);
             const f32x4 sc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, cok ? (unsigned)col * 4u : OOB, 0, 0));
@@ -149,10 +168,15 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < PASSES / CH; ++c) {
-                if (c > 0 && p.resid) {
+                if (c > 0 && (p.resid || BSTATS)) {
 #pragma unroll
                     for (int i = 0; i < CH; ++i)
                         res[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off_of(c * CH + i), 0, 0));
+                    if (BSTATS) {
+#pragma unroll
+                        for (int i = 0; i < CH; ++i)
+                            zr[BSTATS ? i : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, off_of(c * CH + i), 0, 0));
+                    }
                     __builtin_amdgcn_s_waitcnt(0x0F70);
                 }
 #pragma unroll
@@ -169,9 +193,28 @@ __device__ __forceinline__ void epilogue(const ConvArgs& p, float* smem,
                     if (STATS) {
                         if (off != OOB) { s1 += v; s2 += v * v; }
                     }
+                    if (BSTATS) {
+                        if (off != OOB) {
+                            const f32x4 z = zr[BSTATS ? i : 0];
+                            f32x4 g = v;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                // the LeakyReLU branch exactly as bn_apply_fwd / bn_apply_bwd take it (y3_train.hip is built
+                                // without FMA contraction): a fused multiply-add here flips the elements that sit on the edge
+                                float u;
+                                {
+#pragma clang fp contract(off)
+                                    u = z[q] * bsc[q] + bsh[q];
+                                }
+                                g[q] = u > 0.f ? g[q] : 0.1f * g[q];
+                            }
+                            s1 += g;
+                            s2 += g * ((z - bmu) * bis);
+                        }
+                    }
                 }
             }
-            if (STATS) {
+            if (STATS || BSTATS) {
                 __syncthreads();                           // every thread is done reading the staged tile
                 float* red = smem;                         // [RPP][2][BN]
                 *reinterpret_cast<f32x4*>(red + (tr * 2 + 0) * BN + tc) = s1;

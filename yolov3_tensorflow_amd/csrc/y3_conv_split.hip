@@ -399,7 +399,7 @@ int check_desc(const y3_conv_desc* d, const void* x_up, const char* who) {
 
 void fill_args(ConvArgs& a, const y3_conv_desc* d) {
     a.partial = nullptr; a.flags = nullptr; a.workers = 0; a.wrev = 0; a.tmode = 0; a.cy = a.cx = 0; a.ntaps = 0;
-    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr;
+    a.err = nullptr; a.spin_limit = 0; a.fault = 0; a.stats = nullptr; a.bz = nullptr; a.bvec = nullptr;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cu = d->c_up; a.Cx = d->cin - d->c_up;
     a.Cout = d->cout; a.stride = d->stride; a.pad = d->k / 2; a.act = d->act;
     a.Ho = d->h / d->stride; a.Wo = d->w / d->stride;

@@ -30,9 +30,20 @@ struct y3_sk_opts {
                                 // inside the workspace and zeroes them itself ahead of the launch
     unsigned* err = nullptr;    // device-visible error word (y3_ctx::err_host) or nullptr
     float* stats = nullptr;     // [y3_conv_stats_blocks][2][cout] column sums of y / y^2 per output row block, or nullptr
+    // y3_launch_conv_dgrad of a 1x1 conv whose output is the dy of a BN layer: that layer's z and its [4][C] mean / inv_std /
+    // scale / shift; `stats` then receives [y3_conv_dgrad_stats_blocks][2][C] partial sums of g' and g' * zhat (the BN backward
+    // reduction, y3_bn_train_bwd_partials consumes them)
+    const float* bwd_z = nullptr;
+    const float* bwd_vec = nullptr;
 };
 // rows of the `stats` output of the exact-fp32 conv launchers for this conv (0: not available); wino != 0: the Winograd kernel
 int y3_conv_stats_blocks_impl(const y3_conv_desc* d, int wino);
+// rows of the fused BN-backward partial sums of the 1x1 data gradient of forward layer `fwd` (0: not available)
+int y3_conv_dgrad_stats_blocks_impl(const y3_conv_desc* fwd);
+// BN backward with the reduction already done: partial = [nblocks][2][c] sums of g' and g' * zhat (scratch: y3_bn_bwd_scratch_bytes)
+int y3_bn_train_bwd_partials(y3_ctx* ctx, const float* z, const float* dy, const float* gamma, const float* scale, const float* shift,
+                             const float* mean, const float* inv_std, long long rows, int c, const float* partial, int nblocks,
+                             float* dgamma, float* dbeta, float* dz, float* scratch);
 #define Y3_ERR_STREAMK_TIMEOUT 1u
 // Test hook: with Y3_STREAMK_FAULT=1 in the environment the producers of a stream-K launch never raise their flag and
 // the consumers give up after 2^10 polls, so the time-out path (error word -> Y3_EHIP) can be exercised.

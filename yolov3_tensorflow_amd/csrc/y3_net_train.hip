@@ -399,6 +399,25 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
         return Y3_OK;
     };
 
+    // The BN backward reduction (column sums of g' and g' * zhat over dy and z) rides in the epilogue of the data gradient
+    // that WRITES that dy, where it can: the gradient of tensor t is complete once its first consumer in forward order - the
+    // last one backward visits - has added its part; if that consumer is a stride-1 1x1 conv on the direct kernel, its data
+    // gradient's epilogue has the finished dy in registers (conv + what the later consumers had left) and reads z beside it.
+    // That is every residual block's output, every yolo-block 3x3 and every stride-2 conv: the large tensors.  The separate
+    // reduction pass (col_reduce<1>: z and dy from memory) is then skipped for that layer.
+#ifndef Y3_BN_FUSE
+#define Y3_BN_FUSE 1
+#endif
+    std::vector<int> first_consumer(nt, -1);
+    for (int li = (int)nl - 1; li >= 0; --li) {
+        const Layer& q = net->layers[li];
+        first_consumer[q.src] = li;
+        if (q.up >= 0) first_consumer[q.up] = li;
+        if (q.resid >= 0) first_consumer[q.resid] = li;
+    }
+    std::vector<Buf> fused_part(nl);
+    std::vector<int> fused_nb(nl, 0);
+
     for (int i = (int)nl - 1; i >= first; --i) {
         const Layer& l = net->layers[i];
         const y3_train_var& v = vars[i];
@@ -434,8 +453,15 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
             float *dgam = gptr(v.g_gamma), *dbet = gptr(v.g_beta);
             if (!dgam || !dbet) tmp = A.alloc((size_t)2 * cout * 4);
             const float* st = A.p(S.stats[i]);
-            Y3_TRY(y3_bn_train_bwd(ctx, A.p(S.z[i]), A.p(dy), v.gamma, st + 2 * cout, st + 3 * cout, st, st + cout, rows, cout,
-                                   dgam ? dgam : A.p(tmp), dbet ? dbet : A.p(tmp) + cout, A.p(dz_buf), A.p(S.bnbwd_sc)));
+            if (fused_nb[i] > 0) {
+                Y3_TRY(y3_bn_train_bwd_partials(ctx, A.p(S.z[i]), A.p(dy), v.gamma, st + 2 * cout, st + 3 * cout, st, st + cout, rows,
+                                                cout, A.p(fused_part[i]), fused_nb[i], dgam ? dgam : A.p(tmp),
+                                                dbet ? dbet : A.p(tmp) + cout, A.p(dz_buf), A.p(S.bnbwd_sc)));
+                A.release(fused_part[i]);
+            } else {
+                Y3_TRY(y3_bn_train_bwd(ctx, A.p(S.z[i]), A.p(dy), v.gamma, st + 2 * cout, st + 3 * cout, st, st + cout, rows, cout,
+                                       dgam ? dgam : A.p(tmp), dbet ? dbet : A.p(tmp) + cout, A.p(dz_buf), A.p(S.bnbwd_sc)));
+            }
             A.release(tmp);
             dz_stride = cout;
         } else {
@@ -513,7 +539,27 @@ int backward_impl(y3_net* net, const y3_train_var* vars, float* flat_grad, y3_gr
                 A.release(dcat);
             } else {
                 if (!have[src]) { grads[src] = A.alloc(tbytes(src)); own[src] = 1; }
-                if (int rc = dgrad(have[src] ? 1 : 0, A.p(grads[src]))) return rc;
+                // src is the output of layer src - 1: fuse its BN backward reduction where this is the last contribution
+                const int pj = src - 1;
+                const int nbf = (!wino44_d && !wino_d && !planes && pj >= first && pj >= 0 && net->layers[pj].bn &&
+                                 first_consumer[src] == i && S.z[pj].ok())
+                                    ? (Y3_BN_FUSE ? y3_conv_dgrad_stats_blocks_impl(&d) : 0) : 0;
+                if (nbf > 0) {
+                    fused_part[pj] = A.alloc((size_t)nbf * 2 * cin * 4);
+                    fused_nb[pj] = nbf;
+                    if (!dry) {
+                        y3_sk_opts o;
+                        o.err = ctx->err_host;
+                        o.stats = A.p(fused_part[pj]);
+                        o.bwd_z = A.p(S.z[pj]);
+                        o.bwd_vec = A.p(S.stats[pj]);
+                        if (int rc = y3_launch_conv_dgrad(ctx->stream, &d, dz, dz_stride, w_d, ones, zeros, have[src] ? 1 : 0,
+                                                          A.p(grads[src]), skp, skb, &o))
+                            return rc;
+                    }
+                } else if (int rc = dgrad(have[src] ? 1 : 0, A.p(grads[src]))) {
+                    return rc;
+                }
                 have[src] = 1;
             }
             A.release(wk);

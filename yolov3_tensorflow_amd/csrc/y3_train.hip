@@ -809,6 +809,23 @@ extern "C" int y3_bn_train_bwd(y3_ctx* ctx, const float* z, const float* dy, con
     return Y3_OK;
 }
 
+int y3_bn_train_bwd_partials(y3_ctx* ctx, const float* z, const float* dy, const float* gamma, const float* scale, const float* shift,
+                             const float* mean, const float* inv_std, long long rows, int c, const float* partial, int nblocks,
+                             float* dgamma, float* dbeta, float* dz, float* scratch) {
+    Y3_CHECK_ARG(ctx && z && dy && gamma && scale && shift && mean && inv_std && dz && scratch && partial && nblocks > 0,
+                 "y3_bn_train_bwd_partials: null argument");
+    Y3_CHECK_ARG(rows > 0 && c > 0 && c % 4 == 0, "y3_bn_train_bwd_partials: bad shape");
+    float* coef = scratch + (size_t)RED_BLOCKS * 2 * c;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(c), dim3(256), 0, ctx->stream, partial, nblocks, c,
+                       (double)rows, gamma, inv_std, dbeta, dgamma, coef);
+    Y3_CHECK_HIP(hipGetLastError());
+    const long long total4 = rows * (c / 4);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, ctx->stream, z, dy, scale, shift,
+                       mean, inv_std, coef, total4, c / 4, dz);
+    Y3_CHECK_HIP(hipGetLastError());
+    return Y3_OK;
+}
+
 extern "C" size_t y3_bn_bwd_scratch_bytes(int c) { return y3_reduce_scratch_bytes(c) + (size_t)3 * (c > 0 ? c : 0) * sizeof(float); }
 
 extern "C" int y3_bias_grad(y3_ctx* ctx, const float* dy, long long rows, int c, float* dbias, float* scratch) {
